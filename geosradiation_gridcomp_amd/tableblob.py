@@ -37,3 +37,26 @@ def read_blob(path):
         out[name] = a
         off += nbytes + ((8 - nbytes % 8) % 8)
     return int(rb), out
+
+
+def write_blob(path, real_bytes, arrays):
+    """Write {name: ndarray} as a GRTB blob (arrays given in Fortran-shape, any memory order)."""
+    with open(path, "wb") as f:
+        f.write(b"GRTB")
+        f.write(np.array([1, real_bytes], dtype="<i4").tobytes())
+
+        def entry(name, kind, ndim, dims, data):
+            f.write(name.encode().ljust(32, b"\0"))
+            f.write(np.array([kind, ndim] + list(dims), dtype="<i4").tobytes())
+            f.write(data)
+            f.write(b"\0" * ((8 - len(data) % 8) % 8))
+
+        for name, a in arrays.items():
+            a = np.asarray(a)
+            if a.dtype.kind in "iu":
+                kind, dt = -4, "<i4"
+            else:
+                kind, dt = real_bytes, ("<f4" if real_bytes == 4 else "<f8")
+            dims = list(a.shape) + [1] * (4 - a.ndim)
+            entry(name, kind, a.ndim, dims, np.asfortranarray(a.astype(dt)).tobytes(order="F"))
+        entry("END", 0, 0, [0, 0, 0, 0], b"")

@@ -1,0 +1,173 @@
+"""oracle/clib.py -- TEST INFRASTRUCTURE.  ctypes driver for oracle/liboracle.so, the plain-C restatement
+of RRTMG_LW + McICA (oracle/lw_oracle_impl.h).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this; the product path never does.
+
+Same array convention as oracle/reflib.py (numpy C-order == reversed Fortran shape).
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+from geosradiation_gridcomp_amd.tableblob import read_blob
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(os.path.dirname(HERE), "geosradiation_gridcomp_amd", "data")
+_lib = None
+_keep = {}     # keeps table arrays alive
+_state = {"f32": None, "f64": None}
+
+LW_IN2D = ["h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr",
+           "cldf", "ciwp", "clwp", "rei", "rel"]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _lib = ctypes.CDLL(so)
+        for sfx in ("f32", "f64"):
+            getattr(_lib, f"oracle_lw_set_table_{sfx}").argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+            getattr(_lib, f"oracle_kiss_to_real_{sfx}").restype = ctypes.c_float if sfx == "f32" else ctypes.c_double
+            _load_tables(sfx)
+            set_inhomogeneity(0, sfx)
+            set_corr_lengths(None, None, sfx)
+    return _lib
+
+
+def _sfx(prec):
+    return {"r4": "f32", "r8": "f64", "f32": "f32", "f64": "f64"}[prec]
+
+
+def dtype_of(prec):
+    return np.float32 if _sfx(prec) == "f32" else np.float64
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _load_tables(sfx):
+    kind = "r4" if sfx == "f32" else "r8"
+    _, t = read_blob(os.path.join(DATA, f"rrtmg_lw_{kind}.grtb"))
+    setter = getattr(_lib, f"oracle_lw_set_table_{sfx}")
+    for name, a in t.items():
+        a = np.asfortranarray(a)
+        flat = np.ascontiguousarray(a.ravel(order="F"))
+        _keep[(sfx, name)] = flat
+        setter(name.encode(), _p(flat))
+
+
+def set_inhomogeneity(ih, prec="f32"):
+    """0 = homogeneous, 1 = beta, 2 = gamma (cloud_condensate_inhomogeneity.F90:45)."""
+    sfx = _sfx(prec)
+    L = _lib if _lib is not None else lib()
+    setter = getattr(L, f"oracle_lw_set_table_{sfx}")
+    if ih == 0:
+        setter(b"xcw", None)
+        return
+    kind = "r4" if sfx == "f32" else "r8"
+    _, t = read_blob(os.path.join(DATA, f"xcw_{'beta' if ih == 1 else 'gamma'}_{kind}.grtb"))
+    flat = np.ascontiguousarray(t["xcw"].ravel(order="F"))
+    _keep[(sfx, "xcw")] = flat
+    setter(b"xcw", _p(flat))
+
+
+# Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
+DEF_ADL = (1.4315, 2.1219, 7.0, -25.584)
+DEF_RDL = (0.72192, 0.78996, 8.5, 40.404)
+
+
+def set_corr_lengths(adl=None, rdl=None, prec="f32"):
+    sfx = _sfx(prec)
+    L = _lib if _lib is not None else lib()
+    dt = dtype_of(sfx)
+    a = np.array(DEF_ADL if adl is None else adl, dtype=dt)
+    r = np.array(DEF_RDL if rdl is None else rdl, dtype=dt)
+    getattr(L, f"oracle_set_corr_lengths_{sfx}")(_p(a), _p(r))
+
+
+def rrtmg_lw(inp, prec="f32", dudTs=True, iceflg=3, liqflg=1, band_output=None, intermediates=False):
+    L = lib()
+    sfx = _sfx(prec)
+    dt = dtype_of(sfx)
+    nlay, ncol = inp["play"].shape
+    a = {k: _c(inp[k], dt) for k in ["play", "plev", "tlay", "tlev", "tsfc", "emis", "tauaer", "zm", "alat"] + LW_IN2D}
+    bo = np.zeros(16, dtype=np.int32) if band_output is None else _c(band_output, np.int32)
+    out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ["uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs"]}
+    out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
+    out["olrb"] = np.zeros((ncol, 16), dtype=dt)
+    out["dolrb_dTs"] = np.zeros((ncol, 16), dtype=dt)
+    inter = [None, None, None]
+    if intermediates:
+        for k, nm in enumerate(("taug", "pfracs", "taucmc")):
+            out[nm] = np.zeros((ncol, 140, nlay), dtype=dt)
+            inter[k] = _p(out[nm])
+    ci = ctypes.c_int
+    rc = getattr(L, f"oracle_rrtmg_lw_{sfx}")(
+        ci(ncol), ci(nlay), ci(1 if dudTs else 0), _p(a["play"]), _p(a["plev"]), _p(a["tlay"]), _p(a["tlev"]),
+        _p(a["tsfc"]), _p(a["emis"]), *[_p(a[k]) for k in LW_IN2D], ci(iceflg), ci(liqflg), _p(a["tauaer"]),
+        _p(a["zm"]), _p(a["alat"]), ci(int(inp["dyofyr"])), ci(int(inp["cloudLM"])), ci(int(inp["cloudMH"])),
+        _p(out["clearCounts"]), _p(out["uflx"]), _p(out["dflx"]), _p(out["uflxc"]), _p(out["dflxc"]),
+        _p(out["duflx_dTs"]), _p(out["duflxc_dTs"]), _p(bo), _p(out["olrb"]), _p(out["dolrb_dTs"]), *inter)
+    out["rc"] = rc
+    return out
+
+
+def mcica(zmid, alat, doy, play, cldfrac, ciwp, clwp, nsubcol, seed_order=(1, 2, 3, 4), cwp_tiny=1e-20, prec="f32"):
+    L = lib()
+    sfx = _sfx(prec)
+    dt = dtype_of(sfx)
+    nlay, ncol = play.shape
+    cldy = np.zeros((ncol, nsubcol, nlay), dtype=np.int32)
+    ci_s = np.zeros((ncol, nsubcol, nlay), dtype=dt); cl_s = np.zeros_like(ci_s)
+    so = np.array(seed_order, dtype=np.int32)
+    ci = ctypes.c_int
+    tiny = ctypes.c_float(cwp_tiny) if sfx == "f32" else ctypes.c_double(cwp_tiny)
+    rc = getattr(L, f"oracle_mcica_{sfx}")(ci(ncol), ci(nsubcol), ci(nlay), _p(_c(zmid, dt)), _p(_c(alat, dt)), ci(int(doy)),
+                                           _p(_c(play, dt)), _p(_c(cldfrac, dt)), _p(_c(ciwp, dt)), _p(_c(clwp, dt)), tiny,
+                                           _p(so), _p(cldy), _p(ci_s), _p(cl_s))
+    if rc:
+        raise RuntimeError(f"oracle_mcica rc={rc}")
+    return cldy, ci_s, cl_s
+
+
+def clearcounts(cldy, cloudLM, cloudMH):
+    L = lib()
+    ncol, nsubcol, nlay = cldy.shape
+    cnt = np.zeros((ncol, 4), dtype=np.int32)
+    ci = ctypes.c_int
+    rc = L.oracle_clearcounts_f32(ci(ncol), ci(nsubcol), ci(nlay), ci(int(cloudLM)), ci(int(cloudMH)), _p(_c(cldy, np.int32)), _p(cnt))
+    if rc:
+        raise RuntimeError("invalid pressure super-layers!")
+    return cnt
+
+
+def kiss_stream(seed4, n, prec="f32"):
+    L = lib()
+    sfx = _sfx(prec)
+    out = np.zeros(n, dtype=dtype_of(sfx))
+    getattr(L, f"oracle_kiss_stream_{sfx}")(_p(np.array(seed4, dtype=np.int32)), ctypes.c_int(n), _p(out))
+    return out
+
+
+def kiss_to_real(kiss, prec="f32"):
+    return getattr(lib(), f"oracle_kiss_to_real_{_sfx(prec)}")(ctypes.c_int32(kiss))
+
+
+def zcw_lookup(cdf, sigma, prec="f32"):
+    L = lib()
+    sfx = _sfx(prec)
+    dt = dtype_of(sfx)
+    c = _c(cdf, dt); s = _c(sigma, dt); z = np.zeros_like(c)
+    getattr(L, f"oracle_zcw_lookup_{sfx}")(ctypes.c_int(c.size), _p(c), _p(s), _p(z))
+    return z
