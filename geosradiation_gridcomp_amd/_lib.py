@@ -1,0 +1,51 @@
+"""Loader for the C-ABI shared library (include/geosrad.h) and its build recipe.
+
+The product has no CPU path: if libgeosrad.so cannot be loaded, or no HIP device is visible, everything
+here raises.  (oracle/ is test infrastructure and is never imported from this package.)
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(CSRC, "libgeosrad.so")
+DATA = os.path.join(HERE, "data")
+
+EXPORTS = [
+    "geosrad_create", "geosrad_destroy", "geosrad_last_error", "geosrad_real_kind", "geosrad_set_chunk",
+    "geosrad_workspace_bytes", "geosrad_set_tables_lw", "geosrad_load_tables_lw", "geosrad_set_inhomogeneity",
+    "geosrad_load_inhomogeneity", "geosrad_set_corr_lengths", "geosrad_rrtmg_lw", "geosrad_rrtmg_lw_dev",
+    "geosrad_check", "geosrad_profile", "geosrad_profile_read", "geosrad_kernel_name", "geosrad_rrtmg_lw_taumol", "geosrad_mcica", "geosrad_clearcounts",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "geosrad.h"))
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", os.path.join(CSRC, "geosrad.hip"), "-o", SO]
+    subprocess.check_call(cmd)
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RuntimeError(f"{SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = ctypes.CDLL(SO)
+        L.geosrad_last_error.restype = ctypes.c_char_p
+        L.geosrad_last_error.argtypes = [ctypes.c_void_p]
+        L.geosrad_workspace_bytes.restype = ctypes.c_size_t
+        L.geosrad_workspace_bytes.argtypes = [ctypes.c_void_p]
+        L.geosrad_kernel_name.restype = ctypes.c_char_p
+        L.geosrad_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
+        _lib = L
+    return _lib

@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's solver interface for the hot path, over the C ABI.
+
+Names, argument order and meaning follow the reference's Fortran entry points so parity tests read like
+calls into the reference:
+
+    rrtmg_lw_ini()                          rrtmg_lw_init.F90:22
+    rrtmg_lw(ncol, nlay, psize, dudTs, ...) rrtmg_lw_rad.F90:15-23
+    generate_stochastic_clouds(...)         cloud_subcol_gen.F90:132-137
+    clearCounts_threeBand(...)              cloud_subcol_gen.F90:611-614
+    set_inhomogeneity / unset_inhomogeneity cloud_condensate_inhomogeneity.F90:45,75
+    initialize_cloud_subcol_gen(...)        cloud_subcol_gen.F90:109-111
+
+Array convention: numpy C-order arrays whose reversed shape is the Fortran shape (Fortran
+``play(ncol,nlay)`` <-> numpy ``(nlay, ncol)``), i.e. byte-identical to what the Fortran caller passes.
+Where the reference would ``error stop`` a ``GeosradInputError`` carrying the reference's message is raised.
+"""
+import ctypes
+import os
+import numpy as np
+from . import _lib
+
+NBNDLW = 16
+NGPTLW = 140
+
+_IN2D = ["h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr",
+         "cldf", "ciwp", "clwp", "rei", "rel"]
+
+
+class GeosradError(RuntimeError):
+    pass
+
+
+class GeosradInputError(GeosradError):
+    """The reference would `error stop` on these inputs."""
+
+
+def _p(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One (GPU, precision) instance of the solver: replaces the reference's module-level state."""
+
+    def __init__(self, real_kind=4, device=0, tables=True):
+        self.L = _lib.lib()
+        self.real_kind = int(real_kind)
+        self.dtype = np.float32 if self.real_kind == 4 else np.float64
+        self.h = ctypes.c_void_p()
+        rc = self.L.geosrad_create(ctypes.byref(self.h), int(device), self.real_kind)
+        if rc:
+            raise GeosradError({2: "no usable HIP device (the product has no CPU fallback)"}.get(rc, f"geosrad_create rc={rc}"))
+        if tables:
+            self.rrtmg_lw_ini()
+
+    def close(self):
+        if self.h:
+            self.L.geosrad_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            msg = self.L.geosrad_last_error(self.h).decode()
+            raise (GeosradInputError if rc == 5 else GeosradError)(msg)
+
+    def _kind(self):
+        return "r4" if self.real_kind == 4 else "r8"
+
+    # ---- initialisation ------------------------------------------------------------------------------
+    def rrtmg_lw_ini(self, path=None):
+        path = path or os.path.join(_lib.DATA, f"rrtmg_lw_{self._kind()}.grtb")
+        self._chk(self.L.geosrad_load_tables_lw(self.h, os.fsencode(path)))
+
+    def set_inhomogeneity(self, ih, path=None):
+        if ih and path is None:
+            path = os.path.join(_lib.DATA, f"xcw_{'beta' if ih == 1 else 'gamma'}_{self._kind()}.grtb")
+        self._chk(self.L.geosrad_load_inhomogeneity(self.h, int(ih), os.fsencode(path) if path else None))
+
+    def unset_inhomogeneity(self):
+        self.set_inhomogeneity(0)
+
+    def initialize_cloud_subcol_gen(self, adl=None, rdl=None):
+        a = (ctypes.c_double * 4)(*adl) if adl is not None else None
+        r = (ctypes.c_double * 4)(*rdl) if rdl is not None else None
+        self._chk(self.L.geosrad_set_corr_lengths(self.h, a, r))
+
+    def set_chunk(self, n):
+        self._chk(self.L.geosrad_set_chunk(self.h, int(n)))
+
+    def workspace_bytes(self):
+        return int(self.L.geosrad_workspace_bytes(self.h))
+
+    # ---- RRTMG_LW, host arrays -------------------------------------------------------------------------
+    def rrtmg_lw(self, ncol, nlay, psize, dudTs, play, plev, tlay, tlev, tsfc, emis,
+                 h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr,
+                 cldf, ciwp, clwp, rei, rel, iceflglw, liqflglw, tauaer, zm, alat, dyofyr, cloudLM, cloudMH,
+                 band_output=None):
+        """Returns dict(uflx,dflx,uflxc,dflxc,duflx_dTs,duflxc_dTs (nlay+1,ncol); clearCounts (4,ncol);
+        olrb,dolrb_dTs (ncol,16))."""
+        dt = self.dtype
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        args2 = [c(x) for x in (h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr,
+                                cldf, ciwp, clwp, rei, rel)]
+        play, plev, tlay, tlev, tsfc, emis, tauaer, zm, alat = map(c, (play, plev, tlay, tlev, tsfc, emis, tauaer, zm, alat))
+        assert play.shape == (nlay, ncol) and plev.shape == (nlay + 1, ncol)
+        out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs")}
+        out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
+        out["olrb"] = np.zeros((ncol, NBNDLW), dtype=dt)
+        out["dolrb_dTs"] = np.zeros((ncol, NBNDLW), dtype=dt)
+        bo = np.zeros(NBNDLW, dtype=np.int32) if band_output is None else np.ascontiguousarray(band_output, dtype=np.int32)
+        ci = ctypes.c_int
+        rc = self.L.geosrad_rrtmg_lw(
+            self.h, ci(ncol), ci(nlay), ci(psize), ci(1 if dudTs else 0), _p(play), _p(plev), _p(tlay), _p(tlev), _p(tsfc),
+            _p(emis), *[_p(a) for a in args2[:10]], *[_p(a) for a in args2[10:]], ci(iceflglw), ci(liqflglw), _p(tauaer),
+            _p(zm), _p(alat), ci(int(dyofyr)), ci(int(cloudLM)), ci(int(cloudMH)), _p(out["clearCounts"]), _p(out["uflx"]),
+            _p(out["dflx"]), _p(out["uflxc"]), _p(out["dflxc"]), _p(out["duflx_dTs"]), _p(out["duflxc_dTs"]), _p(bo),
+            _p(out["olrb"]), _p(out["dolrb_dTs"]))
+        self._chk(rc)
+        return out
+
+    def rrtmg_lw_columns(self, inp, psize=4, dudTs=True, iceflg=3, liqflg=1, band_output=None):
+        """Convenience: `inp` as produced by synth.make_columns."""
+        nlay, ncol = inp["play"].shape
+        return self.rrtmg_lw(ncol, nlay, psize, dudTs, inp["play"], inp["plev"], inp["tlay"], inp["tlev"], inp["tsfc"],
+                             inp["emis"], *[inp[k] for k in _IN2D], iceflg, liqflg, inp.get("tauaer"), inp["zm"],
+                             inp["alat"], inp["dyofyr"], inp["cloudLM"], inp["cloudMH"], band_output=band_output)
+
+    def rrtmg_lw_taumol(self, inp):
+        """(taug, pfracs) numpy (ncol,140,nlay) == Fortran (nlay,140,ncol), as left by the reference's taumol."""
+        dt = self.dtype
+        nlay, ncol = inp["play"].shape
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        a = {k: c(inp[k]) for k in ["play", "plev", "tlay", "tlev", "tsfc", "emis", "tauaer"] + _IN2D[:10]}
+        taug = np.zeros((ncol, NGPTLW, nlay), dtype=dt); pfr = np.zeros_like(taug)
+        rc = self.L.geosrad_rrtmg_lw_taumol(self.h, ctypes.c_int(ncol), ctypes.c_int(nlay), _p(a["play"]), _p(a["plev"]),
+                                            _p(a["tlay"]), _p(a["tlev"]), _p(a["tsfc"]), _p(a["emis"]),
+                                            *[_p(a[k]) for k in _IN2D[:10]], _p(a["tauaer"]), _p(taug), _p(pfr))
+        self._chk(rc)
+        return taug, pfr
+
+    # ---- RRTMG_LW, device pointers (bench / drivers that keep data in HBM) -------------------------------------
+    def rrtmg_lw_dev(self, stream, ncol, nlay, dudTs, ptr, iceflg, liqflg, dyofyr, cloudLM, cloudMH, band_output=None):
+        """`ptr`: dict name -> device address (int) for every argument array of rrtmg_lw (inputs and outputs)."""
+        bo = np.zeros(NBNDLW, dtype=np.int32) if band_output is None else np.ascontiguousarray(band_output, dtype=np.int32)
+        v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
+        ci = ctypes.c_int
+        rc = self.L.geosrad_rrtmg_lw_dev(
+            self.h, ctypes.c_void_p(stream), ci(ncol), ci(nlay), ci(4), ci(1 if dudTs else 0), v("play"), v("plev"), v("tlay"),
+            v("tlev"), v("tsfc"), v("emis"), *[v(k) for k in _IN2D[:10]], *[v(k) for k in _IN2D[10:]], ci(iceflg), ci(liqflg),
+            v("tauaer"), v("zm"), v("alat"), ci(int(dyofyr)), ci(int(cloudLM)), ci(int(cloudMH)), v("clearCounts"), v("uflx"),
+            v("dflx"), v("uflxc"), v("dflxc"), v("duflx_dTs"), v("duflxc_dTs"), _p(bo), v("olrb"), v("dolrb_dTs"))
+        self._chk(rc)
+
+    def profile(self, enable=True):
+        self._chk(self.L.geosrad_profile(self.h, ctypes.c_int(1 if enable else 0)))
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
+        out = {}
+        for k in range(6):
+            ms = ctypes.c_double(); n = ctypes.c_long()
+            self._chk(self.L.geosrad_profile_read(self.h, ctypes.c_int(k), ctypes.byref(ms), ctypes.byref(n)))
+            out[self.L.geosrad_kernel_name(ctypes.c_int(k)).decode()] = (ms.value, n.value)
+        return out
+
+    def check(self, stream=0):
+        self._chk(self.L.geosrad_check(self.h, ctypes.c_void_p(stream)))
+
+    # ---- McICA ---------------------------------------------------------------------------------------------
+    def generate_stochastic_clouds(self, ncol, nsubcol, nlay, zmid, alat, doy, play, cldfrac, ciwp, clwp, cwp_tiny,
+                                   seed_order=(1, 2, 3, 4)):
+        """Inputs in the solver-API layout, numpy (nlay,ncol).  Returns cldy (int32), ciwp_stoch, clwp_stoch as numpy
+        (ncol,nsubcol,nlay) == Fortran (nlay,nsubcol,ncol)."""
+        dt = self.dtype
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        zmid, alat, play, cldfrac, ciwp, clwp = map(c, (zmid, alat, play, cldfrac, ciwp, clwp))
+        cldy = np.zeros((ncol, nsubcol, nlay), dtype=np.int32)
+        ci_s = np.zeros((ncol, nsubcol, nlay), dtype=dt); cl_s = np.zeros_like(ci_s)
+        so = (ctypes.c_int32 * 4)(*[int(s) for s in seed_order])
+        rc = self.L.geosrad_mcica(self.h, ctypes.c_int(ncol), ctypes.c_int(nsubcol), ctypes.c_int(nlay), _p(zmid), _p(alat),
+                                  ctypes.c_int(int(doy)), _p(play), _p(cldfrac), _p(ciwp), _p(clwp), ctypes.c_double(cwp_tiny),
+                                  so, _p(cldy), _p(ci_s), _p(cl_s))
+        self._chk(rc)
+        return cldy, ci_s, cl_s
+
+    def clearCounts_threeBand(self, ncol, nsubcol, nlay, cloudLM, cloudMH, cldy_stoch):
+        cldy = np.ascontiguousarray(cldy_stoch, dtype=np.int32)
+        cnt = np.zeros((ncol, 4), dtype=np.int32)
+        rc = self.L.geosrad_clearcounts(self.h, ctypes.c_int(ncol), ctypes.c_int(nsubcol), ctypes.c_int(nlay),
+                                        ctypes.c_int(int(cloudLM)), ctypes.c_int(int(cloudMH)), _p(cldy), _p(cnt))
+        self._chk(rc)
+        return cnt

@@ -1,0 +1,773 @@
+// geosrad.hip -- C-ABI (include/geosrad.h) of the MI355X-native radiation hot path: context, coefficient
+// table upload (GRTB blobs -> GPU-friendly layouts), HBM workspace, kernel launches.
+// There is deliberately NO CPU fallback: without a HIP device geosrad_create() fails with GEOSRAD_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/geosrad.h"
+#include "lw_device.hpp"
+#include "lw_kernels.hpp"
+#include "mcica_kernels.hpp"
+
+using namespace geosrad;
+
+namespace {
+
+struct BlobEntry { int kind, ndim, dims[4]; const char *data; size_t count; };
+struct Blob {
+    int realbytes = 0;
+    std::map<std::string, BlobEntry> e;
+    std::string err;
+    bool parse(const void *blob, size_t nbytes)
+    {
+        const char *b = (const char *)blob;
+        if (nbytes < 12 || memcmp(b, "GRTB", 4) != 0) { err = "not a GRTB blob"; return false; }
+        int32_t ver, rb;
+        memcpy(&ver, b + 4, 4); memcpy(&rb, b + 8, 4);
+        if (ver != 1 || (rb != 4 && rb != 8)) { err = "unsupported GRTB version / real size"; return false; }
+        realbytes = rb;
+        size_t off = 12;
+        while (true) {
+            if (off + 56 > nbytes) { err = "truncated GRTB blob"; return false; }
+            char name[33]; memcpy(name, b + off, 32); name[32] = 0;
+            int32_t h[6]; memcpy(h, b + off + 32, 24);
+            off += 56;
+            if (!strcmp(name, "END")) break;
+            BlobEntry en; en.kind = h[0]; en.ndim = h[1];
+            size_t cnt = 1;
+            for (int k = 0; k < 4; k++) { en.dims[k] = h[2 + k]; if (k < en.ndim) cnt *= (size_t)h[2 + k]; }
+            en.count = cnt; en.data = b + off;
+            size_t nb = cnt * (size_t)(en.kind < 0 ? -en.kind : en.kind);
+            if (off + nb > nbytes) { err = "truncated GRTB blob"; return false; }
+            off += nb + ((8 - nb % 8) % 8);
+            e[name] = en;
+        }
+        return true;
+    }
+};
+
+#define HIPCHK(call)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) { return fail(GEOSRAD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+
+static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr",
+                                       "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel",
+                                       "plev", "tsfc", "emis", "tauaer"};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+struct geosrad_ctx {
+    int device = 0, real_kind = 4, chunk = 131072;
+    std::string last_error;
+    hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
+    // optional per-kernel timing with HIP events recorded on the launch stream (geosrad_profile*)
+    bool profiling = false;
+    struct Span { int kid; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> evpool;
+    double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t getev()
+    {
+        hipEvent_t e = nullptr;
+        if (!evpool.empty()) { e = evpool.back(); evpool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    }
+    void span_begin(int kid, hipStream_t st)
+    {
+        if (!profiling) return;
+        Span s{kid, getev(), getev()};
+        (void)hipEventRecord(s.a, st);
+        spans.push_back(s);
+    }
+    void span_end(hipStream_t st) { if (profiling && !spans.empty()) (void)hipEventRecord(spans.back().b, st); }
+    void prof_collect()
+    {
+        for (auto &s : spans) {
+            float ms = 0;
+            if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { prof_ms[s.kid] += ms; prof_n[s.kid]++; }
+            evpool.push_back(s.a); evpool.push_back(s.b);
+        }
+        spans.clear();
+    }
+    int fail(int code, const std::string &msg) { last_error = msg; return code; }
+    virtual ~geosrad_ctx() {}
+    virtual int set_tables_lw(const void *blob, size_t n) = 0;
+    virtual int set_inhomogeneity(int ih, const void *blob, size_t n) = 0;
+    virtual int set_corr(const double *adl, const double *rdl) = 0;
+    virtual size_t workspace_bytes() const = 0;
+    virtual int lw_dev(hipStream_t st, int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr,
+                       int cloudLM, int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output,
+                       void *dbg_taug, void *dbg_pfracs) = 0;
+    virtual int lw_host(int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr, int cloudLM,
+                        int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output, void *taug,
+                        void *pfracs) = 0;
+    virtual int mcica_host(int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
+                           const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so,
+                           int32_t *cldy, void *ciwp_s, void *clwp_s) = 0;
+    virtual int check(hipStream_t st) = 0;
+};
+
+// order of the `in` pointer array of lw_dev / lw_host
+enum LwIn { I_PLAY, I_PLEV, I_TLAY, I_TLEV, I_TSFC, I_EMIS, I_H2O, I_O3, I_CO2, I_CH4, I_N2O, I_O2, I_CFC11, I_CFC12, I_CFC22,
+            I_CCL4, I_CLDF, I_CIWP, I_CLWP, I_REI, I_REL, I_TAUAER, I_ZM, I_ALAT, I_NIN };
+enum LwOutIx { O_UFLX, O_DFLX, O_UFLXC, O_DFLXC, O_DUFLX, O_DUFLXC, O_OLRB, O_DOLRB, O_NOUT };
+
+namespace {
+
+template <typename R> struct Ctx : geosrad_ctx {
+    using R2 = typename Vec2<R>::T;
+    // tables
+    char *d_tab = nullptr; size_t tab_bytes = 0;
+    char *d_xcw = nullptr; size_t xcw_bytes = 0;
+    LwDev<R> h_T{};            // host copy (device pointers inside)
+    LwDev<R> *d_T = nullptr;
+    bool have_lw = false;
+    // workspace
+    char *d_ws = nullptr; size_t ws_bytes = 0; int ws_ncol = 0, ws_nlay = 0;
+    uint32_t *d_err = nullptr;
+    // staging for host-pointer entry points
+    char *d_io = nullptr; size_t io_bytes = 0;
+
+    Ctx() { for (int i = 0; i < 4; i++) { h_T.aam[i] = 0; h_T.ram[i] = 0; } }
+    ~Ctx() override
+    {
+        if (d_tab) (void)hipFree(d_tab);
+        if (d_xcw) (void)hipFree(d_xcw);
+        if (d_T) (void)hipFree(d_T);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_err) (void)hipFree(d_err);
+        if (d_io) (void)hipFree(d_io);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int init()
+    {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipMalloc((void **)&d_err, 256));
+        HIPCHK(hipMemset(d_err, 0, 256));
+        HIPCHK(hipMalloc((void **)&d_T, sizeof(LwDev<R>)));
+        // Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
+        const double adl[4] = {1.4315, 2.1219, 7., -25.584}, rdl[4] = {0.72192, 0.78996, 8.5, 40.404};
+        for (int i = 0; i < 4; i++) { h_T.aam[i] = (R)(sizeof(R) == 4 ? (float)adl[i] : adl[i]); h_T.ram[i] = (R)(sizeof(R) == 4 ? (float)rdl[i] : rdl[i]); }
+        return GEOSRAD_OK;
+    }
+
+    int sync_T()
+    {
+        HIPCHK(hipMemcpy(d_T, &h_T, sizeof(LwDev<R>), hipMemcpyHostToDevice));
+        return GEOSRAD_OK;
+    }
+
+    // ---- table upload ----------------------------------------------------------------------------------
+    int set_tables_lw(const void *blob, size_t nbytes) override
+    {
+        HIPCHK(hipSetDevice(device));
+        Blob B;
+        if (!B.parse(blob, nbytes)) return fail(GEOSRAD_ETABLE, B.err);
+        if (B.realbytes != (int)sizeof(R))
+            return fail(GEOSRAD_ETABLE, "table blob real size does not match the context's real_kind (use the _r4 blob for "
+                                        "real_kind 4 and the _r8 blob for real_kind 8)");
+        std::vector<char> stage;
+        std::vector<std::pair<const R **, size_t>> fix;   // (pointer slot, byte offset)
+        std::string missing;
+        auto get = [&](const std::string &nm, size_t expect) -> const R * {
+            auto it = B.e.find(nm);
+            if (it == B.e.end() || it->second.kind != (int)sizeof(R) || (expect && it->second.count != expect)) {
+                missing += nm + " ";
+                return nullptr;
+            }
+            return (const R *)it->second.data;
+        };
+        auto reserve = [&](size_t nreal) -> size_t {
+            size_t off = (stage.size() + 15) & ~(size_t)15;
+            stage.resize(off + nreal * sizeof(R), 0);
+            return off;
+        };
+        auto at = [&](size_t off) -> R * { return (R *)(stage.data() + off); };
+        // Fortran (n1, ng) -> [n1][NGP]
+        auto tr2 = [&](const R **slot, const std::string &nm, int n1, int ng) {
+            const R *s = get(nm, (size_t)n1 * ng);
+            if (!s) return;
+            const int ngp = pad4(ng);
+            size_t off = reserve((size_t)n1 * ngp);
+            for (int g = 0; g < ng; g++)
+                for (int i = 0; i < n1; i++) at(off)[(size_t)i * ngp + g] = s[(size_t)g * n1 + i];
+            fix.push_back({slot, off});
+        };
+        // Fortran (nsp, 19, ng) -> [19][nsp][NGP]
+        auto tr3 = [&](const R **slot, const std::string &nm, int nsp, int ng) {
+            const R *s = get(nm, (size_t)nsp * 19 * ng);
+            if (!s) return;
+            const int ngp = pad4(ng);
+            size_t off = reserve((size_t)19 * nsp * ngp);
+            for (int g = 0; g < ng; g++)
+                for (int im = 0; im < 19; im++)
+                    for (int j = 0; j < nsp; j++) at(off)[((size_t)im * nsp + j) * ngp + g] = s[((size_t)g * 19 + im) * nsp + j];
+            fix.push_back({slot, off});
+        };
+        // Fortran (ng, m) -> [m][NGP]   (m = 1 for plain per-g vectors)
+        auto rows = [&](const R **slot, const std::string &nm, int ng, int m) {
+            const R *s = get(nm, (size_t)ng * m);
+            if (!s) return;
+            const int ngp = pad4(ng);
+            size_t off = reserve((size_t)m * ngp);
+            for (int j = 0; j < m; j++)
+                for (int g = 0; g < ng; g++) at(off)[(size_t)j * ngp + g] = s[(size_t)j * ng + g];
+            fix.push_back({slot, off});
+        };
+        auto raw = [&](const R **slot, const std::string &nm, size_t cnt) {
+            const R *s = get(nm, cnt);
+            if (!s) return;
+            size_t off = reserve(cnt);
+            memcpy(at(off), s, cnt * sizeof(R));
+            fix.push_back({slot, off});
+        };
+        auto scalar = [&](const std::string &nm) -> R { const R *s = get(nm, 1); return s ? *s : (R)0; };
+
+        static const int ng[17] = {0, 10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2};
+        static const int nspa[17] = {0, 1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9};
+        static const int nspb[17] = {0, 1, 1, 5, 5, 5, 0, 1, 1, 1, 1, 1, 0, 0, 1, 0, 0};
+        LwDev<R> &T = h_T;
+        const R *xcw_keep = T.xcw;
+        R aam[4], ram[4];
+        for (int i = 0; i < 4; i++) { aam[i] = T.aam[i]; ram[i] = T.ram[i]; }
+        memset(&T, 0, sizeof(T));
+        T.xcw = xcw_keep;
+        for (int i = 0; i < 4; i++) { T.aam[i] = aam[i]; T.ram[i] = ram[i]; }
+        char nm[64];
+        for (int b = 1; b <= 16; b++) {
+            BandTab<R> &bt = T.b[b];
+            auto N = [&](const char *s) { snprintf(nm, sizeof nm, "b%02d_%s", b, s); return std::string(nm); };
+            tr2(&bt.absa, N("absa"), 65 * nspa[b], ng[b]);
+            // band 16 declares absb(235,ng) although nspb(16) = 0 (rrlw_kg16.F90); bands 6,12,13,15 have no absb
+            if (nspb[b] > 0 || b == 16) tr2(&bt.absb, N("absb"), 235 * (b == 16 ? 1 : nspb[b]), ng[b]);
+            rows(&bt.fracrefa, N("fracrefa"), ng[b], nspa[b] == 9 ? 9 : 1);
+            if (b != 6 && b != 12 && b != 15) rows(&bt.fracrefb, N("fracrefb"), ng[b], nspb[b] == 5 ? 5 : 1);
+            tr2(&bt.selfref, N("selfref"), 10, ng[b]);
+            tr2(&bt.forref, N("forref"), 4, ng[b]);
+        }
+        tr2(&T.b[1].m[0], "b01_ka_mn2", 19, ng[1]);   tr2(&T.b[1].m[1], "b01_kb_mn2", 19, ng[1]);
+        tr3(&T.b[3].m[0], "b03_ka_mn2o", 9, ng[3]);   tr3(&T.b[3].m[1], "b03_kb_mn2o", 5, ng[3]);
+        tr3(&T.b[5].m[0], "b05_ka_mo3", 9, ng[5]);    rows(&T.b[5].m[1], "b05_ccl4", ng[5], 1);
+        tr2(&T.b[6].m[0], "b06_ka_mco2", 19, ng[6]);  rows(&T.b[6].m[1], "b06_cfc11adj", ng[6], 1);
+        rows(&T.b[6].m[2], "b06_cfc12", ng[6], 1);
+        tr3(&T.b[7].m[0], "b07_ka_mco2", 9, ng[7]);   tr2(&T.b[7].m[1], "b07_kb_mco2", 19, ng[7]);
+        tr2(&T.b[8].m[0], "b08_ka_mco2", 19, ng[8]);  tr2(&T.b[8].m[1], "b08_kb_mco2", 19, ng[8]);
+        tr2(&T.b[8].m[2], "b08_ka_mo3", 19, ng[8]);   tr2(&T.b[8].m[3], "b08_ka_mn2o", 19, ng[8]);
+        tr2(&T.b[8].m[4], "b08_kb_mn2o", 19, ng[8]);  rows(&T.b[8].m[5], "b08_cfc12", ng[8], 1);
+        rows(&T.b[8].m[6], "b08_cfc22adj", ng[8], 1);
+        tr3(&T.b[9].m[0], "b09_ka_mn2o", 9, ng[9]);   tr2(&T.b[9].m[1], "b09_kb_mn2o", 19, ng[9]);
+        tr2(&T.b[11].m[0], "b11_ka_mo2", 19, ng[11]); tr2(&T.b[11].m[1], "b11_kb_mo2", 19, ng[11]);
+        tr3(&T.b[13].m[0], "b13_ka_mco2", 9, ng[13]); tr3(&T.b[13].m[1], "b13_ka_mco", 9, ng[13]);
+        tr2(&T.b[13].m[2], "b13_kb_mo3", 19, ng[13]);
+        tr3(&T.b[15].m[0], "b15_ka_mn2", 9, ng[15]);
+
+        raw(&T.totplnk, "totplnk", 181 * 16); raw(&T.totplnkderiv, "totplnkderiv", 181 * 16);
+        raw(&T.preflog, "preflog", 59); raw(&T.tref, "tref", 59); raw(&T.chi_mls, "chi_mls", 7 * 59);
+        raw(&T.tau_tbl, "tau_tbl", NTBL + 1);
+        raw(&T.absice0, "absice0", 2); raw(&T.absice1, "absice1", 10); raw(&T.absice2, "absice2", 43 * 16);
+        raw(&T.absice3, "absice3", 46 * 16); raw(&T.absice4, "absice4", 200 * 16); raw(&T.absliq1, "absliq1", 58 * 16);
+        {   // interleaved (exp_tbl, tfn_tbl)
+            const R *ex = get("exp_tbl", NTBL + 1), *tf = get("tfn_tbl", NTBL + 1);
+            if (ex && tf) {
+                size_t off = reserve(2 * (size_t)(NTBL + 1));
+                for (int i = 0; i <= NTBL; i++) { at(off)[2 * i] = ex[i]; at(off)[2 * i + 1] = tf[i]; }
+                fix.push_back({(const R **)&T.lut, off});
+            }
+        }
+        {   // chi_mls ratio tables: the same IEEE divisions setcoef performs per layer
+            const R *chi = get("chi_mls", 7 * 59);
+            if (chi) {
+                static const int pa[RAT_NPAIR] = {1, 1, 1, 1, 4, 3}, pb[RAT_NPAIR] = {2, 3, 4, 6, 2, 2};
+                size_t off = reserve((size_t)RAT_NPAIR * 60);
+                for (int p = 0; p < RAT_NPAIR; p++)
+                    for (int j = 1; j <= 59; j++) at(off)[p * 60 + j] = chi[(j - 1) * 7 + pa[p] - 1] / chi[(j - 1) * 7 + pb[p] - 1];
+                fix.push_back({&T.rat, off});
+            }
+        }
+        T.bpade = scalar("bpade"); T.fluxfac = scalar("fluxfac"); T.oneminus = scalar("oneminus");
+        T.grav = scalar("grav"); T.avogad = scalar("avogad");
+        {
+            const R *dw = get("delwave", 16);
+            if (dw) for (int b = 1; b <= 16; b++) T.delwave[b] = dw[b - 1];
+            auto it = B.e.find("ice1b");
+            if (it == B.e.end() || it->second.kind != -4 || it->second.count != 16) missing += "ice1b ";
+            else memcpy(T.ice1b, it->second.data, 16 * sizeof(int32_t));
+            // the band <-> g-point map is compiled into the kernels; refuse tables that disagree
+            auto ig = B.e.find("ngb");
+            if (ig == B.e.end() || ig->second.count != 140) missing += "ngb ";
+            else {
+                const int32_t *ngb = (const int32_t *)ig->second.data;
+                int g = 0;
+                for (int b = 1; b <= 16; b++) for (int k = 0; k < ng[b]; k++, g++) if (ngb[g] != b) missing += "ngb(mismatch) ";
+            }
+        }
+        if (!missing.empty()) return fail(GEOSRAD_ETABLE, "missing/ill-shaped table entries: " + missing);
+
+        if (d_tab) { HIPCHK(hipFree(d_tab)); d_tab = nullptr; }
+        tab_bytes = stage.size();
+        HIPCHK(hipMalloc((void **)&d_tab, tab_bytes));
+        HIPCHK(hipMemcpy(d_tab, stage.data(), tab_bytes, hipMemcpyHostToDevice));
+        for (auto &f : fix) *f.first = (const R *)(d_tab + f.second);
+        have_lw = true;
+        return sync_T();
+    }
+
+    int set_inhomogeneity(int ih, const void *blob, size_t nbytes) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ih == 0) {
+            h_T.xcw = nullptr;
+            return sync_T();
+        }
+        if (ih != 1 && ih != 2) return fail(GEOSRAD_EINPUT, "unknown inhomogeneity type");
+        Blob B;
+        if (!blob || !B.parse(blob, nbytes)) return fail(GEOSRAD_ETABLE, blob ? B.err : "xcw blob required for ih > 0");
+        auto it = B.e.find("xcw");
+        if (B.realbytes != (int)sizeof(R) || it == B.e.end() || it->second.count != 140000 || it->second.kind != (int)sizeof(R))
+            return fail(GEOSRAD_ETABLE, "xcw blob missing / wrong precision");
+        auto ii = B.e.find("ih");
+        if (ii != B.e.end() && *(const int32_t *)ii->second.data != ih) return fail(GEOSRAD_ETABLE, "xcw blob is for a different ih");
+        if (!d_xcw) HIPCHK(hipMalloc((void **)&d_xcw, 140000 * sizeof(R)));
+        HIPCHK(hipMemcpy(d_xcw, it->second.data, 140000 * sizeof(R), hipMemcpyHostToDevice));
+        h_T.xcw = (const R *)d_xcw;
+        return sync_T();
+    }
+
+    int set_corr(const double *adl, const double *rdl) override
+    {
+        // parameters are default-real in the reference: round through float for real_kind 4
+        for (int i = 0; i < 4; i++) {
+            if (adl) h_T.aam[i] = (R)adl[i];
+            if (rdl) h_T.ram[i] = (R)rdl[i];
+        }
+        return sync_T();
+    }
+
+    size_t workspace_bytes() const override { return ws_bytes + io_bytes + tab_bytes; }
+
+    // ---- workspace -------------------------------------------------------------------------------------
+    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
+    static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+    size_t ws_layout(int nc, int nlay, Ws *w, char *base) const
+    {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return base ? base + o : (char *)nullptr; };
+        const size_t cl = (size_t)nlay * nc;
+        char *p;
+        p = take(SC_NFIELD * cl * sizeof(R)); if (w) w->sc = (R *)p;
+        p = take(cl * 4); if (w) w->scidx = (uint32_t *)p;
+        p = take((size_t)nc * sizeof(R)); if (w) w->pwvcm = (R *)p;
+        p = take(nc); if (w) w->colcloudy = (uint8_t *)p;
+        p = take(cl); if (w) w->laycloudy = (uint8_t *)p;
+        p = take(cl * sizeof(R)); if (w) w->alpha = (R *)p;
+        p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
+        p = take(NG_LW * cl * sizeof(R)); if (w) w->taucmc = (R *)p;
+        p = take(NG_LW * cl * sizeof(R2)); if (w) w->s1 = (R2 *)p;
+        p = take(NG_LW * cl * sizeof(R2)); if (w) w->s2 = (R2 *)p;
+        p = take((size_t)6 * NB_LW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
+        return off;
+    }
+    int ensure_ws(int nc, int nlay)
+    {
+        if (d_ws && nc <= ws_ncol && nlay == ws_nlay) return GEOSRAD_OK;
+        // grow-only in columns for a given nlay
+        const int want = (d_ws && nlay == ws_nlay && nc < ws_ncol) ? ws_ncol : nc;
+        if (d_ws) { HIPCHK(hipFree(d_ws)); d_ws = nullptr; ws_bytes = 0; }
+        const size_t need = ws_layout(want, nlay, nullptr, nullptr);
+        hipError_t e = hipMalloc((void **)&d_ws, need);
+        if (e != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the LW workspace failed (" + std::to_string(need >> 20) +
+                                                         " MiB); lower it with geosrad_set_chunk()");
+        ws_bytes = need; ws_ncol = want; ws_nlay = nlay;
+        return GEOSRAD_OK;
+    }
+
+    // ---- RRTMG_LW, device pointers ---------------------------------------------------------------------------
+    int lw_dev(hipStream_t st, int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr,
+               int cloudLM, int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output, void *dbg_taug,
+               void *dbg_pfracs) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (!have_lw) return fail(GEOSRAD_EINVAL, "RRTMG_LW tables not set: call geosrad_set_tables_lw first (rrtmg_lw_ini)");
+        if (ncol <= 0 || nlay < 4 || nlay > 203) return fail(GEOSRAD_EINVAL, "bad ncol/nlay (4 <= nlay <= mxlay = 203)");
+        // checks the reference performs on scalars
+        if (iceflg < 0 || iceflg > 4) return fail(GEOSRAD_EINPUT, "cldprmc: invalid iceflag");
+        if (liqflg != 1) return fail(GEOSRAD_EINPUT, "cldprmc: invalid liqflag");
+        if (cloudLM == cloudMH) return fail(GEOSRAD_EINPUT, "invalid pressure super-layers!");
+        for (int k = 0; k < I_NIN; k++)
+            if (!in[k] && k != I_TAUAER) return fail(GEOSRAD_EINVAL, "null input array");
+        for (int k = 0; k < 4; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+        if (dudTs && (!out[O_DUFLX] || !out[O_DUFLXC])) return fail(GEOSRAD_EINVAL, "dudTs set but duflx_dTs/duflxc_dTs null");
+        bool any_bo = false;
+        LwOut<R> O{};
+        for (int b = 0; b < NB_LW; b++) { O.band_output[b] = band_output ? (band_output[b] != 0) : 0; any_bo |= O.band_output[b] != 0; }
+        if (any_bo && (!out[O_OLRB] || (dudTs && !out[O_DOLRB]))) return fail(GEOSRAD_EINVAL, "band_output set but olrb/dolrb_dTs null");
+
+        const int nc_max = ncol < chunk ? ncol : chunk;
+        int rc = ensure_ws(nc_max, nlay);
+        if (rc) return rc;
+
+        for (int c0 = 0; c0 < ncol; c0 += nc_max) {
+            const int nc = (ncol - c0) < nc_max ? (ncol - c0) : nc_max;
+            Ws w;
+            ws_layout(nc, nlay, &w, d_ws);
+            LwArgs<R> A{};
+            A.ncol = nc; A.ld = ncol; A.nlay = nlay; A.dudTs = dudTs; A.iceflg = iceflg; A.liqflg = liqflg; A.doy = dyofyr;
+            A.cloudLM = cloudLM; A.cloudMH = cloudMH;
+            auto P = [&](int k) { return in[k] ? (const R *)in[k] + c0 : (const R *)nullptr; };
+            A.play = P(I_PLAY); A.plev = P(I_PLEV); A.tlay = P(I_TLAY); A.tlev = P(I_TLEV); A.tsfc = P(I_TSFC); A.emis = P(I_EMIS);
+            A.h2o = P(I_H2O); A.o3 = P(I_O3); A.co2 = P(I_CO2); A.ch4 = P(I_CH4); A.n2o = P(I_N2O); A.o2 = P(I_O2);
+            A.cfc11 = P(I_CFC11); A.cfc12 = P(I_CFC12); A.cfc22 = P(I_CFC22); A.ccl4 = P(I_CCL4);
+            A.cldf = P(I_CLDF); A.ciwp = P(I_CIWP); A.clwp = P(I_CLWP); A.rei = P(I_REI); A.rel = P(I_REL);
+            A.tauaer = P(I_TAUAER); A.zm = P(I_ZM); A.alat = P(I_ALAT);
+            A.sc = w.sc; A.scidx = w.scidx; A.pwvcm = w.pwvcm; A.colcloudy = w.colcloudy; A.laycloudy = w.laycloudy;
+            A.taucmc = w.taucmc; A.alpha = w.alpha; A.rcorr = w.rcorr; A.s1 = w.s1; A.s2 = w.s2; A.part = w.part;
+            A.err = d_err;
+            A.dbg_taug = dbg_taug ? (R *)dbg_taug + (size_t)c0 * NG_LW * nlay : nullptr;
+            A.dbg_pfracs = dbg_pfracs ? (R *)dbg_pfracs + (size_t)c0 * NG_LW * nlay : nullptr;
+            A.clearCounts = clearCounts + c0;
+
+            const dim3 blk(256);
+            const unsigned gx = (unsigned)((nc + 255) / 256);
+            span_begin(0, st); hipLaunchKernelGGL(k_validate_pwv<R>, dim3(gx), blk, 0, st, A, d_T); span_end(st);
+            span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, d_T); span_end(st);
+            // McICA + cloud optics (threads of clear columns exit at once)
+            span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,
+                               (const uint8_t *)A.colcloudy, (const LwDev<R> *)d_T, A.alpha, A.rcorr); span_end(st);
+            McArgs<R> M{};
+            M.ncol = nc; M.ld = ncol; M.nlay = nlay; M.nsubcol = NG_LW; M.doy = dyofyr; M.cloudLM = cloudLM; M.cloudMH = cloudMH;
+            M.iceflg = iceflg; M.liqflg = liqflg;
+            M.so[0] = 1; M.so[1] = 2; M.so[2] = 3; M.so[3] = 4;        // seed_order=[1,2,3,4] (rrtmg_lw_rad.F90:546)
+            M.cwp_tiny = (R)1.e-20;                                       // rrtmg_lw_rad.F90:544
+            M.play = A.play; M.cldf = A.cldf; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
+            M.alpha = A.alpha; M.rcorr = A.rcorr; M.colcloudy = A.colcloudy;
+            M.taucmc = A.taucmc; M.laycloudy = A.laycloudy; M.clearCounts = A.clearCounts; M.err = d_err;
+            span_begin(3, st); hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, M, (const LwDev<R> *)d_T); span_end(st);
+            span_begin(4, st); hipLaunchKernelGGL(k_lw_bands<R>, dim3(gx, NB_LW), blk, 0, st, A, (const LwDev<R> *)d_T); span_end(st);
+            auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
+            O.uflx = Q(O_UFLX); O.dflx = Q(O_DFLX); O.uflxc = Q(O_UFLXC); O.dflxc = Q(O_DFLXC);
+            O.duflx_dTs = Q(O_DUFLX); O.duflxc_dTs = Q(O_DUFLXC);
+            O.olrb = (R *)out[O_OLRB]; O.dolrb_dTs = (R *)out[O_DOLRB]; O.col0 = c0;
+            span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, A, O); span_end(st);
+        }
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int check(hipStream_t st) override
+    {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamSynchronize(st));
+        uint32_t e = 0;
+        HIPCHK(hipMemcpy(&e, d_err, 4, hipMemcpyDeviceToHost));
+        if (!e) return GEOSRAD_OK;
+        HIPCHK(hipMemset(d_err, 0, 4));
+        for (int k = 0; k < 21; k++)
+            if (e & (1u << k)) return fail(GEOSRAD_EINPUT, std::string("negative values in input: ") + LW_NEG_NAMES[k]);
+        if (e & (1u << ERR_PRESSURE_ORDER)) return fail(GEOSRAD_EINPUT, "RRTMG LW pressure misordering");
+        if (e & (1u << ERR_ICE_RADIUS_HI)) return fail(GEOSRAD_EINPUT, "cldprmc: iceflag: excessive high-radius extrapolation forbidden!");
+        if (e & (1u << ERR_ICE_RADIUS_LO)) return fail(GEOSRAD_EINPUT, "cldprmc: iceflag: excessive low-radius extrapolation forbidden!");
+        if (e & (1u << ERR_LIQ_RADIUS_HI)) return fail(GEOSRAD_EINPUT, "cldprmc: liqflag 1: excessive high-radius extrapolation forbidden!");
+        if (e & (1u << ERR_LIQ_RADIUS_LO)) return fail(GEOSRAD_EINPUT, "cldprmc: liqflag 1: excessive low-radius extrapolation forbidden!");
+        return fail(GEOSRAD_EINPUT, "device-side input check failed");
+    }
+
+    int ensure_io(size_t bytes)
+    {
+        if (bytes <= io_bytes) return GEOSRAD_OK;
+        if (d_io) { HIPCHK(hipFree(d_io)); d_io = nullptr; io_bytes = 0; }
+        hipError_t e = hipMalloc((void **)&d_io, bytes);
+        if (e != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the host-API staging buffer failed");
+        io_bytes = bytes;
+        return GEOSRAD_OK;
+    }
+
+    // ---- RRTMG_LW, host pointers --------------------------------------------------------------------------------
+    int lw_host(int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr, int cloudLM, int cloudMH,
+                int32_t *clearCounts, void *const *out, const int32_t *band_output, void *taug, void *pfracs) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || nlay <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay");
+        const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
+        size_t insz[I_NIN];
+        for (int k = 0; k < I_NIN; k++) insz[k] = cl;
+        insz[I_PLEV] = insz[I_TLEV] = cv; insz[I_TSFC] = insz[I_ALAT] = ncol; insz[I_EMIS] = (size_t)ncol * 16;
+        insz[I_TAUAER] = cl * 16;
+        size_t outsz[O_NOUT] = {cv, cv, cv, cv, cv, cv, (size_t)ncol * 16, (size_t)ncol * 16};
+        size_t off = 0;
+        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
+        size_t ino[I_NIN], outo[O_NOUT];
+        for (int k = 0; k < I_NIN; k++) ino[k] = in[k] ? take(insz[k]) : (size_t)-1;
+        for (int k = 0; k < O_NOUT; k++) outo[k] = take(outsz[k]);
+        const size_t cco = take((size_t)ncol * 4 * sizeof(int32_t) / sizeof(R) + 4);
+        size_t dbgo[2] = {0, 0};
+        if (taug) { dbgo[0] = take(cl * NG_LW); dbgo[1] = take(cl * NG_LW); }
+        int rc = ensure_io(off);
+        if (rc) return rc;
+        const void *din[I_NIN]; void *dout[O_NOUT];
+        for (int k = 0; k < I_NIN; k++) {
+            din[k] = in[k] ? d_io + ino[k] : nullptr;
+            if (in[k]) HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
+        }
+        for (int k = 0; k < O_NOUT; k++) dout[k] = d_io + outo[k];
+        if (band_output) {   // the reference leaves un-requested bands untouched: round-trip the caller's content
+            bool any = false;
+            for (int b = 0; b < 16; b++) any |= band_output[b] != 0;
+            if (any && out[O_OLRB]) HIPCHK(hipMemcpyAsync(dout[O_OLRB], out[O_OLRB], outsz[O_OLRB] * sizeof(R), hipMemcpyHostToDevice, stream));
+            if (any && dudTs && out[O_DOLRB]) HIPCHK(hipMemcpyAsync(dout[O_DOLRB], out[O_DOLRB], outsz[O_DOLRB] * sizeof(R), hipMemcpyHostToDevice, stream));
+        }
+        void *dout_eff[O_NOUT];
+        for (int k = 0; k < O_NOUT; k++) dout_eff[k] = out[k] ? dout[k] : nullptr;
+        rc = lw_dev(stream, ncol, nlay, dudTs, din, iceflg, liqflg, dyofyr, cloudLM, cloudMH, (int32_t *)(d_io + cco), dout_eff,
+                    band_output, taug ? d_io + dbgo[0] : nullptr, taug ? d_io + dbgo[1] : nullptr);
+        if (rc) return rc;
+        rc = check(stream);
+        if (rc) return rc;
+        bool any_bo = false;
+        if (band_output) for (int b = 0; b < 16; b++) any_bo |= band_output[b] != 0;
+        for (int k = 0; k < O_NOUT; k++) {
+            if (!out[k]) continue;
+            if ((k == O_DUFLX || k == O_DUFLXC) && !dudTs) continue;
+            if (k == O_OLRB && !any_bo) continue;
+            if (k == O_DOLRB && !(any_bo && dudTs)) continue;
+            HIPCHK(hipMemcpyAsync(out[k], dout[k], outsz[k] * sizeof(R), hipMemcpyDeviceToHost, stream));
+        }
+        if (clearCounts) HIPCHK(hipMemcpyAsync(clearCounts, d_io + cco, (size_t)ncol * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (taug) {
+            HIPCHK(hipMemcpyAsync(taug, d_io + dbgo[0], cl * NG_LW * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(pfracs, d_io + dbgo[1], cl * NG_LW * sizeof(R), hipMemcpyDeviceToHost, stream));
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        return GEOSRAD_OK;
+    }
+
+    // ---- stand-alone McICA generator, host pointers ------------------------------------------------------------------
+    int mcica_host(int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play, const void *cldfrac,
+                   const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so, int32_t *cldy, void *ciwp_s,
+                   void *clwp_s) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || nlay < 4 || nsubcol <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay/nsubcol");
+        // seed_order validation as in the reference (cloud_subcol_gen.F90:273-295)
+        int sov[4] = {1, 2, 3, 4};
+        if (so) {
+            for (int k = 0; k < 4; k++) {
+                if (so[k] < 1) return fail(GEOSRAD_EINPUT, "seed_order element < 1");
+                if (so[k] > 4) return fail(GEOSRAD_EINPUT, "seed_order element > 4");
+                sov[k] = so[k];
+            }
+        }
+        const size_t cl = (size_t)ncol * nlay, co = cl * nsubcol;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+        const size_t o_z = take(cl * sizeof(R)), o_p = take(cl * sizeof(R)), o_f = take(cl * sizeof(R)), o_i = take(cl * sizeof(R)),
+                     o_l = take(cl * sizeof(R)), o_a = take((size_t)ncol * sizeof(R)), o_al = take(cl * sizeof(R)),
+                     o_rc = take(cl * sizeof(R)), o_cy = take(co * 4), o_ci = take(co * sizeof(R)), o_cl = take(co * sizeof(R));
+        int rc = ensure_io(off);
+        if (rc) return rc;
+        const void *src[6] = {zmid, play, cldfrac, ciwp, clwp, alat};
+        const size_t dst[6] = {o_z, o_p, o_f, o_i, o_l, o_a};
+        for (int k = 0; k < 6; k++)
+            HIPCHK(hipMemcpyAsync(d_io + dst[k], src[k], (k == 5 ? (size_t)ncol : cl) * sizeof(R), hipMemcpyHostToDevice, stream));
+        const unsigned gx = (unsigned)((ncol + 255) / 256);
+        hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), dim3(256), 0, stream, ncol, ncol, nlay, doy, (const R *)(d_io + o_z),
+                           (const R *)(d_io + o_a), (const uint8_t *)nullptr, (const LwDev<R> *)d_T, (R *)(d_io + o_al), (R *)(d_io + o_rc));
+        McArgs<R> M{};
+        M.ncol = ncol; M.ld = ncol; M.nlay = nlay; M.nsubcol = nsubcol; M.doy = doy; M.cloudLM = 1; M.cloudMH = 2;
+        for (int k = 0; k < 4; k++) M.so[k] = sov[k];
+        M.cwp_tiny = (R)cwp_tiny;
+        M.play = (const R *)(d_io + o_p); M.cldf = (const R *)(d_io + o_f); M.ciwp = (const R *)(d_io + o_i); M.clwp = (const R *)(d_io + o_l);
+        M.alpha = (const R *)(d_io + o_al); M.rcorr = (const R *)(d_io + o_rc);
+        M.cldy = (int32_t *)(d_io + o_cy); M.ciwp_s = (R *)(d_io + o_ci); M.clwp_s = (R *)(d_io + o_cl);
+        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, stream, M, (const LwDev<R> *)d_T);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(cldy, d_io + o_cy, co * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(ciwp_s, d_io + o_ci, co * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(clwp_s, d_io + o_cl, co * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return GEOSRAD_OK;
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
+{
+    if (!out || (real_kind != 4 && real_kind != 8)) return GEOSRAD_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return GEOSRAD_ENODEV;
+    geosrad_ctx *c = real_kind == 4 ? (geosrad_ctx *)new Ctx<float>() : (geosrad_ctx *)new Ctx<double>();
+    c->device = device_id; c->real_kind = real_kind;
+    int rc = real_kind == 4 ? static_cast<Ctx<float> *>(c)->init() : static_cast<Ctx<double> *>(c)->init();
+    if (rc) { delete c; return rc; }
+    *out = c;
+    return GEOSRAD_OK;
+}
+
+int geosrad_destroy(geosrad_ctx *c) { if (!c) return GEOSRAD_EINVAL; (void)hipSetDevice(c->device); delete c; return GEOSRAD_OK; }
+const char *geosrad_last_error(const geosrad_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
+int geosrad_real_kind(const geosrad_ctx *c) { return c ? c->real_kind : 0; }
+int geosrad_set_chunk(geosrad_ctx *c, int n) { if (!c || n < 64) return GEOSRAD_EINVAL; c->chunk = n; return GEOSRAD_OK; }
+size_t geosrad_workspace_bytes(const geosrad_ctx *c) { return c ? c->workspace_bytes() : 0; }
+
+int geosrad_set_tables_lw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_lw(blob, n) : GEOSRAD_EINVAL; }
+
+static int read_file(geosrad_ctx *c, const char *path, std::vector<char> &buf)
+{
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) return c->fail(GEOSRAD_ETABLE, std::string("cannot open table file: ") + (path ? path : "(null)"));
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    buf.resize(n > 0 ? (size_t)n : 0);
+    size_t got = n > 0 ? fread(buf.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    if (got != buf.size()) return c->fail(GEOSRAD_ETABLE, std::string("short read: ") + path);
+    return GEOSRAD_OK;
+}
+int geosrad_load_tables_lw(geosrad_ctx *c, const char *path)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    std::vector<char> buf;
+    int rc = read_file(c, path, buf);
+    return rc ? rc : c->set_tables_lw(buf.data(), buf.size());
+}
+int geosrad_set_inhomogeneity(geosrad_ctx *c, int ih, const void *blob, size_t n) { return c ? c->set_inhomogeneity(ih, blob, n) : GEOSRAD_EINVAL; }
+int geosrad_load_inhomogeneity(geosrad_ctx *c, int ih, const char *path)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    if (ih == 0) return c->set_inhomogeneity(0, nullptr, 0);
+    std::vector<char> buf;
+    int rc = read_file(c, path, buf);
+    return rc ? rc : c->set_inhomogeneity(ih, buf.data(), buf.size());
+}
+int geosrad_set_corr_lengths(geosrad_ctx *c, const double *adl, const double *rdl) { return c ? c->set_corr(adl, rdl) : GEOSRAD_EINVAL; }
+
+#define LW_PACK_IN()                                                                                                     \
+    const void *in[I_NIN] = {play, plev, tlay, tlev, tsfc, emis, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, \
+                             cfc12vmr, cfc22vmr, ccl4vmr, cldf, ciwp, clwp, rei, rel, tauaer, zm, alat}
+
+int geosrad_rrtmg_lw(geosrad_ctx *c, int ncol, int nlay, int psize, int dudTs, const void *play, const void *plev, const void *tlay,
+                     const void *tlev, const void *tsfc, const void *emis, const void *h2ovmr, const void *o3vmr, const void *co2vmr,
+                     const void *ch4vmr, const void *n2ovmr, const void *o2vmr, const void *cfc11vmr, const void *cfc12vmr,
+                     const void *cfc22vmr, const void *ccl4vmr, const void *cldf, const void *ciwp, const void *clwp, const void *rei,
+                     const void *rel, int iceflglw, int liqflglw, const void *tauaer, const void *zm, const void *alat, int dyofyr,
+                     int cloudLM, int cloudMH, int32_t *clearCounts, void *uflx, void *dflx, void *uflxc, void *dflxc, void *duflx_dTs,
+                     void *duflxc_dTs, const int32_t *band_output, void *olrb, void *dolrb_dTs)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    (void)psize;
+    LW_PACK_IN();
+    void *out[O_NOUT] = {uflx, dflx, uflxc, dflxc, duflx_dTs, duflxc_dTs, olrb, dolrb_dTs};
+    return c->lw_host(ncol, nlay, dudTs, in, iceflglw, liqflglw, dyofyr, cloudLM, cloudMH, clearCounts, out, band_output, nullptr, nullptr);
+}
+
+int geosrad_rrtmg_lw_dev(geosrad_ctx *c, void *stream, int ncol, int nlay, int psize, int dudTs, const void *play, const void *plev,
+                         const void *tlay, const void *tlev, const void *tsfc, const void *emis, const void *h2ovmr, const void *o3vmr,
+                         const void *co2vmr, const void *ch4vmr, const void *n2ovmr, const void *o2vmr, const void *cfc11vmr,
+                         const void *cfc12vmr, const void *cfc22vmr, const void *ccl4vmr, const void *cldf, const void *ciwp,
+                         const void *clwp, const void *rei, const void *rel, int iceflglw, int liqflglw, const void *tauaer, const void *zm,
+                         const void *alat, int dyofyr, int cloudLM, int cloudMH, int32_t *clearCounts, void *uflx, void *dflx, void *uflxc,
+                         void *dflxc, void *duflx_dTs, void *duflxc_dTs, const int32_t *band_output, void *olrb, void *dolrb_dTs)
+{
+    if (!c || !clearCounts) return GEOSRAD_EINVAL;
+    (void)psize;
+    LW_PACK_IN();
+    void *out[O_NOUT] = {uflx, dflx, uflxc, dflxc, duflx_dTs, duflxc_dTs, olrb, dolrb_dTs};
+    return c->lw_dev((hipStream_t)stream, ncol, nlay, dudTs, in, iceflglw, liqflglw, dyofyr, cloudLM, cloudMH, clearCounts, out,
+                     band_output, nullptr, nullptr);
+}
+
+int geosrad_profile(geosrad_ctx *c, int enable)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    c->prof_collect();
+    c->profiling = enable != 0;
+    for (int k = 0; k < 8; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return GEOSRAD_OK;
+}
+int geosrad_profile_read(geosrad_ctx *c, int kernel_id, double *total_ms, long *launches)
+{
+    if (!c || kernel_id < 0 || kernel_id >= 8) return GEOSRAD_EINVAL;
+    (void)hipSetDevice(c->device);
+    c->prof_collect();
+    if (total_ms) *total_ms = c->prof_ms[kernel_id];
+    if (launches) *launches = c->prof_n[kernel_id];
+    return GEOSRAD_OK;
+}
+const char *geosrad_kernel_name(int kernel_id)
+{
+    static const char *nm[6] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce"};
+    return kernel_id >= 0 && kernel_id < 6 ? nm[kernel_id] : "";
+}
+
+int geosrad_check(geosrad_ctx *c, void *stream) { return c ? c->check((hipStream_t)stream) : GEOSRAD_EINVAL; }
+
+int geosrad_rrtmg_lw_taumol(geosrad_ctx *c, int ncol, int nlay, const void *play, const void *plev, const void *tlay, const void *tlev,
+                            const void *tsfc, const void *emis, const void *h2ovmr, const void *o3vmr, const void *co2vmr,
+                            const void *ch4vmr, const void *n2ovmr, const void *o2vmr, const void *cfc11vmr, const void *cfc12vmr,
+                            const void *cfc22vmr, const void *ccl4vmr, const void *tauaer, void *taug, void *pfracs)
+{
+    if (!c || !taug || !pfracs) return GEOSRAD_EINVAL;
+    // clear-sky run with a zero cloud field; fluxes are discarded
+    const size_t esz = (size_t)c->real_kind;
+    std::vector<char> zero((size_t)ncol * (nlay + 1) * esz, 0), ones((size_t)ncol * nlay * esz, 0), scratch((size_t)ncol * (nlay + 1) * esz * 4);
+    for (size_t i = 0; i < (size_t)ncol * nlay; i++) { if (esz == 4) ((float *)ones.data())[i] = 10.f; else ((double *)ones.data())[i] = 10.; }
+    std::vector<int32_t> cc((size_t)ncol * 4);
+    const void *cldf = zero.data(), *ciwp = zero.data(), *clwp = zero.data(), *rei = ones.data(), *rel = ones.data(), *zm = zero.data(),
+               *alat = zero.data();
+    LW_PACK_IN();
+    char *s = scratch.data();
+    const size_t cv = (size_t)ncol * (nlay + 1) * esz;
+    void *out[O_NOUT] = {s, s + cv, s + 2 * cv, s + 3 * cv, nullptr, nullptr, nullptr, nullptr};
+    return c->lw_host(ncol, nlay, 0, in, 3, 1, 1, 1, 2, cc.data(), out, nullptr, taug, pfracs);
+}
+
+int geosrad_mcica(geosrad_ctx *c, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
+                  const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t seed_order[4],
+                  int32_t *cldy_stoch, void *ciwp_stoch, void *clwp_stoch)
+{
+    if (!c || !zmid || !alat || !play || !cldfrac || !ciwp || !clwp || !cldy_stoch || !ciwp_stoch || !clwp_stoch) return GEOSRAD_EINVAL;
+    return c->mcica_host(ncol, nsubcol, nlay, zmid, alat, doy, play, cldfrac, ciwp, clwp, cwp_tiny, seed_order, cldy_stoch, ciwp_stoch,
+                         clwp_stoch);
+}
+
+int geosrad_clearcounts(geosrad_ctx *c, int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH, const int32_t *cldy, int32_t *cnt)
+{
+    if (!c || !cldy || !cnt || ncol <= 0) return GEOSRAD_EINVAL;
+    if (cloudLM == cloudMH) return c->fail(GEOSRAD_EINPUT, "invalid pressure super-layers!");
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(GEOSRAD_EHIP, "hipSetDevice");
+    int32_t *d_in = nullptr, *d_out = nullptr;
+    const size_t nin = (size_t)ncol * nsubcol * nlay * 4;
+    if (hipMalloc((void **)&d_in, nin) != hipSuccess || hipMalloc((void **)&d_out, (size_t)ncol * 16) != hipSuccess) {
+        if (d_in) (void)hipFree(d_in);
+        return c->fail(GEOSRAD_ENOMEM, "hipMalloc failed in geosrad_clearcounts");
+    }
+    int rc = GEOSRAD_OK;
+    if (hipMemcpy(d_in, cldy, nin, hipMemcpyHostToDevice) != hipSuccess) rc = c->fail(GEOSRAD_EHIP, "hipMemcpy H2D");
+    if (!rc) {
+        hipLaunchKernelGGL(k_clearcounts, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, c->stream, ncol, nsubcol, nlay, cloudLM, cloudMH,
+                           (const int32_t *)d_in, d_out);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(cnt, d_out, (size_t)ncol * 16, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = c->fail(GEOSRAD_EHIP, "k_clearcounts failed");
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// mcica_kernels.hpp -- McICA stochastic sub-column generator + LW cloud optics (gfx950).
+//
+// Reference behaviour: GEOS_RadiationShared/cloud_subcol_gen.F90:132-487 (generate_stochastic_clouds),
+// :546-576 (rng_kiss), :611-769 (clearCounts_threeBand); cloud_condensate_inhomogeneity.F90:86-124
+// (zcw_lookup); LW/rrtmg_lw_cldprmc.F90:24-385 (cldprmc).
+//
+// Mapping: lane = column (each column owns one KISS stream, seeded from its own lowest-layer pressures;
+// the stream is sequential over (sub-column, layer), so a column is a natural lane).  The 32-bit
+// wrap-around integer arithmetic of KISS is done in uint32_t; int -> real conversion and the affine map
+// to (0,1) use explicitly un-fused round-to-nearest ops so the random numbers are bit-identical to the
+// reference in either precision.
+#pragma once
+#include "lw_device.hpp"
+#include "lw_kernels.hpp"
+
+namespace geosrad {
+
+// un-contracted arithmetic (hipcc contracts a*b+c into fma by default; discrete decisions below must not
+// depend on that)
+GR_DEV float nf_mul(float a, float b) { return __fmul_rn(a, b); }
+GR_DEV double nf_mul(double a, double b) { return __dmul_rn(a, b); }
+GR_DEV float nf_add(float a, float b) { return __fadd_rn(a, b); }
+GR_DEV double nf_add(double a, double b) { return __dadd_rn(a, b); }
+GR_DEV float nf_sub(float a, float b) { return __fsub_rn(a, b); }
+GR_DEV double nf_sub(double a, double b) { return __dsub_rn(a, b); }
+
+struct Kiss { uint32_t s1, s2, s3, s4; };
+
+// rng_kiss (cloud_subcol_gen.F90:570-575)
+template <typename R> GR_DEV R kiss_next(Kiss &k)
+{
+    k.s1 = 69069u * k.s1 + 1327217885u;
+    uint32_t x = k.s2;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    k.s2 = x;
+    k.s3 = 18000u * (k.s3 & 65535u) + (k.s3 >> 16);
+    k.s4 = 30903u * (k.s4 & 65535u) + (k.s4 >> 16);
+    const int32_t kiss = (int32_t)(k.s1 + k.s2 + (k.s3 << 16) + k.s4);
+    return nf_add(nf_mul((R)kiss, (R)2.328306e-10), (R)0.5);
+}
+
+// correlation_length (cloud_subcol_gen.F90:491-514)
+template <typename R> GR_DEV R corr_length(const R *am, int doy, R alat)
+{
+    const R r2d = (R)(180.0 / 3.14159265358979323846);
+    R am3;
+    if (doy > 181) am3 = (R)-4. * am[2] / (R)365. * (R)(doy - 272);
+    else am3 = (R)4. * am[2] / (R)365. * (R)(doy - 91);
+    const R x = alat * r2d - am3;
+    return (am[0] + am[1] * gr_exp<R>(-(x * x) / (am[3] * am[3]))) * (R)1.e3;
+}
+
+// zcw_lookup (cloud_condensate_inhomogeneity.F90:86-124); xcw Fortran (1000,140)
+template <typename R> GR_DEV R zcw_lookup(const R *__restrict__ xcw, R cdf, R sigma)
+{
+    constexpr int n1 = 1000, n2 = 140;
+    R rind1 = nf_add(nf_mul(cdf, (R)(n1 - 1)), (R)1.);
+    int ind1 = (int)rind1; ind1 = ind1 > n1 - 1 ? n1 - 1 : ind1; ind1 = ind1 < 1 ? 1 : ind1;
+    rind1 = nf_sub(rind1, (R)ind1);
+    R rind2 = nf_sub(nf_mul((R)40., sigma), (R)3.);
+    int ind2 = (int)rind2; ind2 = ind2 > n2 - 1 ? n2 - 1 : ind2; ind2 = ind2 < 1 ? 1 : ind2;
+    rind2 = nf_sub(rind2, (R)ind2);
+    const R *p = xcw + (size_t)(ind2 - 1) * n1 + (ind1 - 1);
+    const R u1 = nf_sub((R)1.0, rind1), u2 = nf_sub((R)1.0, rind2);
+    const R t1 = nf_mul(nf_mul(u1, u2), p[0]), t2 = nf_mul(nf_mul(u1, rind2), p[n1]);
+    const R t3 = nf_mul(nf_mul(rind1, u2), p[1]), t4 = nf_mul(nf_mul(rind1, rind2), p[n1 + 1]);
+    return nf_add(nf_add(nf_add(t1, t2), t3), t4);
+}
+
+// KISS seeds from the fractional part of the four lowest-layer pressures (cloud_subcol_gen.F90:375-400)
+template <typename R> GR_DEV Kiss kiss_seed(const R *__restrict__ play, int ld, int nlay, int col, bool surface_at_one,
+                                            const int *so)
+{
+    R pseed[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int lay = surface_at_one ? k : nlay - 1 - k;
+        pseed[k] = nf_mul(play[(size_t)lay * ld + col], (R)100.);
+    }
+    uint32_t sd[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // pseed[so[k]-1] with a register-resident select (so is a permutation of 1..4)
+        const int j = so[k];
+        const R ps = j == 1 ? pseed[0] : (j == 2 ? pseed[1] : (j == 3 ? pseed[2] : pseed[3]));
+        const R frac = nf_sub(ps, (R)(int32_t)ps);
+        sd[k] = (uint32_t)(int32_t)nf_add(nf_mul(frac, (R)2147483646), (R)1);
+    }
+    Kiss k; k.s1 = sd[0]; k.s2 = sd[1]; k.s3 = sd[2]; k.s4 = sd[3];
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_overlap: per (layer, column): alpha / rcorr = exp(-|dz| / L) (cloud_subcol_gen.F90:310-321), computed
+// once instead of once per sub-column.  Layer 0 entries are unused (set to 0).
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_overlap(int ncol, int ld, int nlay, int doy, const R *__restrict__ zmid,
+                                                 const R *__restrict__ alat, const uint8_t *__restrict__ colcloudy,
+                                                 const LwDev<R> *__restrict__ T, R *__restrict__ alpha, R *__restrict__ rcorr)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lay = blockIdx.y;
+    if (col >= ncol) return;
+    if (colcloudy && !colcloudy[col]) return;
+    const size_t w = (size_t)lay * ncol + col;
+    if (lay == 0) { alpha[w] = 0; if (rcorr) rcorr[w] = 0; return; }
+    const R dz = fabs(zmid[(size_t)lay * ld + col] - zmid[(size_t)(lay - 1) * ld + col]);
+    const R adl = corr_length<R>(T->aam, doy, alat[col]);
+    alpha[w] = gr_exp<R>(-dz / adl);
+    if (T->xcw) {
+        const R rdl = corr_length<R>(T->ram, doy, alat[col]);
+        rcorr[w] = gr_exp<R>(-dz / rdl);
+    }
+}
+
+// LW cloud optical depth of one McICA cell (LW/rrtmg_lw_cldprmc.F90:84-360); returns tau, raises error
+// bits where the reference would `error stop`.
+template <typename R>
+GR_DEV R lw_cloud_tau(const LwDev<R> &T, int iceflag, int ib, R ciwp, R clwp, R reice, R reliq, uint32_t &err)
+{
+    R tau = 0;
+    // ---- ice ----
+    if (iceflag == 0) {
+        if (ciwp > 0) tau = ciwp * (T.absice0[0] + T.absice0[1] / reice);
+    } else if (iceflag == 1) {
+        if (ciwp > 0) { const int i1 = T.ice1b[ib - 1]; tau = ciwp * (T.absice1[(i1 - 1) * 2] + T.absice1[(i1 - 1) * 2 + 1] / reice); }
+    } else {
+        R factor; int nmax; const R *tab;
+        if (iceflag == 2) { factor = (reice - (R)2.) / (R)3.; nmax = 43; tab = T.absice2; }
+        else if (iceflag == 3) { factor = (reice - (R)2.) / (R)3.; nmax = 46; tab = T.absice3; }
+        else { factor = reice; nmax = 200; tab = T.absice4; }
+        int index = (int)factor;
+        if (index >= nmax) { if (index == nmax) index = nmax - 1; else { err |= 1u << ERR_ICE_RADIUS_HI; index = nmax - 1; } }
+        else if (index <= 0) { if (index == 0) index = 1; else { err |= 1u << ERR_ICE_RADIUS_LO; index = 1; } }
+        const R fint = factor - (R)index;
+        if (ciwp > 0) {
+            const R *p = tab + (size_t)(ib - 1) * nmax + (index - 1);
+            tau = ciwp * (p[0] + fint * (p[1] - p[0]));
+        }
+    }
+    // ---- liquid (liqflag == 1, Hu & Stamnes) ----
+    {
+        const R factor = reliq - (R)1.5;
+        int index = (int)factor;
+        if (index >= 58) { if (index == 58) index = 57; else { err |= 1u << ERR_LIQ_RADIUS_HI; index = 57; } }
+        else if (index <= 0) { if (index == 0) index = 1; else { err |= 1u << ERR_LIQ_RADIUS_LO; index = 1; } }
+        const R fint = factor - (R)index;
+        if (clwp > 0) {
+            const R *p = T.absliq1 + (size_t)(ib - 1) * 58 + (index - 1);
+            tau = tau + clwp * (p[0] + fint * (p[1] - p[0]));
+        }
+    }
+    return tau;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_mcica: one thread per column, sequential over (sub-column, layer) like the reference's stream.
+//   MODE 0 (RRTMG_LW): fused generate_stochastic_clouds + clearCounts_threeBand + cldprmc:
+//          writes taucmc[g][lay][col], laycloudy[lay][col], clearCounts(ncol,4).
+//   MODE 1 (stand-alone generator API): writes cldy/ciwp_stoch/clwp_stoch Fortran (nlay,nsubcol,ncol).
+// Two passes per sub-column: pass 1 draws (cdf1,cdf2) for every layer and parks the cloud-presence
+// decision in the output cell; pass 2 draws (cdf2,cdf3) and finishes the cell.  No per-thread arrays.
+// ---------------------------------------------------------------------------------------------------
+template <typename R> struct McArgs {
+    int ncol, ld, nlay, nsubcol, doy, cloudLM, cloudMH, iceflg, liqflg;
+    int so[4];
+    R cwp_tiny;
+    const R *play, *cldf, *ciwp, *clwp, *rei, *rel;
+    const R *alpha, *rcorr;            // [nlay][ncol]
+    const uint8_t *colcloudy;          // nullable
+    // MODE 0
+    R *taucmc; uint8_t *laycloudy; int32_t *clearCounts; uint32_t *err;
+    // MODE 1
+    int32_t *cldy; R *ciwp_s, *clwp_s;
+};
+
+template <typename R, int MODE>
+__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__restrict__ Tp)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= M.ncol) return;
+    if (M.colcloudy && !M.colcloudy[col]) return;
+    const LwDev<R> &T = *Tp;
+    const int n = M.ncol, ld = M.ld, nlay = M.nlay;
+    const bool inhomo = T.xcw != nullptr;
+    // vertical ordering is detected from the first column of the call (cloud_subcol_gen.F90:266)
+    const bool surface_at_one = M.play[0] > M.play[(size_t)(nlay - 1) * ld];
+    Kiss ks = kiss_seed<R>(M.play, ld, nlay, col, surface_at_one, M.so);
+    uint32_t err = 0;
+
+    // pressure super-layer bounds, 0-based inclusive (cloud_subcol_gen.F90:617-632)
+    int lo0, lo1, mi0, mi1, hi0, hi1;
+    if (M.cloudLM < M.cloudMH) { lo0 = 0; lo1 = M.cloudLM - 1; mi0 = M.cloudLM; mi1 = M.cloudMH - 1; hi0 = M.cloudMH; hi1 = nlay - 1; }
+    else { hi0 = 0; hi1 = M.cloudMH - 2; mi0 = M.cloudMH - 1; mi1 = M.cloudLM - 2; lo0 = M.cloudLM - 1; lo1 = nlay - 1; }
+    int cnt_all = 0, cnt_hi = 0, cnt_mid = 0, cnt_lo = 0;
+
+    if (MODE == 0)
+        for (int il = 0; il < nlay; il++) M.laycloudy[(size_t)il * n + col] = 0;
+
+    for (int is = 0; is < M.nsubcol; is++) {
+        const int ib = MODE == 0 ? (is < 10 ? 1 : is < 22 ? 2 : is < 38 ? 3 : is < 52 ? 4 : is < 68 ? 5 : is < 76 ? 6 : is < 88 ? 7 :
+                                    is < 96 ? 8 : is < 108 ? 9 : is < 114 ? 10 : is < 122 ? 11 : is < 130 ? 12 : is < 134 ? 13 :
+                                    is < 136 ? 14 : is < 138 ? 15 : 16) : 0;
+        bool any_all = false, any_hi = false, any_mid = false, any_lo = false;
+        // ---- pass 1: cloud presence with exponential overlap (:406-414) ----
+        R cprev = 0;
+        for (int il = 0; il < nlay; il++) {
+            R cdf1 = kiss_next<R>(ks);
+            const R cdf2 = kiss_next<R>(ks);
+            const size_t w = (size_t)il * n + col, a = (size_t)il * ld + col;
+            if (il > 0 && cdf2 < M.alpha[w]) cdf1 = cprev;
+            cprev = cdf1;
+            const R cf = M.cldf[a];
+            const bool cloudy = cdf1 >= nf_sub((R)1., cf);
+            if (!inhomo) {
+                // homogeneous condensate: finish the cell now (:438-443)
+                R ci = 0, cl = 0; bool c = false;
+                if (cloudy) {
+                    ci = M.ciwp[a]; cl = M.clwp[a];
+                    const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
+                    if (cin) ci = 0;
+                    if (cln) cl = 0;
+                    c = !(cin && cln);
+                }
+                if (c) { any_all = true; if (il >= hi0 && il <= hi1) any_hi = true; if (il >= mi0 && il <= mi1) any_mid = true; if (il >= lo0 && il <= lo1) any_lo = true; }
+                if (MODE == 0) {
+                    R tau = 0;
+                    if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
+                    M.taucmc[((size_t)is * nlay + il) * n + col] = tau;
+                    if (tau > 0) M.laycloudy[w] = 1;
+                } else {
+                    const size_t o = ((size_t)col * M.nsubcol + is) * nlay + il;
+                    M.cldy[o] = c ? 1 : 0; M.ciwp_s[o] = ci; M.clwp_s[o] = cl;
+                }
+            } else {
+                if (MODE == 0) M.taucmc[((size_t)is * nlay + il) * n + col] = cloudy ? (R)1 : (R)0;
+                else M.cldy[((size_t)col * M.nsubcol + is) * nlay + il] = cloudy ? 1 : 0;
+            }
+        }
+        // ---- pass 2: condensate with exponential overlap + inhomogeneity (:416-466) ----
+        if (inhomo) {
+            R c3prev = 0;
+            for (int il = 0; il < nlay; il++) {
+                const R cdf2 = kiss_next<R>(ks);
+                R cdf3 = kiss_next<R>(ks);
+                const size_t w = (size_t)il * n + col, a = (size_t)il * ld + col;
+                if (il > 0 && cdf2 < M.rcorr[w]) cdf3 = c3prev;
+                c3prev = cdf3;
+                const size_t oc = MODE == 0 ? ((size_t)is * nlay + il) * n + col : ((size_t)col * M.nsubcol + is) * nlay + il;
+                const bool cloudy = MODE == 0 ? (M.taucmc[oc] != (R)0) : (M.cldy[oc] != 0);
+                R ci = 0, cl = 0; bool c = false;
+                if (cloudy) {
+                    const R cf = M.cldf[a];
+                    const R sigma = cf > (R)0.99 ? (R)0.5 : (cf > (R)0.9 ? (R)0.71 : (R)1.0);
+                    const R zcw = zcw_lookup<R>(T.xcw, cdf3, sigma);
+                    ci = nf_mul(M.ciwp[a], zcw); cl = nf_mul(M.clwp[a], zcw);
+                    const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
+                    if (cin) ci = 0;
+                    if (cln) cl = 0;
+                    c = !(cin && cln);
+                }
+                if (c) { any_all = true; if (il >= hi0 && il <= hi1) any_hi = true; if (il >= mi0 && il <= mi1) any_mid = true; if (il >= lo0 && il <= lo1) any_lo = true; }
+                if (MODE == 0) {
+                    R tau = 0;
+                    if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
+                    M.taucmc[oc] = tau;
+                    if (tau > 0) M.laycloudy[w] = 1;
+                } else {
+                    M.cldy[oc] = c ? 1 : 0; M.ciwp_s[oc] = ci; M.clwp_s[oc] = cl;
+                }
+            }
+        }
+        if (!any_all) cnt_all++;
+        if (!any_hi) cnt_hi++;
+        if (!any_mid) cnt_mid++;
+        if (!any_lo) cnt_lo++;
+    }
+    if (MODE == 0) {
+        M.clearCounts[(size_t)0 * ld + col] = cnt_all;
+        M.clearCounts[(size_t)1 * ld + col] = cnt_hi;
+        M.clearCounts[(size_t)2 * ld + col] = cnt_mid;
+        M.clearCounts[(size_t)3 * ld + col] = cnt_lo;
+        if (err) atomicOr(M.err, err);
+    }
+}
+
+// clearCounts_threeBand stand-alone (cloud_subcol_gen.F90:611-769): cldy Fortran (nlay,nsubcol,ncol)
+__global__ void __launch_bounds__(64) k_clearcounts(int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH,
+                                                    const int32_t *__restrict__ cldy, int32_t *__restrict__ cnt /*(4,ncol)*/)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncol) return;
+    int lo0, lo1, mi0, mi1, hi0, hi1;
+    if (cloudLM < cloudMH) { lo0 = 0; lo1 = cloudLM - 1; mi0 = cloudLM; mi1 = cloudMH - 1; hi0 = cloudMH; hi1 = nlay - 1; }
+    else { hi0 = 0; hi1 = cloudMH - 2; mi0 = cloudMH - 1; mi1 = cloudLM - 2; lo0 = cloudLM - 1; lo1 = nlay - 1; }
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int is = 0; is < nsubcol; is++) {
+        bool a = false, h = false, m = false, l = false;
+        const int32_t *p = cldy + ((size_t)col * nsubcol + is) * nlay;
+        for (int il = 0; il < nlay; il++)
+            if (p[il]) { a = true; if (il >= hi0 && il <= hi1) h = true; if (il >= mi0 && il <= mi1) m = true; if (il >= lo0 && il <= lo1) l = true; }
+        c0 += !a; c1 += !h; c2 += !m; c3 += !l;
+    }
+    cnt[4 * col] = c0; cnt[4 * col + 1] = c1; cnt[4 * col + 2] = c2; cnt[4 * col + 3] = c3;
+}
+
+}  // namespace geosrad

@@ -1,0 +1,77 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+from tests.conftest import ROOT
+from geosradiation_gridcomp_amd import synth, tableblob, _lib
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "geosrad.h")).read()
+    declared = set(re.findall(r"\b(geosrad_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    _lib.build()
+    L = ctypes.CDLL(_lib.SO)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _lib.build()
+    from geosradiation_gridcomp_amd.api import Context, GeosradError
+    with pytest.raises(GeosradError):
+        Context(4)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "geosradiation_gridcomp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".F90")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src and "libref_" not in src, f
+
+
+def test_blob_roundtrip(tmp_path):
+    a = {"x": np.arange(12, dtype=np.float64).reshape(3, 4), "n": np.int32(7), "v": np.arange(5, dtype=np.int32)}
+    p = tmp_path / "t.grtb"
+    tableblob.write_blob(str(p), 8, a)
+    rb, b = tableblob.read_blob(str(p))
+    assert rb == 8
+    np.testing.assert_array_equal(b["x"], a["x"]); assert int(b["n"]) == 7; np.testing.assert_array_equal(b["v"], a["v"])
+
+
+def test_shipped_tables_are_consistent():
+    rb4, t4 = tableblob.read_blob(os.path.join(_lib.DATA, "rrtmg_lw_r4.grtb"))
+    rb8, t8 = tableblob.read_blob(os.path.join(_lib.DATA, "rrtmg_lw_r8.grtb"))
+    assert (rb4, rb8) == (4, 8) and set(t4) == set(t8)
+    assert t4["b03_absa"].shape == (585, 16) and t4["exp_tbl"].shape == (10001,)
+    assert list(t4["ngs"]) == [10, 22, 38, 52, 68, 76, 88, 96, 108, 114, 122, 130, 134, 136, 138, 140]
+    for k in ("b03_absa", "totplnk"):
+        assert np.allclose(t4[k], t8[k], rtol=3e-7, atol=0)
+    assert np.allclose(t4["exp_tbl"], t8["exp_tbl"], rtol=0, atol=2e-7)
+    assert np.allclose(t4["tfn_tbl"], t8["tfn_tbl"], rtol=0, atol=5e-5)   # fp32 cancellation in 1/tau - e/(1-e)
+    for nm in ("beta", "gamma"):
+        _, x4 = tableblob.read_blob(os.path.join(_lib.DATA, f"xcw_{nm}_r4.grtb"))
+        _, x8 = tableblob.read_blob(os.path.join(_lib.DATA, f"xcw_{nm}_r8.grtb"))
+        assert x4["xcw"].shape == (1000, 140) and np.allclose(x4["xcw"], x8["xcw"], rtol=1e-7)
+
+
+def test_synth_is_shardable_and_valid():
+    a = synth.make_columns(64, 72, cloudy_frac=0.6, aerosol=True)
+    b = synth.make_columns(16, 72, start=32, cloudy_frac=0.6, aerosol=True)
+    for k, v in b.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == 16:
+            np.testing.assert_array_equal(v, a[k][..., 32:48], err_msg=k)
+    assert np.all(np.diff(a["plev"], axis=0) < 0) and a["plev"].min() > 0
+    assert a["tlay"].min() > 160 and a["tlay"].max() < 340
+    for k in ("h2ovmr", "o3vmr", "cldf", "ciwp", "clwp", "tauaer"):
+        assert a[k].min() >= 0
+    assert 2.5 <= a["rel"].min() and a["rel"].max() <= 60 and 5 <= a["rei"].min() and a["rei"].max() <= 140
+    assert a["cldf"].max() == 1.0 and 0.3 < (a["cldf"].max(axis=0) > 0).mean() < 0.9
