@@ -17,12 +17,26 @@ namespace geosrad {
 
 // un-contracted arithmetic (hipcc contracts a*b+c into fma by default; discrete decisions below must not
 // depend on that)
-GR_DEV float nf_mul(float a, float b) { return __fmul_rn(a, b); }
-GR_DEV double nf_mul(double a, double b) { return __dmul_rn(a, b); }
-GR_DEV float nf_add(float a, float b) { return __fadd_rn(a, b); }
-GR_DEV double nf_add(double a, double b) { return __dadd_rn(a, b); }
-GR_DEV float nf_sub(float a, float b) { return __fsub_rn(a, b); }
-GR_DEV double nf_sub(double a, double b) { return __dsub_rn(a, b); }
+// (HIP's __fmul_rn/__dmul_rn are plain `a * b` and still contract after inlining; the pragma strips the
+// `contract` flag from the emitted instruction itself.)
+GR_DEV float nf_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b; }
+GR_DEV double nf_mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b; }
+GR_DEV float nf_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b; }
+GR_DEV double nf_add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b; }
+GR_DEV float nf_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b; }
+GR_DEV double nf_sub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b; }
 
 struct Kiss { uint32_t s1, s2, s3, s4; };
 
