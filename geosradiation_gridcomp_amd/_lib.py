@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(CSRC, "libgeosrad.so")
+SO = os.environ.get("GEOSRAD_LIB") or os.path.join(CSRC, "libgeosrad.so")   # override only for A/B kernel experiments
 DATA = os.path.join(HERE, "data")
 
 EXPORTS = [

@@ -358,7 +358,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     size_t workspace_bytes() const override { return ws_bytes + io_bytes + tab_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
-    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
+    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *blkcloudy, *laycloudy; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
     static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t ws_layout(int nc, int nlay, Ws *w, char *base) const
     {
@@ -370,6 +370,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(cl * 4); if (w) w->scidx = (uint32_t *)p;
         p = take((size_t)nc * sizeof(R)); if (w) w->pwvcm = (R *)p;
         p = take(nc); if (w) w->colcloudy = (uint8_t *)p;
+        p = take((size_t)(nc + 255) / 256); if (w) w->blkcloudy = (uint8_t *)p;
         p = take(cl); if (w) w->laycloudy = (uint8_t *)p;
         p = take(cl * sizeof(R)); if (w) w->alpha = (R *)p;
         p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
@@ -414,7 +415,10 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (int b = 0; b < NB_LW; b++) { O.band_output[b] = band_output ? (band_output[b] != 0) : 0; any_bo |= O.band_output[b] != 0; }
         if (any_bo && (!out[O_OLRB] || (dudTs && !out[O_DOLRB]))) return fail(GEOSRAD_EINVAL, "band_output set but olrb/dolrb_dTs null");
 
-        const int nc_max = ncol < chunk ? ncol : chunk;
+        // one band's [layer][g<=16][column] plane of (a,bbu) pairs must stay below 4 GiB (32-bit byte offsets)
+        const long cap = (long)(0xFFFFFFFFull / ((unsigned long long)nlay * 16ull * sizeof(R2))) & ~255L;
+        int nc_max = ncol < chunk ? ncol : chunk;
+        if ((long)nc_max > cap) nc_max = (int)cap;
         int rc = ensure_ws(nc_max, nlay);
         if (rc) return rc;
 
@@ -431,7 +435,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.cfc11 = P(I_CFC11); A.cfc12 = P(I_CFC12); A.cfc22 = P(I_CFC22); A.ccl4 = P(I_CCL4);
             A.cldf = P(I_CLDF); A.ciwp = P(I_CIWP); A.clwp = P(I_CLWP); A.rei = P(I_REI); A.rel = P(I_REL);
             A.tauaer = P(I_TAUAER); A.zm = P(I_ZM); A.alat = P(I_ALAT);
-            A.sc = w.sc; A.scidx = w.scidx; A.pwvcm = w.pwvcm; A.colcloudy = w.colcloudy; A.laycloudy = w.laycloudy;
+            A.sc = w.sc; A.scidx = w.scidx; A.pwvcm = w.pwvcm; A.colcloudy = w.colcloudy; A.blkcloudy = w.blkcloudy; A.laycloudy = w.laycloudy;
             A.taucmc = w.taucmc; A.alpha = w.alpha; A.rcorr = w.rcorr; A.s1 = w.s1; A.s2 = w.s2; A.part = w.part;
             A.err = d_err;
             A.dbg_taug = dbg_taug ? (R *)dbg_taug + (size_t)c0 * NG_LW * nlay : nullptr;
@@ -440,6 +444,7 @@ template <typename R> struct Ctx : geosrad_ctx {
 
             const dim3 blk(256);
             const unsigned gx = (unsigned)((nc + 255) / 256);
+            HIPCHK(hipMemsetAsync(w.blkcloudy, 0, (size_t)(nc + 255) / 256, st));
             span_begin(0, st); hipLaunchKernelGGL(k_validate_pwv<R>, dim3(gx), blk, 0, st, A, d_T); span_end(st);
             span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, d_T); span_end(st);
             // McICA + cloud optics (threads of clear columns exit at once)
@@ -454,7 +459,14 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.alpha = A.alpha; M.rcorr = A.rcorr; M.colcloudy = A.colcloudy;
             M.taucmc = A.taucmc; M.laycloudy = A.laycloudy; M.clearCounts = A.clearCounts; M.err = d_err;
             span_begin(3, st); hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, M, (const LwDev<R> *)d_T); span_end(st);
-            span_begin(4, st); hipLaunchKernelGGL(k_lw_bands<R>, dim3(gx, NB_LW), blk, 0, st, A, (const LwDev<R> *)d_T); span_end(st);
+            span_begin(4, st);
+            if (A.dbg_taug) {
+                hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
+            } else {
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
+            }
+            span_end(st);
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
             O.uflx = Q(O_UFLX); O.dflx = Q(O_DFLX); O.uflxc = Q(O_UFLXC); O.dflxc = Q(O_DFLXC);
             O.duflx_dTs = Q(O_DUFLX); O.duflxc_dTs = Q(O_DUFLXC);

@@ -8,7 +8,8 @@
 //   k_setcoef      : per (layer,column) - p/T interpolation record shared by all 16 bands
 //   k_lw_bands     : per (column, band): fused taumol -> rtrnmc; blockIdx.y selects the band body
 //                    (heaviest bands first); down sweep keeps the band's g-point radiances in
-//                    registers, up sweep re-reads the (absorptivity, source) pairs it parked in HBM
+//                    registers and evaluates the k-distribution 4 g-points at a time, up sweep
+//                    re-reads the (absorptivity, source) pairs it parked in HBM
 //   k_lw_reduce    : per (level,column) - fixed-order sum of the 16 band partials (bitwise reproducible)
 #pragma once
 #include "lw_device.hpp"
@@ -31,6 +32,18 @@ template <> GR_DEV double gr_pow<double>(double x, double y) { return pow(x, y);
 GR_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 constexpr int pad4(int n) { return (n + 3) & ~3; }
+
+// Addressing idiom of the hot kernels:  wave-uniform base pointer (SGPR pair)  +  32-bit per-lane BYTE offset.
+// Written on bytes so the compiler sees base + zext(u32) and emits `global_load v, voff, s[base:base+1]`
+// instead of materialising a 64-bit per-lane address (2 VGPRs + 64-bit VALU adds) for every array.
+template <typename T> GR_DEV T ldg(const T *base, uint32_t byteoff)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byteoff);
+}
+template <typename T> GR_DEV void stg(T *base, uint32_t byteoff, T v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byteoff) = v;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // k_validate_pwv: one thread per column.
@@ -80,6 +93,7 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
     const R wvsh = (amw * wvttl) / (amd * amttl);
     A.pwvcm[col] = wvsh * ((R)1.e3 * A.plev[col]) / ((R)1.e2 * grav);
     A.colcloudy[col] = cloudy ? 1 : 0;
+    if (cloudy) A.blkcloudy[blockIdx.x] = 1;   // zeroed by the host before the launch; same-value race is benign
     if (!cloudy) {
         // clear column: all sub-columns clear in every super-layer (cloud_subcol_gen.F90:649-659)
         for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = NG_LW;
@@ -173,153 +187,161 @@ __global__ void __launch_bounds__(256) k_setcoef(LwArgs<R> A, const LwDev<R> *__
     A.scidx[(size_t)lay * n + col] = pack_idx(jp, jt, jt1, indfor, indself, indminor, lower ? 1 : 0);
 }
 
+
 // ---------------------------------------------------------------------------------------------------
-// band bodies: gas optical depth tau[g] and Planck fraction pf[g] of ONE layer of ONE column for all
-// g-points of a band (LW/rrtmg_lw_taumol.F90:155-3126, one struct per taugbN).
+// band bodies (LW/rrtmg_lw_taumol.F90:155-3126, one struct per taugbN).
+//
+// Each band is split into
+//   prep():  everything of a (layer, column) that does not depend on the g-point: column amounts,
+//            binary-species parameters, "too much of a minor gas" adjustments, table row numbers;
+//   eval<W>(): gas optical depth tau[] and Planck fraction pf[] of W consecutive g-points starting at
+//            `go`, as a short list of  coefficient x table-row  products, each row fetched with one
+//            16-byte load per lane.
+// The band kernel walks a band's g-points W = 4 at a time with a scheduling barrier between groups, so
+// only one group's rows are in flight: that keeps the VGPR count low enough for several waves per SIMD
+// (the first version evaluated all 16 g-points at once and needed 256 VGPRs + AGPR spills).
 // ---------------------------------------------------------------------------------------------------
 template <typename R> struct Layer {
     R fac00, fac01, fac10, fac11, coldry, forfac, forfrac, selffac, selffrac, minorfrac, scaleminor, scaleminorn2,
         colbrd, pavel;
     int jp, jt, jt1, indfor, indself, indminor;
     bool lower;
-    size_t i;  // API index (lay*ld + col) of this cell, for on-demand gas loads
+    uint32_t ab;  // BYTE offset of this (layer, column) cell in an API array of reals: (lay*ld + col)*sizeof(R)
 };
 
 template <typename R> GR_DEV R colamt(const R *__restrict__ vmr, const Layer<R> &L)
 {
-    return (R)1.e-20 * vmr[L.i] * L.coldry;
+    return (R)1.e-20 * ldg(vmr, L.ab) * L.coldry;
 }
 // "require some minor absorbers to be non-zero" (LW/rrtmg_lw_setcoef.F90:560-564)
 template <typename R> GR_DEV R colamt_nz(const R *__restrict__ vmr, const Layer<R> &L)
 {
-    R c = (R)1.e-20 * vmr[L.i] * L.coldry;
+    R c = (R)1.e-20 * ldg(vmr, L.ab) * L.coldry;
     return c == (R)0 ? (R)1.e-32 * L.coldry : c;
 }
 
-// row fetch: NGP contiguous reals, 16-byte aligned -> dwordx4 loads
-template <typename R, int NG> GR_DEV void ldrow(const R *__restrict__ p, R (&o)[NG])
+// W consecutive reals of a table row (W = 4 or 2), 16-byte aligned: uniform table base + per-lane byte offset
+template <typename R, int W> GR_DEV void ldw(const R *__restrict__ tab, uint32_t byteoff, R (&o)[W])
 {
-    constexpr int NGP = pad4(NG);
-    constexpr int VW = 16 / sizeof(R);
-    using V = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
-    const V *q = reinterpret_cast<const V *>(__builtin_assume_aligned(p, 16));
-    R tmp[NGP];
-#pragma unroll
-    for (int k = 0; k < NGP / VW; k++) {
-        V v = q[k];
-        if constexpr (sizeof(R) == 4) {
-            tmp[4 * k] = v.x; tmp[4 * k + 1] = v.y; tmp[4 * k + 2] = v.z; tmp[4 * k + 3] = v.w;
-        } else {
-            tmp[2 * k] = v.x; tmp[2 * k + 1] = v.y;
-        }
+    if constexpr (sizeof(R) == 4 && W == 4) {
+        const float4 v = ldg(reinterpret_cast<const float4 *>(tab), byteoff);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else if constexpr (sizeof(R) == 4 && W == 2) {
+        const float2 v = ldg(reinterpret_cast<const float2 *>(tab), byteoff);
+        o[0] = v.x; o[1] = v.y;
+    } else if constexpr (sizeof(R) == 8 && W == 4) {
+        const double2 a = ldg(reinterpret_cast<const double2 *>(tab), byteoff);
+        const double2 b = ldg(reinterpret_cast<const double2 *>(tab), byteoff + 16u);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    } else {
+        const double2 a = ldg(reinterpret_cast<const double2 *>(tab), byteoff);
+        o[0] = a.x; o[1] = a.y;
     }
-#pragma unroll
-    for (int g = 0; g < NG; g++) o[g] = tmp[g];
 }
-// acc[g] (+)= c * row[g]
-template <typename R, int NG, bool INIT> GR_DEV void axrow(R (&acc)[NG], R c, const R *__restrict__ tab, int row)
+// byte offset of row r (0-based) of a [rows][S] table, columns go..go+W-1
+#define ROWB(r) (((uint32_t)(r) * (uint32_t)S + (uint32_t)go) * (uint32_t)sizeof(R))
+
+template <typename R, int W, int S, bool INIT> GR_DEV void axw(R (&acc)[W], R c, const R *__restrict__ tab, int row, int go)
 {
-    R r[NG];
-    ldrow<R, NG>(tab + (size_t)row * pad4(NG), r);
+    R r[W];
+    ldw<R, W>(tab, ROWB(row), r);
 #pragma unroll
-    for (int g = 0; g < NG; g++) acc[g] = INIT ? c * r[g] : acc[g] + c * r[g];
+    for (int j = 0; j < W; j++) acc[j] = INIT ? c * r[j] : acc[j] + c * r[j];
 }
-// acc[g] += s * (t[i][g] + f * (t[i+1][g] - t[i][g]))      (linear interpolation between two rows)
-template <typename R, int NG> GR_DEV void add_lin(R (&acc)[NG], R s, R f, const R *__restrict__ tab, int row)
+// o[j] = a[j] + f (b[j] - a[j]) between rows `row` and `row + 1`
+template <typename R, int W, int S> GR_DEV void linw(R (&o)[W], R f, const R *__restrict__ tab, int row, int go)
 {
-    R a[NG], b[NG];
-    ldrow<R, NG>(tab + (size_t)row * pad4(NG), a);
-    ldrow<R, NG>(tab + (size_t)(row + 1) * pad4(NG), b);
+    R a[W], b[W];
+    ldw<R, W>(tab, ROWB(row), a);
+    ldw<R, W>(tab, ROWB(row + 1), b);
 #pragma unroll
-    for (int g = 0; g < NG; g++) acc[g] = acc[g] + s * (a[g] + f * (b[g] - a[g]));
+    for (int j = 0; j < W; j++) o[j] = a[j] + f * (b[j] - a[j]);
 }
-template <typename R, int NG> GR_DEV void lin(R (&o)[NG], R f, const R *__restrict__ tab, int row)
+template <typename R, int W, int S> GR_DEV void add_linw(R (&acc)[W], R s, R f, const R *__restrict__ tab, int row, int go)
 {
-    R a[NG], b[NG];
-    ldrow<R, NG>(tab + (size_t)row * pad4(NG), a);
-    ldrow<R, NG>(tab + (size_t)(row + 1) * pad4(NG), b);
+    R t[W];
+    linw<R, W, S>(t, f, tab, row, go);
 #pragma unroll
-    for (int g = 0; g < NG; g++) o[g] = a[g] + f * (b[g] - a[g]);
+    for (int j = 0; j < W; j++) acc[j] = acc[j] + s * t[j];
 }
-// minor gas on a (species parameter, T) grid, table rows [indm][jm] with NSP species rows per T
-// (e.g. LW/rrtmg_lw_taumol.F90:546-551); 0-based row = (indm-1)*NSP + (jm-1)
-template <typename R, int NG, int NSP>
-GR_DEV void minor2(R (&o)[NG], const R *__restrict__ tab, int jm, int indm, R fm, R minorfrac)
+// minor gas on a (species parameter, T) grid, rows [indm][jm], NSP species rows per T (e.g. :546-551)
+template <typename R, int W, int S, int NSP>
+GR_DEV void minor2w(R (&o)[W], const R *__restrict__ tab, int jm, int indm, R fm, R minorfrac, int go)
 {
-    R m1[NG], m2[NG];
-    lin<R, NG>(m1, fm, tab, (indm - 1) * NSP + (jm - 1));
-    lin<R, NG>(m2, fm, tab, indm * NSP + (jm - 1));
+    R m1[W], m2[W];
+    linw<R, W, S>(m1, fm, tab, (indm - 1) * NSP + (jm - 1), go);
+    linw<R, W, S>(m2, fm, tab, indm * NSP + (jm - 1), go);
 #pragma unroll
-    for (int g = 0; g < NG; g++) o[g] = m1[g] + minorfrac * (m2[g] - m1[g]);
+    for (int j = 0; j < W; j++) o[j] = m1[j] + minorfrac * (m2[j] - m1[j]);
 }
 
-template <typename R> struct Spec { R speccomb, specparm, fs; int js; };
-// binary-species parameter (e.g. LW/rrtmg_lw_taumol.F90:435-441)
+// binary-species parameter (e.g. LW/rrtmg_lw_taumol.F90:435-441) with the interpolation weights of the
+// species dimension: linear in the interior, cubic towards specparm -> 0 / 1 (:482-541)
+template <typename R> struct Spec { R speccomb, fs, c0, c1, c2; int js, boff; bool edge; };
 template <typename R> GR_DEV Spec<R> spec(R cola, R rat, R colb, R mult, R oneminus)
 {
     Spec<R> s;
     s.speccomb = cola + rat * colb;
-    s.specparm = cola / s.speccomb;
-    if (s.specparm >= oneminus) s.specparm = oneminus;
-    const R sm = mult * s.specparm;
+    R specparm = cola / s.speccomb;
+    if (specparm >= oneminus) specparm = oneminus;
+    const R sm = mult * specparm;
     const int j = (int)sm;
     s.js = 1 + j;
     s.fs = sm - (R)j;
+    const bool lo = specparm < (R)0.125, hi = specparm > (R)0.875;
+    s.edge = lo || hi;
+    s.boff = hi ? -1 : 0;
+    if (s.edge) {
+        const R p = lo ? s.fs - (R)1 : -s.fs;
+        const R p4 = ((p * p) * p) * p;
+        const R fk0 = p4, fk1 = (R)1 - p - (R)2.0 * p4, fk2 = p + p4;
+        s.c0 = lo ? fk0 : fk2; s.c1 = fk1; s.c2 = lo ? fk2 : fk0;
+    } else {
+        s.c0 = (R)1. - s.fs; s.c1 = s.fs; s.c2 = 0;
+    }
     return s;
 }
 
-// key-species term of one reference-pressure side of a binary (9-species-row) lower-atmosphere band,
-// with the cubic treatment near specparm -> 0 / 1 (LW/rrtmg_lw_taumol.F90:482-606).
-// ind = 1-based row of (jp|jp+1, jt|jt1, js); facA/facB = (fac00,fac10) or (fac01,fac11).
-template <typename R, int NG, bool INIT>
-GR_DEV void major_a(R (&acc)[NG], const R *__restrict__ absa, int ind, const Spec<R> &sp, R facA, R facB)
+// key-species term of one reference-pressure side of a 9-species-row lower-atmosphere band (:553-606);
+// ind = 1-based row of (jp|jp+1, jt|jt1, js); (facA, facB) = (fac00, fac10) or (fac01, fac11)
+template <typename R, int W, int S, bool INIT>
+GR_DEV void major_a(R (&acc)[W], const R *__restrict__ absa, int ind, const Spec<R> &sp, R facA, R facB, int go)
 {
-    R c0, c1, c2 = 0;
-    int base = ind - 1;  // 0-based
-    const bool lo = sp.specparm < (R)0.125, hi = sp.specparm > (R)0.875;
-    if (lo || hi) {
-        const R p = lo ? sp.fs - (R)1 : -sp.fs;
-        const R p4 = ((p * p) * p) * p;
-        const R fk0 = p4, fk1 = (R)1 - p - (R)2.0 * p4, fk2 = p + p4;
-        if (lo) { c0 = fk0; c1 = fk1; c2 = fk2; }
-        else { c0 = fk2; c1 = fk1; c2 = fk0; base -= 1; }
-    } else {
-        c0 = (R)1. - sp.fs; c1 = sp.fs;
-    }
-    R t[NG];
-    axrow<R, NG, true>(t, c0 * facA, absa, base);
-    axrow<R, NG, false>(t, c1 * facA, absa, base + 1);
-    if (lo || hi) axrow<R, NG, false>(t, c2 * facA, absa, base + 2);
-    axrow<R, NG, false>(t, c0 * facB, absa, base + 9);
-    axrow<R, NG, false>(t, c1 * facB, absa, base + 10);
-    if (lo || hi) axrow<R, NG, false>(t, c2 * facB, absa, base + 11);
+    const int base = ind - 1 + sp.boff;
+    R t[W];
+    axw<R, W, S, true>(t, sp.c0 * facA, absa, base, go);
+    axw<R, W, S, false>(t, sp.c1 * facA, absa, base + 1, go);
+    if (sp.edge) axw<R, W, S, false>(t, sp.c2 * facA, absa, base + 2, go);
+    axw<R, W, S, false>(t, sp.c0 * facB, absa, base + 9, go);
+    axw<R, W, S, false>(t, sp.c1 * facB, absa, base + 10, go);
+    if (sp.edge) axw<R, W, S, false>(t, sp.c2 * facB, absa, base + 11, go);
 #pragma unroll
-    for (int g = 0; g < NG; g++) acc[g] = INIT ? sp.speccomb * t[g] : acc[g] + sp.speccomb * t[g];
+    for (int j = 0; j < W; j++) acc[j] = INIT ? sp.speccomb * t[j] : acc[j] + sp.speccomb * t[j];
 }
-// upper-atmosphere binary side, 5 species rows (e.g. :706-716)
-template <typename R, int NG, bool INIT>
-GR_DEV void major_b5(R (&acc)[NG], const R *__restrict__ absb, int ind, const Spec<R> &sp, R facA, R facB)
+// upper-atmosphere binary side, 5 species rows, always linear (e.g. :706-716)
+template <typename R, int W, int S, bool INIT>
+GR_DEV void major_b5(R (&acc)[W], const R *__restrict__ absb, int ind, const Spec<R> &sp, R facA, R facB, int go)
 {
-    R t[NG];
+    R t[W];
     const R c0 = (R)1. - sp.fs, c1 = sp.fs;
-    axrow<R, NG, true>(t, c0 * facA, absb, ind - 1);
-    axrow<R, NG, false>(t, c1 * facA, absb, ind);
-    axrow<R, NG, false>(t, c0 * facB, absb, ind + 4);
-    axrow<R, NG, false>(t, c1 * facB, absb, ind + 5);
+    axw<R, W, S, true>(t, c0 * facA, absb, ind - 1, go);
+    axw<R, W, S, false>(t, c1 * facA, absb, ind, go);
+    axw<R, W, S, false>(t, c0 * facB, absb, ind + 4, go);
+    axw<R, W, S, false>(t, c1 * facB, absb, ind + 5, go);
 #pragma unroll
-    for (int g = 0; g < NG; g++) acc[g] = INIT ? sp.speccomb * t[g] : acc[g] + sp.speccomb * t[g];
+    for (int j = 0; j < W; j++) acc[j] = INIT ? sp.speccomb * t[j] : acc[j] + sp.speccomb * t[j];
 }
 // single key species: col * 4-point (p,T) interpolation (e.g. :240-244); ind0/ind1 1-based
-template <typename R, int NG>
-GR_DEV void major1(R (&acc)[NG], const R *__restrict__ tab, int ind0, int ind1, const Layer<R> &L, R col)
+template <typename R, int W, int S>
+GR_DEV void major1(R (&acc)[W], const R *__restrict__ tab, int ind0, int ind1, const Layer<R> &L, R col, int go)
 {
-    R t[NG];
-    axrow<R, NG, true>(t, L.fac00, tab, ind0 - 1);
-    axrow<R, NG, false>(t, L.fac10, tab, ind0);
-    axrow<R, NG, false>(t, L.fac01, tab, ind1 - 1);
-    axrow<R, NG, false>(t, L.fac11, tab, ind1);
+    R t[W];
+    axw<R, W, S, true>(t, L.fac00, tab, ind0 - 1, go);
+    axw<R, W, S, false>(t, L.fac10, tab, ind0, go);
+    axw<R, W, S, false>(t, L.fac01, tab, ind1 - 1, go);
+    axw<R, W, S, false>(t, L.fac11, tab, ind1, go);
 #pragma unroll
-    for (int g = 0; g < NG; g++) acc[g] = col * t[g];
+    for (int j = 0; j < W; j++) acc[j] = col * t[j];
 }
 // "too much of a minor gas" column adjustment (e.g. :461-468)
 template <typename R> GR_DEV R adjcol(R colx, R coldry, R chiref, R thresh, R a, R pw)
@@ -329,453 +351,575 @@ template <typename R> GR_DEV R adjcol(R colx, R coldry, R chiref, R thresh, R a,
     return colx;
 }
 
-#define CHI(m, j) (T.chi_mls[((j) - 1) * 7 + ((m) - 1)])
-#define RAT(pair, j) (T.rat[(pair) * 60 + (j)])
+// g-independent state of one (layer, column, band); every band uses a subset
+template <typename R> struct Prep {
+    Spec<R> sp, sp1, sm, sm2, spl;
+    R ca, cb, cc, cd, ce, cf;     // column amounts / scale factors, meaning per band
+    int ind0, ind1;
+};
+
+#define CHI(m, j) ldg(T.chi_mls, (uint32_t)(((j) - 1) * 7 + ((m) - 1)) * (uint32_t)sizeof(R))
+#define RAT(pair, j) ldg(T.rat, (uint32_t)((pair) * 60 + (j)) * (uint32_t)sizeof(R))
 #define IND0A(n) (((L.jp - 1) * 5 + (L.jt - 1)) * (n))
 #define IND1A(n) ((L.jp * 5 + (L.jt1 - 1)) * (n))
 #define IND0B(n) (((L.jp - 13) * 5 + (L.jt - 1)) * (n))
 #define IND1B(n) (((L.jp - 12) * 5 + (L.jt1 - 1)) * (n))
-#define ADD_SELF() add_lin<R, NG>(tau, L.selffac, L.selffrac, B.selfref, L.indself - 1)
-#define ADD_FOR() add_lin<R, NG>(tau, L.forfac, L.forfrac, B.forref, L.indfor - 1)
-#define BAND_HEAD(ib, ng, g0)                                                  \
-    static constexpr int IB = ib, NG = ng, G0 = g0;                            \
-    template <typename R>                                                      \
-    GR_DEV static void tau_pf(const LwDev<R> &T, const LwArgs<R> &A, const Layer<R> &L, R (&tau)[NG], R (&pf)[NG])
-
-// Planck fraction helpers
-template <typename R, int NG> GR_DEV void pf_const(R (&pf)[NG], const R *__restrict__ frac) { ldrow<R, NG>(frac, pf); }
-template <typename R, int NG> GR_DEV void pf_interp(R (&pf)[NG], const R *__restrict__ frac, const Spec<R> &s)
-{
-    lin<R, NG>(pf, s.fs, frac, s.js - 1);
-}
+#define ADD_SELF() add_linw<R, W, S>(tau, L.selffac, L.selffrac, B.selfref, L.indself - 1, go)
+#define ADD_FOR() add_linw<R, W, S>(tau, L.forfac, L.forfrac, B.forref, L.indfor - 1, go)
+#define PF_CONST(frac) ldw<R, W>(frac, (uint32_t)go * (uint32_t)sizeof(R), pf)
+#define PF_INTERP(frac, s) linw<R, W, S>(pf, (s).fs, frac, (s).js - 1, go)
+#define BAND_DECL(ib, ng, g0)                                                                                   \
+    static constexpr int IB = ib, NG = ng, G0 = g0, S = pad4(ng);                                             \
+    template <typename R> GR_DEV static void prep(const LwDev<R> &T, const LwArgs<R> &A, const Layer<R> &L, Prep<R> &P)
+#define BAND_EVAL()                                                                                             \
+    template <typename R, int W>                                                                                \
+    GR_DEV static void eval(const LwDev<R> &T, const Layer<R> &L, const Prep<R> &P, int go, R (&tau)[W], R (&pf)[W])
 
 struct Band1 {  // 10-350 cm-1: h2o; minor n2 (:214-291)
-    BAND_HEAD(1, 10, 0)
+    BAND_DECL(1, 10, 0)
+    {
+        P.ca = colamt(A.h2o, L);
+        P.cb = L.colbrd * L.scaleminorn2;   // scalen2
+        if (L.lower) {
+            P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1;
+            P.cc = L.pavel < (R)250. ? (R)1. - (R)0.15 * ((R)250. - L.pavel) / (R)154.4 : (R)1;
+        } else {
+            P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1;
+            P.cc = (R)1. - (R)0.15 * (L.pavel / (R)95.6);
+        }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colh2o = colamt(A.h2o, L);
-        const R scalen2 = L.colbrd * L.scaleminorn2;
-        R corradj;
         if (L.lower) {
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            add_lin<R, NG>(tau, scalen2, L.minorfrac, B.m[0], L.indminor - 1);
-            corradj = L.pavel < (R)250. ? (R)1. - (R)0.15 * ((R)250. - L.pavel) / (R)154.4 : (R)1;
-            pf_const<R, NG>(pf, B.fracrefa);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[0], L.indminor - 1, go);
+            PF_CONST(B.fracrefa);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
             ADD_FOR();
-            add_lin<R, NG>(tau, scalen2, L.minorfrac, B.m[1], L.indminor - 1);
-            corradj = (R)1. - (R)0.15 * (L.pavel / (R)95.6);
-            pf_const<R, NG>(pf, B.fracrefb);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[1], L.indminor - 1, go);
+            PF_CONST(B.fracrefb);
         }
 #pragma unroll
-        for (int g = 0; g < NG; g++) tau[g] = corradj * tau[g];
+        for (int j = 0; j < W; j++) tau[j] = P.cc * tau[j];
     }
 };
 
 struct Band2 {  // 350-500: h2o (:296-363)
-    BAND_HEAD(2, 12, 10)
+    BAND_DECL(2, 12, 10)
+    {
+        P.ca = colamt(A.h2o, L);
+        if (L.lower) { P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1; P.cc = (R)1. - (R).05 * (L.pavel - (R)100.) / (R)900.; }
+        else { P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1; P.cc = 1; }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colh2o = colamt(A.h2o, L);
         if (L.lower) {
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            const R corradj = (R)1. - (R).05 * (L.pavel - (R)100.) / (R)900.;
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = corradj * tau[g];
-            pf_const<R, NG>(pf, B.fracrefa);
+            for (int j = 0; j < W; j++) tau[j] = P.cc * tau[j];
+            PF_CONST(B.fracrefa);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
             ADD_FOR();
-            pf_const<R, NG>(pf, B.fracrefb);
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
 struct Band3 {  // 500-630: h2o,co2; minor n2o (:368-727)
-    BAND_HEAD(3, 16, 22)
+    BAND_DECL(3, 16, 22)
+    {
+        const R colh2o = colamt(A.h2o, L), colco2 = colamt_nz(A.co2, L), coln2o = colamt_nz(A.n2o, L);
+        P.ca = adjcol<R>(coln2o, L.coldry, CHI(4, L.jp + 1), (R)1.5, (R)0.5, (R)0.65);
+        if (L.lower) {
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
+            P.sm = spec<R>(colh2o, CHI(1, 3) / CHI(2, 3), colco2, 8, T.oneminus);
+            P.spl = spec<R>(colh2o, CHI(1, 9) / CHI(2, 9), colco2, 8, T.oneminus);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
+        } else {
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 4, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 4, T.oneminus);
+            P.sm = spec<R>(colh2o, CHI(1, 13) / CHI(2, 13), colco2, 4, T.oneminus);   // refrat_m_b == refrat_planck_b
+            P.spl = P.sm;
+            P.ind0 = IND0B(5) + P.sp.js; P.ind1 = IND1B(5) + P.sp1.js;
+        }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colh2o = colamt(A.h2o, L), colco2 = colamt_nz(A.co2, L), coln2o = colamt_nz(A.n2o, L);
-        const R adjn2o = adjcol<R>(coln2o, L.coldry, CHI(4, L.jp + 1), (R)1.5, (R)0.5, (R)0.65);
-        R m[NG];
+        R m[W];
         if (L.lower) {
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
-            const Spec<R> sm = spec<R>(colh2o, CHI(1, 3) / CHI(2, 3), colco2, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 9) / CHI(2, 9), colco2, 8, T.oneminus);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_SELF(); ADD_FOR();
-            minor2<R, NG, 9>(m, B.m[0], sm.js, L.indminor, sm.fs, L.minorfrac);
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            minor2w<R, W, S, 9>(m, B.m[0], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
+            PF_INTERP(B.fracrefa, P.spl);
         } else {
-            const R rp = CHI(1, 13) / CHI(2, 13);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 4, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 4, T.oneminus);
-            const Spec<R> sm = spec<R>(colh2o, rp, colco2, 4, T.oneminus);
-            major_b5<R, NG, true>(tau, B.absb, IND0B(5) + sp.js, sp, L.fac00, L.fac10);
-            major_b5<R, NG, false>(tau, B.absb, IND1B(5) + sp1.js, sp1, L.fac01, L.fac11);
+            major_b5<R, W, S, true>(tau, B.absb, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_b5<R, W, S, false>(tau, B.absb, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_FOR();
-            minor2<R, NG, 5>(m, B.m[1], sm.js, L.indminor, sm.fs, L.minorfrac);
-            pf_interp<R, NG>(pf, B.fracrefb, sm);  // refrat_m_b == refrat_planck_b (:421-422)
+            minor2w<R, W, S, 5>(m, B.m[1], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
+            PF_INTERP(B.fracrefb, P.spl);
         }
 #pragma unroll
-        for (int g = 0; g < NG; g++) tau[g] = tau[g] + adjn2o * m[g];
+        for (int j = 0; j < W; j++) tau[j] = tau[j] + P.ca * m[j];
     }
 };
 
 struct Band4 {  // 630-700: h2o,co2 | o3,co2 (:732-962)
-    BAND_HEAD(4, 14, 38)
+    BAND_DECL(4, 14, 38)
     {
-        const BandTab<R> &B = T.b[IB];
         const R colco2 = colamt_nz(A.co2, L);
         if (L.lower) {
             const R colh2o = colamt(A.h2o, L);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 11) / CHI(2, 11), colco2, 8, T.oneminus);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
-            ADD_SELF(); ADD_FOR();
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
+            P.spl = spec<R>(colh2o, CHI(1, 11) / CHI(2, 11), colco2, 8, T.oneminus);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
         } else {
             const R colo3 = colamt_nz(A.o3, L);
-            const Spec<R> sp = spec<R>(colo3, RAT(RAT_O3CO2, L.jp), colco2, 4, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colo3, RAT(RAT_O3CO2, L.jp + 1), colco2, 4, T.oneminus);
-            const Spec<R> spl = spec<R>(colo3, CHI(3, 13) / CHI(2, 13), colco2, 4, T.oneminus);
-            major_b5<R, NG, true>(tau, B.absb, IND0B(5) + sp.js, sp, L.fac00, L.fac10);
-            major_b5<R, NG, false>(tau, B.absb, IND1B(5) + sp1.js, sp1, L.fac01, L.fac11);
-            pf_interp<R, NG>(pf, B.fracrefb, spl);
-            // empirical stratospheric-cooling tweak (:951-957)
-            tau[7] *= (R)0.92; tau[8] *= (R)0.88; tau[9] *= (R)1.07; tau[10] *= (R)1.1;
-            tau[11] *= (R)0.99; tau[12] *= (R)0.88; tau[13] *= (R)0.943;
+            P.sp = spec<R>(colo3, RAT(RAT_O3CO2, L.jp), colco2, 4, T.oneminus);
+            P.sp1 = spec<R>(colo3, RAT(RAT_O3CO2, L.jp + 1), colco2, 4, T.oneminus);
+            P.spl = spec<R>(colo3, CHI(3, 13) / CHI(2, 13), colco2, 4, T.oneminus);
+            P.ind0 = IND0B(5) + P.sp.js; P.ind1 = IND1B(5) + P.sp1.js;
+        }
+    }
+    BAND_EVAL()
+    {
+        const BandTab<R> &B = T.b[IB];
+        if (L.lower) {
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
+            ADD_SELF(); ADD_FOR();
+            PF_INTERP(B.fracrefa, P.spl);
+        } else {
+            major_b5<R, W, S, true>(tau, B.absb, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_b5<R, W, S, false>(tau, B.absb, P.ind1, P.sp1, L.fac01, L.fac11, go);
+            PF_INTERP(B.fracrefb, P.spl);
+            // empirical stratospheric-cooling tweak on g-points 8..14 (:951-957)
+            constexpr double f[16] = {1, 1, 1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.88, 0.943, 1, 1};
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = go + j;
+                const R s = g == 7 ? (R)f[7] : g == 8 ? (R)f[8] : g == 9 ? (R)f[9] : g == 10 ? (R)f[10] : g == 11 ? (R)f[11] :
+                            g == 12 ? (R)f[12] : g == 13 ? (R)f[13] : (R)1;
+                if (g >= 7 && g <= 13) tau[j] = tau[j] * s;
+            }
         }
     }
 };
 
 struct Band5 {  // 700-820: h2o,co2 | o3,co2; minor o3, ccl4 (:967-1229)
-    BAND_HEAD(5, 16, 52)
+    BAND_DECL(5, 16, 52)
     {
-        const BandTab<R> &B = T.b[IB];
-        const R colco2 = colamt_nz(A.co2, L), colo3 = colamt_nz(A.o3, L), colccl4 = colamt(A.ccl4, L);
-        R c4[NG];
-        ldrow<R, NG>(B.m[1], c4);
+        const R colco2 = colamt_nz(A.co2, L);
+        P.ca = colamt_nz(A.o3, L);
+        P.cb = colamt(A.ccl4, L);
         if (L.lower) {
             const R colh2o = colamt(A.h2o, L);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
-            const Spec<R> sm = spec<R>(colh2o, CHI(1, 7) / CHI(2, 7), colco2, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 5) / CHI(2, 5), colco2, 8, T.oneminus);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
-            ADD_SELF(); ADD_FOR();
-            R m[NG];
-            minor2<R, NG, 9>(m, B.m[0], sm.js, L.indminor, sm.fs, L.minorfrac);
-#pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + m[g] * colo3 + colccl4 * c4[g];
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
+            P.sm = spec<R>(colh2o, CHI(1, 7) / CHI(2, 7), colco2, 8, T.oneminus);
+            P.spl = spec<R>(colh2o, CHI(1, 5) / CHI(2, 5), colco2, 8, T.oneminus);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
         } else {
-            const Spec<R> sp = spec<R>(colo3, RAT(RAT_O3CO2, L.jp), colco2, 4, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colo3, RAT(RAT_O3CO2, L.jp + 1), colco2, 4, T.oneminus);
-            const Spec<R> spl = spec<R>(colo3, CHI(3, 43) / CHI(2, 43), colco2, 4, T.oneminus);
-            major_b5<R, NG, true>(tau, B.absb, IND0B(5) + sp.js, sp, L.fac00, L.fac10);
-            major_b5<R, NG, false>(tau, B.absb, IND1B(5) + sp1.js, sp1, L.fac01, L.fac11);
+            P.sp = spec<R>(P.ca, RAT(RAT_O3CO2, L.jp), colco2, 4, T.oneminus);
+            P.sp1 = spec<R>(P.ca, RAT(RAT_O3CO2, L.jp + 1), colco2, 4, T.oneminus);
+            P.spl = spec<R>(P.ca, CHI(3, 43) / CHI(2, 43), colco2, 4, T.oneminus);
+            P.ind0 = IND0B(5) + P.sp.js; P.ind1 = IND1B(5) + P.sp1.js;
+        }
+    }
+    BAND_EVAL()
+    {
+        const BandTab<R> &B = T.b[IB];
+        R c4[W];
+        ldw<R, W>(B.m[1], (uint32_t)go * (uint32_t)sizeof(R), c4);
+        if (L.lower) {
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
+            ADD_SELF(); ADD_FOR();
+            R m[W];
+            minor2w<R, W, S, 9>(m, B.m[0], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + colccl4 * c4[g];
-            pf_interp<R, NG>(pf, B.fracrefb, spl);
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + m[j] * P.ca + P.cb * c4[j];
+            PF_INTERP(B.fracrefa, P.spl);
+        } else {
+            major_b5<R, W, S, true>(tau, B.absb, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_b5<R, W, S, false>(tau, B.absb, P.ind1, P.sp1, L.fac01, L.fac11, go);
+#pragma unroll
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + P.cb * c4[j];
+            PF_INTERP(B.fracrefb, P.spl);
         }
     }
 };
 
 struct Band6 {  // 820-980: h2o; minor co2, cfc11, cfc12 (:1234-1322)
-    BAND_HEAD(6, 8, 68)
+    BAND_DECL(6, 8, 68)
+    {
+        P.cb = colamt(A.cfc11, L); P.cc = colamt(A.cfc12, L);
+        if (L.lower) {
+            P.ca = colamt(A.h2o, L);
+            P.cd = adjcol<R>(colamt_nz(A.co2, L), L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)2.0, (R)0.77);
+            P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1;
+        }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colcfc11 = colamt(A.cfc11, L), colcfc12 = colamt(A.cfc12, L);
-        R c11[NG], c12[NG];
-        ldrow<R, NG>(B.m[1], c11);
-        ldrow<R, NG>(B.m[2], c12);
+        R c11[W], c12[W];
+        ldw<R, W>(B.m[1], (uint32_t)go * (uint32_t)sizeof(R), c11);
+        ldw<R, W>(B.m[2], (uint32_t)go * (uint32_t)sizeof(R), c12);
         if (L.lower) {
-            const R colh2o = colamt(A.h2o, L), colco2 = colamt_nz(A.co2, L);
-            const R adjco2 = adjcol<R>(colco2, L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)2.0, (R)0.77);
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            add_lin<R, NG>(tau, adjco2, L.minorfrac, B.m[0], L.indminor - 1);
+            add_linw<R, W, S>(tau, P.cd, L.minorfrac, B.m[0], L.indminor - 1, go);
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + colcfc11 * c11[g] + colcfc12 * c12[g];
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + P.cb * c11[j] + P.cc * c12[j];
         } else {
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = (R)0.0 + colcfc11 * c11[g] + colcfc12 * c12[g];
+            for (int j = 0; j < W; j++) tau[j] = (R)0.0 + P.cb * c11[j] + P.cc * c12[j];
         }
-        pf_const<R, NG>(pf, B.fracrefa);
+        PF_CONST(B.fracrefa);
     }
 };
 
 struct Band7 {  // 980-1080: h2o,o3 | o3; minor co2 (:1327-1601)
-    BAND_HEAD(7, 12, 76)
+    BAND_DECL(7, 12, 76)
     {
-        const BandTab<R> &B = T.b[IB];
-        const R colco2 = colamt_nz(A.co2, L), colo3 = colamt_nz(A.o3, L);
+        const R colco2 = colamt_nz(A.co2, L);
+        P.ca = colamt_nz(A.o3, L);
         if (L.lower) {
             const R colh2o = colamt(A.h2o, L);
-            const R rp = CHI(1, 3) / CHI(3, 3);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OO3, L.jp), colo3, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OO3, L.jp + 1), colo3, 8, T.oneminus);
-            const Spec<R> sm = spec<R>(colh2o, rp, colo3, 8, T.oneminus);  // refrat_m_a == refrat_planck_a
-            const R adjco2 = adjcol<R>(colco2, L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)3.0, (R)0.79);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
-            ADD_SELF(); ADD_FOR();
-            R m[NG];
-            minor2<R, NG, 9>(m, B.m[0], sm.js, L.indminor, sm.fs, L.minorfrac);
-#pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + adjco2 * m[g];
-            pf_interp<R, NG>(pf, B.fracrefa, sm);
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OO3, L.jp), P.ca, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OO3, L.jp + 1), P.ca, 8, T.oneminus);
+            P.sm = spec<R>(colh2o, CHI(1, 3) / CHI(3, 3), P.ca, 8, T.oneminus);   // refrat_m_a == refrat_planck_a
+            P.cb = adjcol<R>(colco2, L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)3.0, (R)0.79);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
         } else {
-            const R adjco2 = adjcol<R>(colco2, L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)2.0, (R)0.79);
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colo3);
-            add_lin<R, NG>(tau, adjco2, L.minorfrac, B.m[1], L.indminor - 1);
-            pf_const<R, NG>(pf, B.fracrefb);
-            tau[5] *= (R)0.92; tau[6] *= (R)0.88; tau[7] *= (R)1.07; tau[8] *= (R)1.1; tau[9] *= (R)0.99; tau[10] *= (R)0.855;
+            P.cb = adjcol<R>(colco2, L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)2.0, (R)0.79);
+            P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1;
+        }
+    }
+    BAND_EVAL()
+    {
+        const BandTab<R> &B = T.b[IB];
+        if (L.lower) {
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
+            ADD_SELF(); ADD_FOR();
+            R m[W];
+            minor2w<R, W, S, 9>(m, B.m[0], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
+#pragma unroll
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + P.cb * m[j];
+            PF_INTERP(B.fracrefa, P.sm);
+        } else {
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[1], L.indminor - 1, go);
+            PF_CONST(B.fracrefb);
+            // (:1591-1596) g-points 6..11
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = go + j;
+                const R s = g == 5 ? (R)0.92 : g == 6 ? (R)0.88 : g == 7 ? (R)1.07 : g == 8 ? (R)1.1 : g == 9 ? (R)0.99 :
+                            g == 10 ? (R)0.855 : (R)1;
+                if (g >= 5 && g <= 10) tau[j] = tau[j] * s;
+            }
         }
     }
 };
 
 struct Band8 {  // 1080-1180: h2o | o3; minor co2, o3, n2o, cfc12, cfc22 (:1606-1733)
-    BAND_HEAD(8, 8, 88)
+    BAND_DECL(8, 8, 88)
+    {
+        P.cb = colamt_nz(A.o3, L); P.cc = colamt_nz(A.n2o, L);
+        P.cd = colamt(A.cfc12, L); P.ce = colamt(A.cfc22, L);
+        P.cf = adjcol<R>(colamt_nz(A.co2, L), L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)2.0, (R)0.65);   // adjcolco2
+        if (L.lower) { P.ca = colamt(A.h2o, L); P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1; }
+        else { P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1; }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colco2 = colamt_nz(A.co2, L), colo3 = colamt_nz(A.o3, L), coln2o = colamt_nz(A.n2o, L);
-        const R colcfc12 = colamt(A.cfc12, L), colcfc22 = colamt(A.cfc22, L);
-        const R adjco2 = adjcol<R>(colco2, L.coldry, CHI(2, L.jp + 1), (R)3.0, (R)2.0, (R)0.65);
-        R c12[NG], c22[NG];
-        ldrow<R, NG>(B.m[5], c12);
-        ldrow<R, NG>(B.m[6], c22);
+        const R adjco2 = P.cf;
+        R c12[W], c22[W];
+        ldw<R, W>(B.m[5], (uint32_t)go * (uint32_t)sizeof(R), c12);
+        ldw<R, W>(B.m[6], (uint32_t)go * (uint32_t)sizeof(R), c22);
         if (L.lower) {
-            const R colh2o = colamt(A.h2o, L);
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            add_lin<R, NG>(tau, adjco2, L.minorfrac, B.m[0], L.indminor - 1);
-            add_lin<R, NG>(tau, colo3, L.minorfrac, B.m[2], L.indminor - 1);
-            add_lin<R, NG>(tau, coln2o, L.minorfrac, B.m[3], L.indminor - 1);
-            pf_const<R, NG>(pf, B.fracrefa);
+            add_linw<R, W, S>(tau, adjco2, L.minorfrac, B.m[0], L.indminor - 1, go);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[2], L.indminor - 1, go);
+            add_linw<R, W, S>(tau, P.cc, L.minorfrac, B.m[3], L.indminor - 1, go);
+            PF_CONST(B.fracrefa);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colo3);
-            add_lin<R, NG>(tau, adjco2, L.minorfrac, B.m[1], L.indminor - 1);
-            add_lin<R, NG>(tau, coln2o, L.minorfrac, B.m[4], L.indminor - 1);
-            pf_const<R, NG>(pf, B.fracrefb);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.cb, go);
+            add_linw<R, W, S>(tau, adjco2, L.minorfrac, B.m[1], L.indminor - 1, go);
+            add_linw<R, W, S>(tau, P.cc, L.minorfrac, B.m[4], L.indminor - 1, go);
+            PF_CONST(B.fracrefb);
         }
 #pragma unroll
-        for (int g = 0; g < NG; g++) tau[g] = tau[g] + colcfc12 * c12[g] + colcfc22 * c22[g];
+        for (int j = 0; j < W; j++) tau[j] = tau[j] + P.cd * c12[j] + P.ce * c22[j];
     }
 };
 
 struct Band9 {  // 1180-1390: h2o,ch4 | ch4; minor n2o (:1738-2001)
-    BAND_HEAD(9, 12, 96)
+    BAND_DECL(9, 12, 96)
     {
-        const BandTab<R> &B = T.b[IB];
-        const R colch4 = colamt_nz(A.ch4, L), coln2o = colamt_nz(A.n2o, L);
-        const R adjn2o = adjcol<R>(coln2o, L.coldry, CHI(4, L.jp + 1), (R)1.5, (R)0.5, (R)0.65);
+        P.ca = colamt_nz(A.ch4, L);
+        P.cb = adjcol<R>(colamt_nz(A.n2o, L), L.coldry, CHI(4, L.jp + 1), (R)1.5, (R)0.5, (R)0.65);
         if (L.lower) {
             const R colh2o = colamt(A.h2o, L);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp), colch4, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp + 1), colch4, 8, T.oneminus);
-            const Spec<R> sm = spec<R>(colh2o, CHI(1, 3) / CHI(6, 3), colch4, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 9) / CHI(6, 9), colch4, 8, T.oneminus);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp), P.ca, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp + 1), P.ca, 8, T.oneminus);
+            P.sm = spec<R>(colh2o, CHI(1, 3) / CHI(6, 3), P.ca, 8, T.oneminus);
+            P.spl = spec<R>(colh2o, CHI(1, 9) / CHI(6, 9), P.ca, 8, T.oneminus);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
+        } else { P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1; }
+    }
+    BAND_EVAL()
+    {
+        const BandTab<R> &B = T.b[IB];
+        if (L.lower) {
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_SELF(); ADD_FOR();
-            R m[NG];
-            minor2<R, NG, 9>(m, B.m[0], sm.js, L.indminor, sm.fs, L.minorfrac);
+            R m[W];
+            minor2w<R, W, S, 9>(m, B.m[0], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + adjn2o * m[g];
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + P.cb * m[j];
+            PF_INTERP(B.fracrefa, P.spl);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colch4);
-            add_lin<R, NG>(tau, adjn2o, L.minorfrac, B.m[1], L.indminor - 1);
-            pf_const<R, NG>(pf, B.fracrefb);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[1], L.indminor - 1, go);
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
 struct Band10 {  // 1390-1480: h2o (:2006-2072)
-    BAND_HEAD(10, 6, 108)
+    BAND_DECL(10, 6, 108)
+    {
+        P.ca = colamt(A.h2o, L);
+        if (L.lower) { P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1; } else { P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1; }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colh2o = colamt(A.h2o, L);
         if (L.lower) {
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            pf_const<R, NG>(pf, B.fracrefa);
+            PF_CONST(B.fracrefa);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
             ADD_FOR();
-            pf_const<R, NG>(pf, B.fracrefb);
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
 struct Band11 {  // 1480-1800: h2o; minor o2 (:2077-2160)
-    BAND_HEAD(11, 8, 114)
+    BAND_DECL(11, 8, 114)
+    {
+        P.ca = colamt(A.h2o, L);
+        P.cb = colamt(A.o2, L) * L.scaleminor;   // scaleo2
+        if (L.lower) { P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1; } else { P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1; }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colh2o = colamt(A.h2o, L);
-        const R scaleo2 = colamt(A.o2, L) * L.scaleminor;
         if (L.lower) {
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            add_lin<R, NG>(tau, scaleo2, L.minorfrac, B.m[0], L.indminor - 1);
-            pf_const<R, NG>(pf, B.fracrefa);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[0], L.indminor - 1, go);
+            PF_CONST(B.fracrefa);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colh2o);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
             ADD_FOR();
-            add_lin<R, NG>(tau, scaleo2, L.minorfrac, B.m[1], L.indminor - 1);
-            pf_const<R, NG>(pf, B.fracrefb);
+            add_linw<R, W, S>(tau, P.cb, L.minorfrac, B.m[1], L.indminor - 1, go);
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
 struct Band12 {  // 1800-2080: h2o,co2 | nothing (:2165-2345)
-    BAND_HEAD(12, 8, 122)
+    BAND_DECL(12, 8, 122)
+    {
+        if (L.lower) {
+            const R colh2o = colamt(A.h2o, L), colco2 = colamt_nz(A.co2, L);
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
+            P.spl = spec<R>(colh2o, CHI(1, 10) / CHI(2, 10), colco2, 8, T.oneminus);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
+        }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
         if (L.lower) {
-            const R colh2o = colamt(A.h2o, L), colco2 = colamt_nz(A.co2, L);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp), colco2, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCO2, L.jp + 1), colco2, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 10) / CHI(2, 10), colco2, 8, T.oneminus);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_SELF(); ADD_FOR();
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            PF_INTERP(B.fracrefa, P.spl);
         } else {
 #pragma unroll
-            for (int g = 0; g < NG; g++) { tau[g] = 0; pf[g] = 0; }
+            for (int j = 0; j < W; j++) { tau[j] = 0; pf[j] = 0; }
         }
     }
 };
 
 struct Band13 {  // 2080-2250: h2o,n2o | (o3 minor); minor co2, co (:2350-2585)
-    BAND_HEAD(13, 4, 130)
+    BAND_DECL(13, 4, 130)
+    {
+        if (L.lower) {
+            const R colh2o = colamt(A.h2o, L), coln2o = colamt_nz(A.n2o, L);
+            P.ca = (R)1.e-32 * L.coldry;   // colco: covmr == 0 in GEOS (LW/rrtmg_lw_rad.F90:518, setcoef :564)
+            P.sp = spec<R>(colh2o, RAT(RAT_H2ON2O, L.jp), coln2o, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2ON2O, L.jp + 1), coln2o, 8, T.oneminus);
+            P.sm = spec<R>(colh2o, CHI(1, 1) / CHI(4, 1), coln2o, 8, T.oneminus);     // co2 minor
+            P.sm2 = spec<R>(colh2o, CHI(1, 3) / CHI(4, 3), coln2o, 8, T.oneminus);    // co minor
+            P.spl = spec<R>(colh2o, CHI(1, 5) / CHI(4, 5), coln2o, 8, T.oneminus);
+            P.cb = adjcol<R>(colamt_nz(A.co2, L), L.coldry, (R)3.55e-4, (R)3.0, (R)2.0, (R)0.68);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
+        } else {
+            P.ca = colamt_nz(A.o3, L);
+        }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
         if (L.lower) {
-            const R colh2o = colamt(A.h2o, L), coln2o = colamt_nz(A.n2o, L), colco2 = colamt_nz(A.co2, L);
-            const R colco = (R)1.e-32 * L.coldry;  // covmr == 0 in GEOS (LW/rrtmg_lw_rad.F90:518, setcoef :564)
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2ON2O, L.jp), coln2o, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2ON2O, L.jp + 1), coln2o, 8, T.oneminus);
-            const Spec<R> smco2 = spec<R>(colh2o, CHI(1, 1) / CHI(4, 1), coln2o, 8, T.oneminus);
-            const Spec<R> smco = spec<R>(colh2o, CHI(1, 3) / CHI(4, 3), coln2o, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 5) / CHI(4, 5), coln2o, 8, T.oneminus);
-            const R adjco2 = adjcol<R>(colco2, L.coldry, (R)3.55e-4, (R)3.0, (R)2.0, (R)0.68);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_SELF(); ADD_FOR();
-            R m[NG], mc[NG];
-            minor2<R, NG, 9>(m, B.m[0], smco2.js, L.indminor, smco2.fs, L.minorfrac);
-            minor2<R, NG, 9>(mc, B.m[1], smco.js, L.indminor, smco.fs, L.minorfrac);
+            R m[W], mc[W];
+            minor2w<R, W, S, 9>(m, B.m[0], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
+            minor2w<R, W, S, 9>(mc, B.m[1], P.sm2.js, L.indminor, P.sm2.fs, L.minorfrac, go);
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + adjco2 * m[g] + colco * mc[g];
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + P.cb * m[j] + P.ca * mc[j];
+            PF_INTERP(B.fracrefa, P.spl);
         } else {
-            const R colo3 = colamt_nz(A.o3, L);
-            R m[NG];
-            lin<R, NG>(m, L.minorfrac, B.m[2], L.indminor - 1);
+            R m[W];
+            linw<R, W, S>(m, L.minorfrac, B.m[2], L.indminor - 1, go);
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = colo3 * m[g];
-            pf_const<R, NG>(pf, B.fracrefb);
+            for (int j = 0; j < W; j++) tau[j] = P.ca * m[j];
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
 struct Band14 {  // 2250-2380: co2 (:2590-2653)
-    BAND_HEAD(14, 2, 134)
+    BAND_DECL(14, 2, 134)
+    {
+        P.ca = colamt_nz(A.co2, L);
+        if (L.lower) { P.ind0 = IND0A(1) + 1; P.ind1 = IND1A(1) + 1; } else { P.ind0 = IND0B(1) + 1; P.ind1 = IND1B(1) + 1; }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
-        const R colco2 = colamt_nz(A.co2, L);
         if (L.lower) {
-            major1<R, NG>(tau, B.absa, IND0A(1) + 1, IND1A(1) + 1, L, colco2);
+            major1<R, W, S>(tau, B.absa, P.ind0, P.ind1, L, P.ca, go);
             ADD_SELF(); ADD_FOR();
-            pf_const<R, NG>(pf, B.fracrefa);
+            PF_CONST(B.fracrefa);
         } else {
-            major1<R, NG>(tau, B.absb, IND0B(1) + 1, IND1B(1) + 1, L, colco2);
-            pf_const<R, NG>(pf, B.fracrefb);
+            major1<R, W, S>(tau, B.absb, P.ind0, P.ind1, L, P.ca, go);
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
 struct Band15 {  // 2380-2600: n2o,co2 | nothing; minor n2 (:2658-2866)
-    BAND_HEAD(15, 2, 136)
+    BAND_DECL(15, 2, 136)
+    {
+        if (L.lower) {
+            const R coln2o = colamt_nz(A.n2o, L), colco2 = colamt_nz(A.co2, L);
+            P.sp = spec<R>(coln2o, RAT(RAT_N2OCO2, L.jp), colco2, 8, T.oneminus);
+            P.sp1 = spec<R>(coln2o, RAT(RAT_N2OCO2, L.jp + 1), colco2, 8, T.oneminus);
+            P.sm = spec<R>(coln2o, CHI(4, 1) / CHI(2, 1), colco2, 8, T.oneminus);   // refrat_m_a == refrat_planck_a
+            P.ca = L.colbrd * L.scaleminor;   // scalen2
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
+        }
+    }
+    BAND_EVAL()
     {
         const BandTab<R> &B = T.b[IB];
         if (L.lower) {
-            const R coln2o = colamt_nz(A.n2o, L), colco2 = colamt_nz(A.co2, L);
-            const R rp = CHI(4, 1) / CHI(2, 1);
-            const Spec<R> sp = spec<R>(coln2o, RAT(RAT_N2OCO2, L.jp), colco2, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(coln2o, RAT(RAT_N2OCO2, L.jp + 1), colco2, 8, T.oneminus);
-            const Spec<R> sm = spec<R>(coln2o, rp, colco2, 8, T.oneminus);  // refrat_m_a == refrat_planck_a
-            const R scalen2 = L.colbrd * L.scaleminor;
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_SELF(); ADD_FOR();
-            R m[NG];
-            minor2<R, NG, 9>(m, B.m[0], sm.js, L.indminor, sm.fs, L.minorfrac);
+            R m[W];
+            minor2w<R, W, S, 9>(m, B.m[0], P.sm.js, L.indminor, P.sm.fs, L.minorfrac, go);
 #pragma unroll
-            for (int g = 0; g < NG; g++) tau[g] = tau[g] + scalen2 * m[g];
-            pf_interp<R, NG>(pf, B.fracrefa, sm);
+            for (int j = 0; j < W; j++) tau[j] = tau[j] + P.ca * m[j];
+            PF_INTERP(B.fracrefa, P.sm);
         } else {
 #pragma unroll
-            for (int g = 0; g < NG; g++) { tau[g] = 0; pf[g] = 0; }
+            for (int j = 0; j < W; j++) { tau[j] = 0; pf[j] = 0; }
         }
     }
 };
 
 struct Band16 {  // 2600-3250: h2o,ch4 | ch4 (:2871-3126)
-    BAND_HEAD(16, 2, 138)
+    BAND_DECL(16, 2, 138)
     {
-        const BandTab<R> &B = T.b[IB];
-        const R colch4 = colamt_nz(A.ch4, L);
+        P.ca = colamt_nz(A.ch4, L);
         if (L.lower) {
             const R colh2o = colamt(A.h2o, L);
-            const Spec<R> sp = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp), colch4, 8, T.oneminus);
-            const Spec<R> sp1 = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp + 1), colch4, 8, T.oneminus);
-            const Spec<R> spl = spec<R>(colh2o, CHI(1, 6) / CHI(6, 6), colch4, 8, T.oneminus);
-            major_a<R, NG, true>(tau, B.absa, IND0A(9) + sp.js, sp, L.fac00, L.fac10);
-            major_a<R, NG, false>(tau, B.absa, IND1A(9) + sp1.js, sp1, L.fac01, L.fac11);
+            P.sp = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp), P.ca, 8, T.oneminus);
+            P.sp1 = spec<R>(colh2o, RAT(RAT_H2OCH4, L.jp + 1), P.ca, 8, T.oneminus);
+            P.spl = spec<R>(colh2o, CHI(1, 6) / CHI(6, 6), P.ca, 8, T.oneminus);
+            P.ind0 = IND0A(9) + P.sp.js; P.ind1 = IND1A(9) + P.sp1.js;
+        }
+    }
+    BAND_EVAL()
+    {
+        const BandTab<R> &B = T.b[IB];
+        if (L.lower) {
+            major_a<R, W, S, true>(tau, B.absa, P.ind0, P.sp, L.fac00, L.fac10, go);
+            major_a<R, W, S, false>(tau, B.absa, P.ind1, P.sp1, L.fac01, L.fac11, go);
             ADD_SELF(); ADD_FOR();
-            pf_interp<R, NG>(pf, B.fracrefa, spl);
+            PF_INTERP(B.fracrefa, P.spl);
         } else {
             // reference quirk kept: nspb(16) = 0 (rrtmg_lw_init.F90:195) so ind0 = ind1 = 1 (:3110-3111)
-            major1<R, NG>(tau, B.absb, 1, 1, L, colch4);
-            pf_const<R, NG>(pf, B.fracrefb);
+            major1<R, W, S>(tau, B.absb, 1, 1, L, P.ca, go);
+            PF_CONST(B.fracrefb);
         }
     }
 };
 
-#undef BAND_HEAD
+#undef BAND_DECL
+#undef BAND_EVAL
 #undef ADD_SELF
 #undef ADD_FOR
+#undef PF_CONST
+#undef PF_INTERP
+#undef ROWB
 
 // ---------------------------------------------------------------------------------------------------
 // Fused taumol + rtrnmc for one (column, band): LW/rrtmg_lw_rtrnmc.F90:164-388.
 // ---------------------------------------------------------------------------------------------------
 template <typename R> GR_DEV void load_layer(const LwArgs<R> &A, int lay, int col, Layer<R> &L)
 {
-    const size_t w = (size_t)lay * A.ncol + col;
+    // uniform (SGPR) field base + one shared 32-bit per-lane byte offset
+    const uint32_t cell = (uint32_t)lay * (uint32_t)A.ncol + (uint32_t)col;
+    const uint32_t wb = cell * (uint32_t)sizeof(R);
     const size_t fs = (size_t)A.nlay * A.ncol;
-    const R *sc = A.sc + w;
-    L.fac00 = sc[SC_FAC00 * fs]; L.fac01 = sc[SC_FAC01 * fs]; L.fac10 = sc[SC_FAC10 * fs]; L.fac11 = sc[SC_FAC11 * fs];
-    L.coldry = sc[SC_COLDRY * fs]; L.forfac = sc[SC_FORFAC * fs]; L.forfrac = sc[SC_FORFRAC * fs];
-    L.selffac = sc[SC_SELFFAC * fs]; L.selffrac = sc[SC_SELFFRAC * fs]; L.minorfrac = sc[SC_MINORFRAC * fs];
-    L.scaleminor = sc[SC_SCALEMINOR * fs]; L.scaleminorn2 = sc[SC_SCALEMINORN2 * fs]; L.colbrd = sc[SC_COLBRD * fs];
-    const uint32_t p = A.scidx[w];
+#define SCF(f) ldg(A.sc + (size_t)(f) * fs, wb)
+    L.fac00 = SCF(SC_FAC00); L.fac01 = SCF(SC_FAC01); L.fac10 = SCF(SC_FAC10); L.fac11 = SCF(SC_FAC11);
+    L.coldry = SCF(SC_COLDRY); L.forfac = SCF(SC_FORFAC); L.forfrac = SCF(SC_FORFRAC);
+    L.selffac = SCF(SC_SELFFAC); L.selffrac = SCF(SC_SELFFRAC); L.minorfrac = SCF(SC_MINORFRAC);
+    L.scaleminor = SCF(SC_SCALEMINOR); L.scaleminorn2 = SCF(SC_SCALEMINORN2); L.colbrd = SCF(SC_COLBRD);
+#undef SCF
+    const uint32_t p = ldg(A.scidx, cell * 4u);
     L.jp = p & 63; L.jt = (p >> 6) & 7; L.jt1 = (p >> 9) & 7; L.indfor = (p >> 12) & 3; L.indself = (p >> 14) & 15;
     L.indminor = (p >> 18) & 31; L.lower = (p >> 23) & 1;
-    L.i = (size_t)lay * A.ld + col;
-    L.pavel = A.play[L.i];
+    L.ab = ((uint32_t)lay * (uint32_t)A.ld + (uint32_t)col) * (uint32_t)sizeof(R);
+    L.pavel = ldg(A.play, L.ab);
 }
 
 // Planck function of band IB at temperature t by linear interpolation in totplnk(181,16)
@@ -784,20 +928,33 @@ template <typename R> GR_DEV R planck_at(const R *__restrict__ totplnk, int ib, 
 {
     const int ind = clampi((int)(t - (R)159.), 1, 180);
     const R frac = t - (R)159. - (R)ind;
-    const R *p = totplnk + (size_t)(ib - 1) * 181 + (ind - 1);
-    const R d = p[1] - p[0];
-    return p[0] + frac * d;
+    const uint32_t o = (uint32_t)(ind - 1) * (uint32_t)sizeof(R);
+    const R *tb = totplnk + (ib - 1) * 181;          // uniform: ib is a compile-time band number
+    const R p0 = ldg(tb, o), p1 = ldg(tb, o + (uint32_t)sizeof(R));
+    const R d = p1 - p0;
+    return p0 + frac * d;
 }
 
-template <typename R, typename BAND>
+// Workspace layout of the per-cell planes taucmc / s1 / s2: band-major, then [layer][g-in-band][column]:
+//   element offset = G0*nlay*n + ((lay*NG + g)*n + col)
+// so one band's sub-array stays below 4 GiB and a cell is  uniform band base + 32-bit byte offset.
+//
+// CLD = false: 256-column block without any cloud (clear == total, one stream);
+// CLD = true : general case, per-lane `ccol` predicate, separate clear-sky stream once the streams part.
+// DBG = true : additionally dumps taug/pfracs in the reference's (nlay,140,ncol) layout (test hook only).
+template <typename R, typename BAND, bool CLD, bool DBG>
 GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
 {
     constexpr int NG = BAND::NG, IB = BAND::IB, G0 = BAND::G0;
+    constexpr int W = NG >= 4 ? 4 : 2;
+    constexpr int NQ = (NG + W - 1) / W;
     using R2 = typename Vec2<R>::T;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
     const bool dudTs = A.dudTs != 0;
     const R bpade = T.bpade, tblint = (R)NTBL;
     const R sumfac = (R)0.5 * T.delwave[IB] * T.fluxfac;
+    const uint32_t ucol = (uint32_t)col;
+    const uint32_t cb = ucol * (uint32_t)sizeof(R);       // byte offset of this column in a row of reals
 
     // diffusivity angle (:177-186)
     R secdiff = (R)1.66;
@@ -805,176 +962,210 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
         constexpr double a0[17] = {0, 1.66, 1.55, 1.58, 1.66, 1.54, 1.454, 1.89, 1.33, 1.668, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66};
         constexpr double a1[17] = {0, 0.00, 0.25, 0.22, 0.00, 0.13, 0.446, -0.10, 0.40, -0.006, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
         constexpr double a2[17] = {0, 0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.19, -0.062, 0.414, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
-        secdiff = (R)a0[IB] + (R)a1[IB] * gr_exp<R>((R)a2[IB] * A.pwvcm[col]);
+        secdiff = (R)a0[IB] + (R)a1[IB] * gr_exp<R>((R)a2[IB] * ldg(A.pwvcm, cb));
         secdiff = secdiff > (R)1.80 ? (R)1.80 : (secdiff < (R)1.50 ? (R)1.50 : secdiff);
     }
-    const bool ccol = A.colcloudy[col] != 0;
-    const size_t cell0 = (size_t)G0 * nlay * n + col;   // + (g*nlay + lay)*n
-    R *part = A.part + (size_t)(IB - 1) * (nlay + 1) * n + col;   // + (q*16*(nlay+1) + lev)*n
-    const size_t qs = (size_t)NB_LW * (nlay + 1) * n;
+    const bool ccol = CLD && ldg(A.colcloudy, ucol) != 0;
 
-    R radld[NG], radclrd[NG], pfsfc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) { radld[g] = 0; radclrd[g] = 0; pfsfc[g] = 0; }
-    bool diverge = false;
-    int ltop = -1;   // highest optically cloudy layer: where the clear/total streams part (:297-307)
+    // uniform bases
+    const size_t bandoff = (size_t)G0 * nlay * n;                         // this band's sub-array of the cell planes
+    const R *const taucmc_b = A.taucmc + bandoff;
+    R2 *const s1_b = A.s1 + bandoff;
+    R2 *const s2_b = A.s2 + bandoff;
+    const size_t qs = (size_t)NB_LW * (nlay + 1) * n;                     // one flux kind of `part`
+    R *const part = A.part + (size_t)(IB - 1) * (nlay + 1) * n;           // [(kind*qs) + lev*n + col]
+#define PART(kind, lev, val) stg(part + (size_t)(kind) * qs + (size_t)(lev) * n, cb, (R)(val))
 
-    // ---- downward sweep, top layer -> surface ------------------------------------------------------
-    R plk_up = planck_at<R>(T.totplnk, IB, A.tlev[(size_t)nlay * ld + col]);   // level above the current layer
-    for (int lay = nlay - 1; lay >= 0; lay--) {
-        Layer<R> L;
-        load_layer<R>(A, lay, col, L);
-        R tau[NG], pf[NG];
-        BAND::template tau_pf<R>(T, A, L, tau, pf);
-        const R ta = A.tauaer ? A.tauaer[((size_t)(IB - 1) * nlay + lay) * ld + col] : (R)0;
-        const R blay = planck_at<R>(T.totplnk, IB, A.tlay[L.i]);
-        const R plk_dn = planck_at<R>(T.totplnk, IB, A.tlev[L.i]);
-        const R dplankup = plk_up - blay, dplankdn = plk_dn - blay;
-        plk_up = plk_dn;
-        if (A.dbg_taug) {
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                const size_t o = ((size_t)col * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
-                A.dbg_taug[o] = tau[g] + ta;
-                A.dbg_pfracs[o] = pf[g];
-            }
-        }
-        const bool laycld = ccol && A.laycloudy[(size_t)lay * n + col] != 0;
-        if (laycld && !diverge) { diverge = true; ltop = lay; }   // (:297-299) set before the clear-sky update of this layer
-        R dsum = 0, dcsum = 0;
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            R odepth = secdiff * (tau[g] + ta);
-            if (odepth < 0) odepth = 0;
-            const R tblind = odepth / (bpade + odepth);
-            const int itgas = (int)(tblint * tblind + (R)0.5);
-            const R2 e = T.lut[itgas];
-            const R agas = (R)1. - e.x, tfacgas = e.y;
-            const R bbdgas = pf[g] * (blay + tfacgas * dplankdn);
-            const R bbugas = pf[g] * (blay + tfacgas * dplankup);
-            const size_t c = cell0 + ((size_t)g * nlay + lay) * n;
-            R atot = agas, bbutot = bbugas;
-            const R radprev = radld[g];
-            bool cldcell = false;
-            if (laycld) {
-                const R tc = A.taucmc[c];
-                if (tc > 0) {
-                    cldcell = true;
-                    const R odcld = secdiff * tc;
-                    const R odtot = T.tau_tbl[itgas] + odcld;   // add cloud to the DISCRETISED gas tau (:264-268)
-                    const R tb2 = odtot / (bpade + odtot);
-                    const int ittot = (int)(tblint * tb2 + (R)0.5);
-                    const R2 e2 = T.lut[ittot];
-                    atot = (R)1. - e2.x;
-                    const R bbdtot = pf[g] * (blay + e2.y * dplankdn);
-                    bbutot = pf[g] * (blay + e2.y * dplankup);
-                    radld[g] = radprev + (bbdtot - radprev) * atot;
-                }
-            }
-            if (!cldcell) radld[g] = radprev + (bbdgas - radprev) * agas;
-            R2 s; s.x = atot; s.y = bbutot;
-            A.s1[c] = s;
-            dsum = dsum + sumfac * radld[g];
-            if (ccol) {
-                if (diverge) {
-                    radclrd[g] = radclrd[g] + (bbdgas - radclrd[g]) * agas;
-                    R2 sg; sg.x = agas; sg.y = bbugas;
-                    A.s2[c] = sg;
-                } else {
-                    radclrd[g] = radld[g];
-                }
-                dcsum = dcsum + sumfac * radclrd[g];
-            }
-            if (lay == 0) pfsfc[g] = pf[g];
-        }
-        part[(0 * qs) + (size_t)lay * n] = dsum;
-        if (ccol) part[(1 * qs) + (size_t)lay * n] = dcsum;
-    }
-    // TOA downward flux is zero (level nlay); written so the reduce kernel can sum unconditionally
-    part[(0 * qs) + (size_t)nlay * n] = 0;
-    if (ccol) part[(1 * qs) + (size_t)nlay * n] = 0;
-
-    // ---- surface (:319-333): emission + reflection --------------------------------------------------
-    const R semis = A.emis[(size_t)(IB - 1) * ld + col];
-    const R tb = A.tsfc[col];
+    // surface terms (:319-333), needed when the down sweep reaches layer 0
+    const R semis = ldg(A.emis + (size_t)(IB - 1) * ld, cb);
+    const R tb = ldg(A.tsfc, cb);
     const R plankbnd = semis * planck_at<R>(T.totplnk, IB, tb);
     const R dplankbnd = dudTs ? semis * planck_at<R>(T.totplnkderiv, IB, tb) : (R)0;
     const R reflect = (R)1. - semis;
-    R radlu[NG], radclru[NG], dlu[NG], dclru[NG];
-    R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
+
+    // radiances per g-point: downward during the first sweep, converted in place to upward at the surface
+    R rad[NG], radc[NG], dlu[NG], dclu[NG];   // radc/dclu are dead (eliminated) when CLD == false
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const R rad0 = pfsfc[g] * plankbnd;
-        radlu[g] = rad0 + reflect * radld[g];
-        radclru[g] = rad0 + reflect * radclrd[g];
-        usum = usum + sumfac * radlu[g];
-        ucsum = ucsum + sumfac * radclru[g];
-        dlu[g] = pfsfc[g] * dplankbnd;
-        dclru[g] = dlu[g];
-        dusum = dusum + sumfac * dlu[g];
-        ducsum = ducsum + sumfac * dclru[g];
+    for (int g = 0; g < NG; g++) { rad[g] = 0; dlu[g] = 0; radc[g] = 0; dclu[g] = 0; }
+    bool diverge = false;
+    int ltop = -1;   // highest optically cloudy layer: where the clear/total streams part (:297-307)
+    R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
+
+    // ---- downward sweep, top layer -> surface ------------------------------------------------------
+    R plk_up = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)nlay * ld, cb));   // level above the current layer
+    for (int lay = nlay - 1; lay >= 0; lay--) {
+        Layer<R> L;
+        load_layer<R>(A, lay, col, L);
+        Prep<R> P;
+        BAND::template prep<R>(T, A, L, P);
+        const R ta = A.tauaer ? ldg(A.tauaer + (size_t)(IB - 1) * nlay * ld, L.ab) : (R)0;
+        const R blay = planck_at<R>(T.totplnk, IB, ldg(A.tlay, L.ab));
+        const R plk_dn = planck_at<R>(T.totplnk, IB, ldg(A.tlev, L.ab));
+        const R dplankup = plk_up - blay, dplankdn = plk_dn - blay;
+        plk_up = plk_dn;
+        bool laycld = false;
+        if (CLD) {
+            laycld = ccol && ldg(A.laycloudy, (uint32_t)lay * (uint32_t)n + ucol) != 0;
+            if (laycld && !diverge) { diverge = true; ltop = lay; }   // (:297-299) before this layer's clear-sky update
+        }
+        const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;   // g = 0 cell of this layer; + g*n
+        R dsum = 0, dcsum = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            R tau[W], pf[W];
+            BAND::template eval<R, W>(T, L, P, q * W, tau, pf);
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                if (g >= NG) continue;   // padding of the last group
+                if (DBG) {
+                    const size_t o = ((size_t)col * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
+                    A.dbg_taug[o] = tau[j] + ta;
+                    A.dbg_pfracs[o] = pf[j];
+                }
+                R odepth = secdiff * (tau[j] + ta);
+                if (odepth < 0) odepth = 0;
+                const R tblind = odepth / (bpade + odepth);
+                const int itgas = (int)(tblint * tblind + (R)0.5);
+                const R2 e = ldg(T.lut, (uint32_t)itgas * (uint32_t)sizeof(R2));
+                const R agas = (R)1. - e.x, tfacgas = e.y;
+                const R bbdgas = pf[j] * (blay + tfacgas * dplankdn);
+                const R bbugas = pf[j] * (blay + tfacgas * dplankup);
+                const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
+                R atot = agas, bbutot = bbugas;
+                const R radprev = rad[g];
+                bool cldcell = false;
+                if (CLD && laycld) {
+                    const R tc = ldg(taucmc_b, cell * (uint32_t)sizeof(R));
+                    if (tc > 0) {
+                        cldcell = true;
+                        // cloud added to the DISCRETISED gas tau (:264-268)
+                        const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
+                        const R tb2 = odtot / (bpade + odtot);
+                        const int ittot = (int)(tblint * tb2 + (R)0.5);
+                        const R2 e2 = ldg(T.lut, (uint32_t)ittot * (uint32_t)sizeof(R2));
+                        atot = (R)1. - e2.x;
+                        const R bbdtot = pf[j] * (blay + e2.y * dplankdn);
+                        bbutot = pf[j] * (blay + e2.y * dplankup);
+                        rad[g] = radprev + (bbdtot - radprev) * atot;
+                    }
+                }
+                if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
+                R2 sv; sv.x = atot; sv.y = bbutot;
+                stg(s1_b, cell * (uint32_t)sizeof(R2), sv);
+                dsum = dsum + sumfac * rad[g];
+                if (CLD && ccol) {
+                    if (diverge) {
+                        radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
+                        R2 sg; sg.x = agas; sg.y = bbugas;
+                        stg(s2_b, cell * (uint32_t)sizeof(R2), sg);
+                    } else {
+                        radc[g] = rad[g];
+                    }
+                    dcsum = dcsum + sumfac * radc[g];
+                }
+                if (lay == 0) {
+                    // surface: emission + reflection turn the downward radiance into the upward one (:319-333)
+                    const R rad0 = pf[j] * plankbnd;
+                    rad[g] = rad0 + reflect * rad[g];
+                    dlu[g] = pf[j] * dplankbnd;
+                    usum = usum + sumfac * rad[g];
+                    dusum = dusum + sumfac * dlu[g];
+                    if (CLD) {
+                        radc[g] = rad0 + reflect * radc[g];
+                        dclu[g] = dlu[g];
+                        ucsum = ucsum + sumfac * radc[g];
+                        ducsum = ducsum + sumfac * dclu[g];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep one g-group's table rows in flight at a time
+        }
+        PART(0, lay, dsum);
+        if (CLD && ccol) PART(1, lay, dcsum);
     }
-    part[2 * qs] = usum;
-    if (ccol) part[3 * qs] = ucsum;
-    if (dudTs) { part[4 * qs] = dusum; if (ccol) part[5 * qs] = ducsum; }
+    // TOA downward flux is zero (level nlay); written so the reduce kernel can sum unconditionally
+    PART(0, nlay, 0);
+    if (CLD && ccol) PART(1, nlay, 0);
+    PART(2, 0, usum);
+    if (CLD && ccol) PART(3, 0, ucsum);
+    if (dudTs) { PART(4, 0, dusum); if (CLD && ccol) PART(5, 0, ducsum); }
 
     // ---- upward sweep, surface -> top (:336-379) -----------------------------------------------------
     for (int lay = 0; lay < nlay; lay++) {
         usum = 0; ucsum = 0; dusum = 0; ducsum = 0;
+        const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const size_t c = cell0 + ((size_t)g * nlay + lay) * n;
-            const R2 s = A.s1[c];
-            radlu[g] = radlu[g] + (s.y - radlu[g]) * s.x;
-            dlu[g] = dlu[g] - dlu[g] * s.x;
-            usum = usum + sumfac * radlu[g];
+            const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
+            const R2 sv = ldg(s1_b, cell * (uint32_t)sizeof(R2));
+            rad[g] = rad[g] + (sv.y - rad[g]) * sv.x;
+            dlu[g] = dlu[g] - dlu[g] * sv.x;
+            usum = usum + sumfac * rad[g];
             dusum = dusum + sumfac * dlu[g];
-            if (ccol) {
+            if (CLD && ccol) {
                 if (diverge) {
-                    const R2 sg = (lay <= ltop) ? A.s2[c] : s;   // above ltop the layer is clear: gas == total
-                    radclru[g] = radclru[g] + (sg.y - radclru[g]) * sg.x;
-                    dclru[g] = dclru[g] - dclru[g] * sg.x;
+                    // above ltop the layer is clear for every g-point: gas == total
+                    const R2 sg = (lay <= ltop) ? ldg(s2_b, cell * (uint32_t)sizeof(R2)) : sv;
+                    radc[g] = radc[g] + (sg.y - radc[g]) * sg.x;
+                    dclu[g] = dclu[g] - dclu[g] * sg.x;
                 } else {
-                    radclru[g] = radlu[g];
-                    dclru[g] = dlu[g];
+                    radc[g] = rad[g];
+                    dclu[g] = dlu[g];
                 }
-                ucsum = ucsum + sumfac * radclru[g];
-                ducsum = ducsum + sumfac * dclru[g];
+                ucsum = ucsum + sumfac * radc[g];
+                ducsum = ducsum + sumfac * dclu[g];
             }
         }
-        const size_t o = (size_t)(lay + 1) * n;
-        part[2 * qs + o] = usum;
-        if (ccol) part[3 * qs + o] = ucsum;
-        if (dudTs) { part[4 * qs + o] = dusum; if (ccol) part[5 * qs + o] = ducsum; }
+        PART(2, lay + 1, usum);
+        if (CLD && ccol) PART(3, lay + 1, ucsum);
+        if (dudTs) { PART(4, lay + 1, dusum); if (CLD && ccol) PART(5, lay + 1, ducsum); }
     }
+#undef PART
 }
 
 // band launch order: heaviest first (binary-species bands with 16/14/12 g-points, then the rest)
 __constant__ const int LW_BAND_ORDER[NB_LW] = {3, 5, 4, 7, 9, 2, 1, 8, 12, 6, 11, 13, 10, 15, 16, 14};
-
-template <typename R>
-__global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, const LwDev<R> *__restrict__ Tp)
+__host__ __device__ constexpr int lw_band_g0(int ib)
 {
+    constexpr int g0[17] = {0, 0, 10, 22, 38, 52, 68, 76, 88, 96, 108, 114, 122, 130, 134, 136, 138};
+    return g0[ib];
+}
+__host__ __device__ constexpr int lw_band_ng(int ib)
+{
+    constexpr int ng[17] = {0, 10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2};
+    return ng[ib];
+}
+
+// blockIdx.y selects the band.  Two instantiations are launched back to back: CLD = false handles the
+// 256-column blocks in which k_validate_pwv found no cloud at all (blkcloudy == 0), CLD = true the others;
+// a block of the wrong kind exits immediately, so each kernel keeps the register budget of its own path.
+// T is passed BY VALUE: table pointers that arrive as kernel arguments are known to be global-address-space
+// and wave-uniform, so a table row fetch is `global_load_dwordx4 v, voff, s[base:base+1]`; behind a
+// pointer-to-struct they degrade to flat loads with a 64-bit per-lane address each.
+template <typename R, bool CLD, bool DBG>
+__global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
+{
+    if (!DBG && (A.blkcloudy[blockIdx.x] != 0) != CLD) return;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ncol) return;
-    const LwDev<R> &T = *Tp;
     switch (LW_BAND_ORDER[blockIdx.y]) {
-        case 1: band_body<R, Band1>(A, T, col); break;
-        case 2: band_body<R, Band2>(A, T, col); break;
-        case 3: band_body<R, Band3>(A, T, col); break;
-        case 4: band_body<R, Band4>(A, T, col); break;
-        case 5: band_body<R, Band5>(A, T, col); break;
-        case 6: band_body<R, Band6>(A, T, col); break;
-        case 7: band_body<R, Band7>(A, T, col); break;
-        case 8: band_body<R, Band8>(A, T, col); break;
-        case 9: band_body<R, Band9>(A, T, col); break;
-        case 10: band_body<R, Band10>(A, T, col); break;
-        case 11: band_body<R, Band11>(A, T, col); break;
-        case 12: band_body<R, Band12>(A, T, col); break;
-        case 13: band_body<R, Band13>(A, T, col); break;
-        case 14: band_body<R, Band14>(A, T, col); break;
-        case 15: band_body<R, Band15>(A, T, col); break;
-        default: band_body<R, Band16>(A, T, col); break;
+        case 1: band_body<R, Band1, CLD, DBG>(A, T, col); break;
+        case 2: band_body<R, Band2, CLD, DBG>(A, T, col); break;
+        case 3: band_body<R, Band3, CLD, DBG>(A, T, col); break;
+        case 4: band_body<R, Band4, CLD, DBG>(A, T, col); break;
+        case 5: band_body<R, Band5, CLD, DBG>(A, T, col); break;
+        case 6: band_body<R, Band6, CLD, DBG>(A, T, col); break;
+        case 7: band_body<R, Band7, CLD, DBG>(A, T, col); break;
+        case 8: band_body<R, Band8, CLD, DBG>(A, T, col); break;
+        case 9: band_body<R, Band9, CLD, DBG>(A, T, col); break;
+        case 10: band_body<R, Band10, CLD, DBG>(A, T, col); break;
+        case 11: band_body<R, Band11, CLD, DBG>(A, T, col); break;
+        case 12: band_body<R, Band12, CLD, DBG>(A, T, col); break;
+        case 13: band_body<R, Band13, CLD, DBG>(A, T, col); break;
+        case 14: band_body<R, Band14, CLD, DBG>(A, T, col); break;
+        case 15: band_body<R, Band15, CLD, DBG>(A, T, col); break;
+        default: band_body<R, Band16, CLD, DBG>(A, T, col); break;
     }
 }
 

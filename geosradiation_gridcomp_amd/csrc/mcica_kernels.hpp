@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__res
         const int ib = MODE == 0 ? (is < 10 ? 1 : is < 22 ? 2 : is < 38 ? 3 : is < 52 ? 4 : is < 68 ? 5 : is < 76 ? 6 : is < 88 ? 7 :
                                     is < 96 ? 8 : is < 108 ? 9 : is < 114 ? 10 : is < 122 ? 11 : is < 130 ? 12 : is < 134 ? 13 :
                                     is < 136 ? 14 : is < 138 ? 15 : 16) : 0;
+        // taucmc plane layout (see band_body): band-major, then [layer][g-in-band][column]
+        const size_t tb0 = MODE == 0 ? (size_t)lw_band_g0(ib) * nlay * n + (size_t)(is - lw_band_g0(ib)) * n + col : 0;
+        const size_t tbs = MODE == 0 ? (size_t)lw_band_ng(ib) * n : 0;     // + il * tbs
         bool any_all = false, any_hi = false, any_mid = false, any_lo = false;
         // ---- pass 1: cloud presence with exponential overlap (:406-414) ----
         R cprev = 0;
@@ -241,14 +244,14 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__res
                 if (MODE == 0) {
                     R tau = 0;
                     if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
-                    M.taucmc[((size_t)is * nlay + il) * n + col] = tau;
+                    M.taucmc[tb0 + (size_t)il * tbs] = tau;
                     if (tau > 0) M.laycloudy[w] = 1;
                 } else {
                     const size_t o = ((size_t)col * M.nsubcol + is) * nlay + il;
                     M.cldy[o] = c ? 1 : 0; M.ciwp_s[o] = ci; M.clwp_s[o] = cl;
                 }
             } else {
-                if (MODE == 0) M.taucmc[((size_t)is * nlay + il) * n + col] = cloudy ? (R)1 : (R)0;
+                if (MODE == 0) M.taucmc[tb0 + (size_t)il * tbs] = cloudy ? (R)1 : (R)0;
                 else M.cldy[((size_t)col * M.nsubcol + is) * nlay + il] = cloudy ? 1 : 0;
             }
         }
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__res
                 const size_t w = (size_t)il * n + col, a = (size_t)il * ld + col;
                 if (il > 0 && cdf2 < M.rcorr[w]) cdf3 = c3prev;
                 c3prev = cdf3;
-                const size_t oc = MODE == 0 ? ((size_t)is * nlay + il) * n + col : ((size_t)col * M.nsubcol + is) * nlay + il;
+                const size_t oc = MODE == 0 ? tb0 + (size_t)il * tbs : ((size_t)col * M.nsubcol + is) * nlay + il;
                 const bool cloudy = MODE == 0 ? (M.taucmc[oc] != (R)0) : (M.cldy[oc] != 0);
                 R ci = 0, cl = 0; bool c = false;
                 if (cloudy) {
