@@ -57,6 +57,55 @@ struct Blob {
         if (e_ != hipSuccess) { return fail(GEOSRAD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } \
     } while (0)
 
+// ---- KISS jump-ahead constants (see mcica_kernels.hpp: KissJump) --------------------------------------------
+static uint32_t xs_step(uint32_t x) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; }
+static uint32_t mat_apply(const uint32_t *cols, uint32_t v)
+{
+    uint32_t y = 0;
+    for (int i = 0; i < 32; i++) if ((v >> i) & 1u) y ^= cols[i];
+    return y;
+}
+static uint32_t powmod(uint64_t a, uint64_t n, uint64_t m)
+{
+    uint64_t r = 1 % m; a %= m;
+    while (n) { if (n & 1) r = r * a % m; a = a * a % m; n >>= 1; }
+    return (uint32_t)r;
+}
+static KissJump make_kiss_jump(uint64_t n)
+{
+    KissJump J;
+    // LCG: compose (A,C) by binary exponentiation of x -> a x + c
+    uint32_t A = 1, C = 0, a = 69069u, c = 1327217885u;
+    for (uint64_t k = n; k; k >>= 1) {
+        if (k & 1) { A = A * a; C = C * a + c; }
+        c = c * a + c; a = a * a;          // (a,c) o (a,c)
+    }
+    J.A1 = A; J.C1 = C;
+    // xorshift matrix power
+    uint32_t R[32], P[32], t[32];
+    for (int i = 0; i < 32; i++) { R[i] = 1u << i; P[i] = xs_step(1u << i); }
+    for (uint64_t k = n; k; k >>= 1) {
+        if (k & 1) { for (int i = 0; i < 32; i++) t[i] = mat_apply(P, R[i]); memcpy(R, t, sizeof t); }
+        for (int i = 0; i < 32; i++) t[i] = mat_apply(P, P[i]);
+        memcpy(P, t, sizeof t);
+    }
+    memcpy(J.M2, R, sizeof R);
+    J.K3 = powmod(18000u, n, 18000ull * 65536ull - 1ull);
+    J.K4 = powmod(30903u, n, 30903ull * 65536ull - 1ull);
+    return J;
+}
+// segments of the sub-column range; jump distance = first sub-column * draws per sub-column
+static McSeg make_segments(const int *start, int nseg, int nlay, bool inhomo)
+{
+    McSeg S;
+    memset(&S, 0, sizeof S);
+    S.nseg = nseg;
+    for (int s = 0; s <= nseg; s++) S.start[s] = start[s];
+    const uint64_t per = (uint64_t)(inhomo ? 4 : 2) * (uint64_t)nlay;
+    for (int s = 0; s < nseg; s++) S.j[s] = make_kiss_jump((uint64_t)start[s] * per);
+    return S;
+}
+
 static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr",
                                        "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel",
                                        "plev", "tsfc", "emis", "tauaer"};
@@ -449,7 +498,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, d_T); span_end(st);
             // McICA + cloud optics (threads of clear columns exit at once)
             span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,
-                               (const uint8_t *)A.colcloudy, (const LwDev<R> *)d_T, A.alpha, A.rcorr); span_end(st);
+                               (const uint8_t *)A.colcloudy, (const LwDev<R> *)d_T, A.alpha, A.rcorr, A.laycloudy); span_end(st);
             McArgs<R> M{};
             M.ncol = nc; M.ld = ncol; M.nlay = nlay; M.nsubcol = NG_LW; M.doy = dyofyr; M.cloudLM = cloudLM; M.cloudMH = cloudMH;
             M.iceflg = iceflg; M.liqflg = liqflg;
@@ -458,7 +507,13 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.play = A.play; M.cldf = A.cldf; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
             M.alpha = A.alpha; M.rcorr = A.rcorr; M.colcloudy = A.colcloudy;
             M.taucmc = A.taucmc; M.laycloudy = A.laycloudy; M.clearCounts = A.clearCounts; M.err = d_err;
-            span_begin(3, st); hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, M, (const LwDev<R> *)d_T); span_end(st);
+            {
+                static const int bstart[17] = {0, 10, 22, 38, 52, 68, 76, 88, 96, 108, 114, 122, 130, 134, 136, 138, 140};
+                const McSeg SG = make_segments(bstart, NB_LW, nlay, h_T.xcw != nullptr);
+                span_begin(3, st);
+                hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), NB_LW), dim3(64), 0, st, M, SG, (const LwDev<R> *)d_T);
+                span_end(st);
+            }
             span_begin(4, st);
             if (A.dbg_taug) {
                 hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
@@ -594,7 +649,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             HIPCHK(hipMemcpyAsync(d_io + dst[k], src[k], (k == 5 ? (size_t)ncol : cl) * sizeof(R), hipMemcpyHostToDevice, stream));
         const unsigned gx = (unsigned)((ncol + 255) / 256);
         hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), dim3(256), 0, stream, ncol, ncol, nlay, doy, (const R *)(d_io + o_z),
-                           (const R *)(d_io + o_a), (const uint8_t *)nullptr, (const LwDev<R> *)d_T, (R *)(d_io + o_al), (R *)(d_io + o_rc));
+                           (const R *)(d_io + o_a), (const uint8_t *)nullptr, (const LwDev<R> *)d_T, (R *)(d_io + o_al), (R *)(d_io + o_rc), (uint8_t *)nullptr);
         McArgs<R> M{};
         M.ncol = ncol; M.ld = ncol; M.nlay = nlay; M.nsubcol = nsubcol; M.doy = doy; M.cloudLM = 1; M.cloudMH = 2;
         for (int k = 0; k < 4; k++) M.so[k] = sov[k];
@@ -602,7 +657,10 @@ template <typename R> struct Ctx : geosrad_ctx {
         M.play = (const R *)(d_io + o_p); M.cldf = (const R *)(d_io + o_f); M.ciwp = (const R *)(d_io + o_i); M.clwp = (const R *)(d_io + o_l);
         M.alpha = (const R *)(d_io + o_al); M.rcorr = (const R *)(d_io + o_rc);
         M.cldy = (int32_t *)(d_io + o_cy); M.ciwp_s = (R *)(d_io + o_ci); M.clwp_s = (R *)(d_io + o_cl);
-        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, stream, M, (const LwDev<R> *)d_T);
+        int nseg = nsubcol < 16 ? nsubcol : 16, sstart[17];
+        for (int s = 0; s <= nseg; s++) sstart[s] = (int)((long)s * nsubcol / nseg);
+        const McSeg SG = make_segments(sstart, nseg, nlay, h_T.xcw != nullptr);
+        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, stream, M, SG, (const LwDev<R> *)d_T);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(cldy, d_io + o_cy, co * 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(ciwp_s, d_io + o_ci, co * sizeof(R), hipMemcpyDeviceToHost, stream));

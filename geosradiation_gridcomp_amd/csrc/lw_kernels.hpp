@@ -94,10 +94,9 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
     A.pwvcm[col] = wvsh * ((R)1.e3 * A.plev[col]) / ((R)1.e2 * grav);
     A.colcloudy[col] = cloudy ? 1 : 0;
     if (cloudy) A.blkcloudy[blockIdx.x] = 1;   // zeroed by the host before the launch; same-value race is benign
-    if (!cloudy) {
-        // clear column: all sub-columns clear in every super-layer (cloud_subcol_gen.F90:649-659)
-        for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = NG_LW;
-    }
+    // clear column: all sub-columns clear in every super-layer (cloud_subcol_gen.F90:649-659);
+    // cloudy column: k_mcica's (column, band) threads add their counts
+    for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = cloudy ? 0 : NG_LW;
     // pressure misordering: plog > 4.56 somewhere above a layer with plog <= 4.56
     {
         bool upper = false, bad = false;

@@ -53,6 +53,36 @@ template <typename R> GR_DEV R kiss_next(Kiss &k)
     return nf_add(nf_mul((R)kiss, (R)2.328306e-10), (R)0.5);
 }
 
+// ---- KISS jump-ahead -----------------------------------------------------------------------------------
+// The reference draws one stream per column, sequentially over (sub-column, layer): 2*nlay (homogeneous) or
+// 4*nlay (inhomogeneous condensate) numbers per sub-column.  To give every (column, band) its own lane we
+// advance a freshly seeded state by n = g0 * draws_per_subcolumn in O(1):
+//   s1  (LCG mod 2^32)         x -> A1 x + C1              with (A1, C1) = (a^n, c (a^n - 1)/(a - 1))
+//   s2  (3-shift xorshift)     GF(2)-linear                x -> M^n x, M^n given by its 32 columns
+//   s3,s4 (16-bit multiply-with-carry, s' = a (s & 65535) + (s >> 16)):  s' * 2^16 == s (mod m), m = a 2^16 - 1,
+//         and a * 2^16 == 1 (mod m), hence s_n == s_0 * a^n (mod m); from the 2nd step on the state is the
+//         canonical residue in [0, m) (or the fixed points 0 / m), so the jump is one modular multiply.
+// The constants are computed on the host (geosrad.hip: make_kiss_jump) and passed by value.
+struct KissJump { uint32_t A1, C1, K3, K4; uint32_t M2[32]; };
+struct McSeg { int nseg; int start[17]; KissJump j[16]; };   // segment s covers sub-columns [start[s], start[s+1])
+
+GR_DEV uint32_t mwc_jump(uint32_t s, uint32_t K, uint32_t m)
+{
+    uint64_t r = s >= m ? s - m : s;
+    r = (r * (uint64_t)K) % (uint64_t)m;
+    return r == 0 ? s : (uint32_t)r;      // residue 0 <=> the fixed points s = 0 or s = m
+}
+GR_DEV void kiss_jump(Kiss &k, const KissJump &J)
+{
+    k.s1 = J.A1 * k.s1 + J.C1;
+    uint32_t y = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) y ^= ((k.s2 >> i) & 1u) ? J.M2[i] : 0u;
+    k.s2 = y;
+    k.s3 = mwc_jump(k.s3, J.K3, 18000u * 65536u - 1u);
+    k.s4 = mwc_jump(k.s4, J.K4, 30903u * 65536u - 1u);
+}
+
 // correlation_length (cloud_subcol_gen.F90:491-514)
 template <typename R> GR_DEV R corr_length(const R *am, int doy, R alat)
 {
@@ -111,13 +141,15 @@ template <typename R> GR_DEV Kiss kiss_seed(const R *__restrict__ play, int ld, 
 template <typename R>
 __global__ void __launch_bounds__(256) k_overlap(int ncol, int ld, int nlay, int doy, const R *__restrict__ zmid,
                                                  const R *__restrict__ alat, const uint8_t *__restrict__ colcloudy,
-                                                 const LwDev<R> *__restrict__ T, R *__restrict__ alpha, R *__restrict__ rcorr)
+                                                 const LwDev<R> *__restrict__ T, R *__restrict__ alpha, R *__restrict__ rcorr,
+                                                 uint8_t *__restrict__ laycloudy)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int lay = blockIdx.y;
     if (col >= ncol) return;
     if (colcloudy && !colcloudy[col]) return;
     const size_t w = (size_t)lay * ncol + col;
+    if (laycloudy) laycloudy[w] = 0;     // k_mcica's (column, band) threads OR their findings into it
     if (lay == 0) { alpha[w] = 0; if (rcorr) rcorr[w] = 0; return; }
     const R dz = fabs(zmid[(size_t)lay * ld + col] - zmid[(size_t)(lay - 1) * ld + col]);
     const R adl = corr_length<R>(T->aam, doy, alat[col]);
@@ -169,10 +201,13 @@ GR_DEV R lw_cloud_tau(const LwDev<R> &T, int iceflag, int ib, R ciwp, R clwp, R 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_mcica: one thread per column, sequential over (sub-column, layer) like the reference's stream.
-//   MODE 0 (RRTMG_LW): fused generate_stochastic_clouds + clearCounts_threeBand + cldprmc:
-//          writes taucmc[g][lay][col], laycloudy[lay][col], clearCounts(ncol,4).
-//   MODE 1 (stand-alone generator API): writes cldy/ciwp_stoch/clwp_stoch Fortran (nlay,nsubcol,ncol).
+// k_mcica: one thread per (column, segment of sub-columns); blockIdx.y = segment.  The column's KISS stream is
+// seeded as in the reference and jumped ahead to the segment's first sub-column (see KissJump), then walked
+// sequentially over (sub-column, layer) exactly like the reference's stream.
+//   MODE 0 (RRTMG_LW): segments = the 16 bands; fused generate_stochastic_clouds + clearCounts_threeBand +
+//          cldprmc: writes taucmc (band-major plane layout), ORs laycloudy[lay][col], adds clearCounts(ncol,4).
+//   MODE 1 (stand-alone generator API): up to 16 equal segments; writes cldy/ciwp_stoch/clwp_stoch Fortran
+//          (nlay,nsubcol,ncol).
 // Two passes per sub-column: pass 1 draws (cdf1,cdf2) for every layer and parks the cloud-presence
 // decision in the output cell; pass 2 draws (cdf2,cdf3) and finishes the cell.  No per-thread arrays.
 // ---------------------------------------------------------------------------------------------------
@@ -190,9 +225,10 @@ template <typename R> struct McArgs {
 };
 
 template <typename R, int MODE>
-__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__restrict__ Tp)
+__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev<R> *__restrict__ Tp)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = blockIdx.y;
     if (col >= M.ncol) return;
     if (M.colcloudy && !M.colcloudy[col]) return;
     const LwDev<R> &T = *Tp;
@@ -201,6 +237,8 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__res
     // vertical ordering is detected from the first column of the call (cloud_subcol_gen.F90:266)
     const bool surface_at_one = M.play[0] > M.play[(size_t)(nlay - 1) * ld];
     Kiss ks = kiss_seed<R>(M.play, ld, nlay, col, surface_at_one, M.so);
+    // n = 0 must stay the identity: a raw seed may exceed the MWC modulus (non-canonical), which mwc_jump would reduce
+    if (SG.start[seg] > 0) kiss_jump(ks, SG.j[seg]);
     uint32_t err = 0;
 
     // pressure super-layer bounds, 0-based inclusive (cloud_subcol_gen.F90:617-632)
@@ -209,13 +247,8 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__res
     else { hi0 = 0; hi1 = M.cloudMH - 2; mi0 = M.cloudMH - 1; mi1 = M.cloudLM - 2; lo0 = M.cloudLM - 1; lo1 = nlay - 1; }
     int cnt_all = 0, cnt_hi = 0, cnt_mid = 0, cnt_lo = 0;
 
-    if (MODE == 0)
-        for (int il = 0; il < nlay; il++) M.laycloudy[(size_t)il * n + col] = 0;
-
-    for (int is = 0; is < M.nsubcol; is++) {
-        const int ib = MODE == 0 ? (is < 10 ? 1 : is < 22 ? 2 : is < 38 ? 3 : is < 52 ? 4 : is < 68 ? 5 : is < 76 ? 6 : is < 88 ? 7 :
-                                    is < 96 ? 8 : is < 108 ? 9 : is < 114 ? 10 : is < 122 ? 11 : is < 130 ? 12 : is < 134 ? 13 :
-                                    is < 136 ? 14 : is < 138 ? 15 : 16) : 0;
+    const int ib = MODE == 0 ? seg + 1 : 0;     // MODE 0: segment == band
+    for (int is = SG.start[seg]; is < SG.start[seg + 1]; is++) {
         // taucmc plane layout (see band_body): band-major, then [layer][g-in-band][column]
         const size_t tb0 = MODE == 0 ? (size_t)lw_band_g0(ib) * nlay * n + (size_t)(is - lw_band_g0(ib)) * n + col : 0;
         const size_t tbs = MODE == 0 ? (size_t)lw_band_ng(ib) * n : 0;     // + il * tbs
@@ -294,10 +327,11 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, const LwDev<R> *__res
         if (!any_lo) cnt_lo++;
     }
     if (MODE == 0) {
-        M.clearCounts[(size_t)0 * ld + col] = cnt_all;
-        M.clearCounts[(size_t)1 * ld + col] = cnt_hi;
-        M.clearCounts[(size_t)2 * ld + col] = cnt_mid;
-        M.clearCounts[(size_t)3 * ld + col] = cnt_lo;
+        // integer adds: order-independent, bitwise reproducible (k_validate_pwv zeroed the cloudy columns' counts)
+        atomicAdd(&M.clearCounts[(size_t)0 * ld + col], cnt_all);
+        atomicAdd(&M.clearCounts[(size_t)1 * ld + col], cnt_hi);
+        atomicAdd(&M.clearCounts[(size_t)2 * ld + col], cnt_mid);
+        atomicAdd(&M.clearCounts[(size_t)3 * ld + col], cnt_lo);
         if (err) atomicOr(M.err, err);
     }
 }
