@@ -37,6 +37,22 @@ def algorithmic_bytes_lw(nlay, real_bytes, aerosol):
     return (n_in + n_out) * real_bytes
 
 
+def shard_start(rank, ncol_per_gpu):
+    """first global column of a rank's batch: contiguous blocks, rank-major (no overlap, no exchange)"""
+    return rank * ncol_per_gpu
+
+
+def max_over_ranks(seconds, world, device):
+    """the only cross-rank reduction of the benchmark: MAX of the elapsed time"""
+    if world <= 1:
+        return float(seconds)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def _cpu_worker(args):
     kind, start, ncol, nlay = args
     from geosradiation_gridcomp_amd import synth
@@ -108,7 +124,7 @@ def main():
 
     # ---- inputs resident in HBM -------------------------------------------------------------------------------
     ncol, nlay = a.ncol, a.nlay
-    inp = synth.make_columns(ncol, nlay, start=rank * ncol, cloudy_frac=a.cloudy, aerosol=a.aerosol)
+    inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=a.aerosol)
     tdt = torch.float32 if a.real == 4 else torch.float64
     names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + LW_IN2D + (["tauaer"] if a.aerosol else [])
     d = {k: torch.from_numpy(np.ascontiguousarray(inp[k])).to(dev, dtype=tdt) for k in names}
@@ -140,10 +156,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, dev)
     ctx.check(stream)
     prof = ctx.profile_read()
 

@@ -1,0 +1,45 @@
+"""CPU, world_size 2, gloo: the N > 1 path of bench.py shards columns with no data-path collective -- each rank owns
+columns [rank*n, (rank+1)*n) -- and only a barrier + MAX all-reduce of the elapsed time cross ranks."""
+import os
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from geosradiation_gridcomp_amd import synth
+    import bench
+    shard = synth.make_columns(n, 72, start=bench.shard_start(rank, n), cloudy_frac=0.5)
+    # a per-shard checksum is all that ever needs to leave the rank (outputs stay with their columns)
+    chk = torch.tensor([float(np.float64(shard["tlay"]).sum()), float(np.float64(shard["cldf"]).sum())], dtype=torch.float64)
+    allchk = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allchk, chk)
+    t = bench.max_over_ranks(0.010 * (rank + 1), world, torch.device("cpu"))
+    dist.barrier()
+    q.put((rank, [c.tolist() for c in allchk], t))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_columns_without_exchange():
+    world, n = 2, 48
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from geosradiation_gridcomp_amd import synth
+    full = synth.make_columns(world * n, 72, cloudy_frac=0.5)
+    for rank, allchk, t in res:
+        assert abs(t - 0.020) < 1e-12                      # MAX over ranks
+        for r in range(world):
+            sl = slice(r * n, (r + 1) * n)
+            assert allchk[r][0] == float(np.float64(full["tlay"][:, sl]).sum())
+            assert allchk[r][1] == float(np.float64(full["cldf"][:, sl]).sum())
