@@ -5,6 +5,8 @@ calls into the reference:
 
     rrtmg_lw_ini()                          rrtmg_lw_init.F90:22
     rrtmg_lw(ncol, nlay, psize, dudTs, ...) rrtmg_lw_rad.F90:15-23
+    rrtmg_sw_ini()                          SW rrtmg_sw_init.F90:23
+    rrtmg_sw(rpart, ncol, nlay, scon, ...)  SW rrtmg_sw_rad.F90:68-124
     generate_stochastic_clouds(...)         cloud_subcol_gen.F90:132-137
     clearCounts_threeBand(...)              cloud_subcol_gen.F90:611-614
     set_inhomogeneity / unset_inhomogeneity cloud_condensate_inhomogeneity.F90:45,75
@@ -21,6 +23,10 @@ from . import _lib
 
 NBNDLW = 16
 NGPTLW = 140
+NBNDSW = 14
+NGPTSW = 112
+_SW_GAS = ["h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr"]
+_SW_COT = ["cotdtp", "cotdhp", "cotdmp", "cotdlp", "cotntp", "cotnhp", "cotnmp", "cotnlp"]
 
 _IN2D = ["h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr",
          "cldf", "ciwp", "clwp", "rei", "rel"]
@@ -51,6 +57,7 @@ class Context:
             raise GeosradError({2: "no usable HIP device (the product has no CPU fallback)"}.get(rc, f"geosrad_create rc={rc}"))
         if tables:
             self.rrtmg_lw_ini()
+            self.rrtmg_sw_ini()
 
     def close(self):
         if self.h:
@@ -75,6 +82,10 @@ class Context:
     def rrtmg_lw_ini(self, path=None):
         path = path or os.path.join(_lib.DATA, f"rrtmg_lw_{self._kind()}.grtb")
         self._chk(self.L.geosrad_load_tables_lw(self.h, os.fsencode(path)))
+
+    def rrtmg_sw_ini(self, path=None):
+        path = path or os.path.join(_lib.DATA, f"rrtmg_sw_{self._kind()}.grtb")
+        self._chk(self.L.geosrad_load_tables_sw(self.h, os.fsencode(path)))
 
     def set_inhomogeneity(self, ih, path=None):
         if ih and path is None:
@@ -143,6 +154,81 @@ class Context:
         self._chk(rc)
         return taug, pfr
 
+    # ---- RRTMG_SW, host arrays -------------------------------------------------------------------------
+    def rrtmg_sw(self, rpart, ncol, nlay, scon, adjes, coszen, isolvar, play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr,
+                 iceflgsw, liqflgsw, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer,
+                 asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, do_drfband=False, bndscl=None, indsolvar=None):
+        """rrtmg_sw (SW/rrtmg_sw_rad.F90:68).  Returns dict(swuflx,swdflx,swuflxc,swdflxc (nlay+1,ncol); nirr..uvrf,
+        cotdtp..cotnlp (ncol); fswband[,drband,dfband] (14,ncol); clearCounts (4,ncol))."""
+        dt = self.dtype
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        gases = [c(x) for x in (h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr)]
+        cl5 = [c(x) for x in (cld, ciwp, clwp, rei, rel)]
+        coszen, play, plev, tlay, zm, alat, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif = map(
+            c, (coszen, play, plev, tlay, zm, alat, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif))
+        assert play.shape == (nlay, ncol) and plev.shape == (nlay + 1, ncol)
+        out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
+        for k in ["nirr", "nirf", "parr", "parf", "uvrr", "uvrf"] + _SW_COT:
+            out[k] = np.zeros(ncol, dtype=dt)
+        out["fswband"] = np.zeros((NBNDSW, ncol), dtype=dt)
+        if do_drfband:
+            out["drband"] = np.zeros((NBNDSW, ncol), dtype=dt); out["dfband"] = np.zeros((NBNDSW, ncol), dtype=dt)
+        out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
+        bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
+        ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
+        ci, cd = ctypes.c_int, ctypes.c_double
+        rc = self.L.geosrad_rrtmg_sw(
+            self.h, ci(rpart), ci(ncol), ci(nlay), cd(scon), cd(adjes), _p(coszen), ci(isolvar), _p(play), _p(plev), _p(tlay),
+            *[_p(a) for a in gases], ci(iceflgsw), ci(liqflgsw), *[_p(a) for a in cl5], ci(int(dyofyr)), _p(zm), _p(alat), ci(iaer),
+            _p(tauaer), _p(ssaaer), _p(asmaer), _p(asdir), _p(asdif), _p(aldir), _p(aldif), ci(int(cloudLM)), ci(int(cloudMH)),
+            ci(int(normFlx)), _p(out["clearCounts"]), _p(out["swuflx"]), _p(out["swdflx"]), _p(out["swuflxc"]), _p(out["swdflxc"]),
+            *[_p(out[k]) for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "fswband")], *[_p(out[k]) for k in _SW_COT],
+            ci(1 if do_drfband else 0), _p(out.get("drband")), _p(out.get("dfband")), _p(bs), _p(ind))
+        self._chk(rc)
+        return out
+
+    def rrtmg_sw_columns(self, inp, scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqflg=1, iaer=0, normFlx=0, do_drfband=False,
+                         bndscl=None, indsolvar=None, rpart=4):
+        """Convenience: `inp` as produced by synth.make_columns."""
+        nlay, ncol = inp["play"].shape
+        aer = [inp.get(k) if iaer == 10 else None for k in ("tauaer_sw", "ssaaer_sw", "asmaer_sw")]
+        return self.rrtmg_sw(rpart, ncol, nlay, scon, adjes, inp["coszen"], isolvar, inp["play"], inp["plev"], inp["tlay"],
+                             *[inp[k] for k in _SW_GAS], iceflg, liqflg, inp["cldf"], inp["ciwp"], inp["clwp"], inp["rei"], inp["rel"],
+                             inp["dyofyr"], inp["zm"], inp["alat"], iaer, *aer, inp["asdir"], inp["asdif"], inp["aldir"], inp["aldif"],
+                             inp["cloudLM"], inp["cloudMH"], normFlx, do_drfband=do_drfband, bndscl=bndscl, indsolvar=indsolvar)
+
+    def rrtmg_sw_taumol(self, inp, scon=1361.0, isolvar=0, bndscl=None, indsolvar=None):
+        """(taug, taur) numpy (ncol,112,nlay) and ssi (ncol,112) as left by the reference's taumol_sw."""
+        dt = self.dtype
+        nlay, ncol = inp["play"].shape
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        a = {k: c(inp[k]) for k in ["play", "plev", "tlay"] + _SW_GAS}
+        taug = np.zeros((ncol, NGPTSW, nlay), dtype=dt); taur = np.zeros_like(taug); ssi = np.zeros((ncol, NGPTSW), dtype=dt)
+        bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
+        ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
+        rc = self.L.geosrad_rrtmg_sw_taumol(self.h, ctypes.c_int(ncol), ctypes.c_int(nlay), ctypes.c_double(scon), ctypes.c_int(isolvar),
+                                            _p(a["play"]), _p(a["plev"]), _p(a["tlay"]), *[_p(a[k]) for k in _SW_GAS], _p(bs), _p(ind),
+                                            _p(taug), _p(taur), _p(ssi))
+        self._chk(rc)
+        return taug, taur, ssi
+
+    def rrtmg_sw_dev(self, stream, ncol, nlay, scon, adjes, isolvar, ptr, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx=0,
+                     do_drfband=False, bndscl=None, indsolvar=None, rpart=4):
+        """`ptr`: dict name -> device address (int) for every argument array of rrtmg_sw (inputs and outputs)."""
+        dt = self.dtype
+        v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
+        bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
+        ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
+        ci, cd = ctypes.c_int, ctypes.c_double
+        rc = self.L.geosrad_rrtmg_sw_dev(
+            self.h, ctypes.c_void_p(stream), ci(rpart), ci(ncol), ci(nlay), cd(scon), cd(adjes), v("coszen"), ci(isolvar), v("play"),
+            v("plev"), v("tlay"), *[v(k) for k in _SW_GAS], ci(iceflg), ci(liqflg), v("cldf"), v("ciwp"), v("clwp"), v("rei"), v("rel"),
+            ci(int(dyofyr)), v("zm"), v("alat"), ci(iaer), v("tauaer_sw"), v("ssaaer_sw"), v("asmaer_sw"), v("asdir"), v("asdif"),
+            v("aldir"), v("aldif"), ci(int(cloudLM)), ci(int(cloudMH)), ci(int(normFlx)), v("clearCounts_sw"), v("swuflx"), v("swdflx"),
+            v("swuflxc"), v("swdflxc"), *[v(k) for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "fswband")],
+            *[v(k) for k in _SW_COT], ci(1 if do_drfband else 0), v("drband"), v("dfband"), _p(bs), _p(ind))
+        self._chk(rc)
+
     # ---- RRTMG_LW, device pointers (bench / drivers that keep data in HBM) -------------------------------------
     def rrtmg_lw_dev(self, stream, ncol, nlay, dudTs, ptr, iceflg, liqflg, dyofyr, cloudLM, cloudMH, band_output=None):
         """`ptr`: dict name -> device address (int) for every argument array of rrtmg_lw (inputs and outputs)."""
@@ -162,7 +248,7 @@ class Context:
     def profile_read(self):
         """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
         out = {}
-        for k in range(6):
+        for k in range(10):
             ms = ctypes.c_double(); n = ctypes.c_long()
             self._chk(self.L.geosrad_profile_read(self.h, ctypes.c_int(k), ctypes.byref(ms), ctypes.byref(n)))
             out[self.L.geosrad_kernel_name(ctypes.c_int(k)).decode()] = (ms.value, n.value)

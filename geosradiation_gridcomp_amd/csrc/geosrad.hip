@@ -12,6 +12,7 @@
 #include "../../include/geosrad.h"
 #include "lw_device.hpp"
 #include "lw_kernels.hpp"
+#include "sw_kernels.hpp"
 #include "mcica_kernels.hpp"
 
 using namespace geosrad;
@@ -106,6 +107,92 @@ static McSeg make_segments(const int *start, int nseg, int nlay, bool inhomo)
     return S;
 }
 
+// staging of one coefficient blob into GPU-friendly layouts: k-table rows [index][NGP = pad4(ng)] so that a lane
+// fetches 4 consecutive g-points of its own row with one 16-byte load
+template <typename R> struct TableStage {
+    const Blob &B;
+    std::vector<char> stage;
+    std::vector<std::pair<const R **, size_t>> fix;   // (pointer slot, byte offset)
+    std::string missing;
+    explicit TableStage(const Blob &b) : B(b) {}
+    const R *get(const std::string &nm, size_t expect)
+    {
+        auto it = B.e.find(nm);
+        if (it == B.e.end() || it->second.kind != (int)sizeof(R) || (expect && it->second.count != expect)) {
+            missing += nm + " ";
+            return nullptr;
+        }
+        return (const R *)it->second.data;
+    }
+    size_t reserve(size_t nreal)
+    {
+        size_t off = (stage.size() + 15) & ~(size_t)15;
+        stage.resize(off + nreal * sizeof(R), 0);
+        return off;
+    }
+    R *at(size_t off) { return (R *)(stage.data() + off); }
+    // Fortran (n1, ng) -> [n1][NGP]
+    void tr2(const R **slot, const std::string &nm, int n1, int ng)
+    {
+        const R *s = get(nm, (size_t)n1 * ng);
+        if (!s) return;
+        const int ngp = pad4(ng);
+        size_t off = reserve((size_t)n1 * ngp);
+        for (int g = 0; g < ng; g++)
+            for (int i = 0; i < n1; i++) at(off)[(size_t)i * ngp + g] = s[(size_t)g * n1 + i];
+        fix.push_back({slot, off});
+    }
+    // Fortran (nsp, 19, ng) -> [19][nsp][NGP]
+    void tr3(const R **slot, const std::string &nm, int nsp, int ng)
+    {
+        const R *s = get(nm, (size_t)nsp * 19 * ng);
+        if (!s) return;
+        const int ngp = pad4(ng);
+        size_t off = reserve((size_t)19 * nsp * ngp);
+        for (int g = 0; g < ng; g++)
+            for (int im = 0; im < 19; im++)
+                for (int j = 0; j < nsp; j++) at(off)[((size_t)im * nsp + j) * ngp + g] = s[((size_t)g * 19 + im) * nsp + j];
+        fix.push_back({slot, off});
+    }
+    // Fortran (ng, m) -> [m][NGP]   (m = 1 for plain per-g vectors)
+    void rows(const R **slot, const std::string &nm, int ng, int m)
+    {
+        const R *s = get(nm, (size_t)ng * m);
+        if (!s) return;
+        const int ngp = pad4(ng);
+        size_t off = reserve((size_t)m * ngp);
+        for (int j = 0; j < m; j++)
+            for (int g = 0; g < ng; g++) at(off)[(size_t)j * ngp + g] = s[(size_t)j * ng + g];
+        fix.push_back({slot, off});
+    }
+    // one scalar replicated over a [NGP] row
+    void splat(const R **slot, const std::string &nm, int ng)
+    {
+        const R *s = get(nm, 1);
+        if (!s) return;
+        const int ngp = pad4(ng);
+        size_t off = reserve((size_t)ngp);
+        for (int g = 0; g < ngp; g++) at(off)[g] = *s;
+        fix.push_back({slot, off});
+    }
+    void raw(const R **slot, const std::string &nm, size_t cnt)
+    {
+        const R *s = get(nm, cnt);
+        if (!s) return;
+        size_t off = reserve(cnt);
+        memcpy(at(off), s, cnt * sizeof(R));
+        fix.push_back({slot, off});
+    }
+    R scalar(const std::string &nm) { const R *s = get(nm, 1); return s ? *s : (R)0; }
+    bool ints(const std::string &nm, size_t cnt, int32_t *dst)
+    {
+        auto it = B.e.find(nm);
+        if (it == B.e.end() || it->second.kind != -4 || it->second.count != cnt) { missing += nm + " "; return false; }
+        memcpy(dst, it->second.data, cnt * sizeof(int32_t));
+        return true;
+    }
+};
+
 static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr",
                                        "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel",
                                        "plev", "tsfc", "emis", "tauaer"};
@@ -122,8 +209,8 @@ struct geosrad_ctx {
     struct Span { int kid; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> evpool;
-    double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double prof_ms[12] = {0};
+    long prof_n[12] = {0};
     hipEvent_t getev()
     {
         hipEvent_t e = nullptr;
@@ -164,7 +251,20 @@ struct geosrad_ctx {
                            const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so,
                            int32_t *cldy, void *ciwp_s, void *clwp_s) = 0;
     virtual int check(hipStream_t st) = 0;
+    virtual int set_tables_sw(const void *blob, size_t n) = 0;
+    virtual int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg,
+                       int liqflg, int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
+                       int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
+    virtual int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
+                        int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
+                        int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
 };
+
+// order of the `in` / `out` pointer arrays of sw_dev / sw_host
+enum SwIn { S_PLAY, S_PLEV, S_TLAY, S_H2O, S_O3, S_CO2, S_CH4, S_O2, S_CLD, S_CIWP, S_CLWP, S_REI, S_REL, S_ZM, S_ALAT, S_TAUAER,
+            S_SSAAER, S_ASMAER, S_COSZEN, S_ASDIR, S_ASDIF, S_ALDIR, S_ALDIF, S_NIN };
+enum SwOutIx { SO_UFLX, SO_DFLX, SO_UFLXC, SO_DFLXC, SO_NIRR, SO_NIRF, SO_PARR, SO_PARF, SO_UVRR, SO_UVRF, SO_FSWBAND, SO_COT0,
+               SO_DRBAND = SO_COT0 + 8, SO_DFBAND, SO_NOUT };
 
 // order of the `in` pointer array of lw_dev / lw_host
 enum LwIn { I_PLAY, I_PLEV, I_TLAY, I_TLEV, I_TSFC, I_EMIS, I_H2O, I_O3, I_CO2, I_CH4, I_N2O, I_O2, I_CFC11, I_CFC12, I_CFC22,
@@ -181,6 +281,12 @@ template <typename R> struct Ctx : geosrad_ctx {
     LwDev<R> h_T{};            // host copy (device pointers inside)
     LwDev<R> *d_T = nullptr;
     bool have_lw = false;
+    // RRTMG_SW tables
+    char *d_tab_sw = nullptr; size_t tab_sw_bytes = 0;
+    SwDev<R> h_S{};
+    SwDev<R> *d_S = nullptr;
+    bool have_sw = false;
+    char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0;
     // workspace
     char *d_ws = nullptr; size_t ws_bytes = 0; int ws_ncol = 0, ws_nlay = 0;
     uint32_t *d_err = nullptr;
@@ -194,6 +300,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_xcw) (void)hipFree(d_xcw);
         if (d_T) (void)hipFree(d_T);
         if (d_ws) (void)hipFree(d_ws);
+        if (d_tab_sw) (void)hipFree(d_tab_sw);
+        if (d_S) (void)hipFree(d_S);
+        if (d_ws_sw) (void)hipFree(d_ws_sw);
         if (d_err) (void)hipFree(d_err);
         if (d_io) (void)hipFree(d_io);
         if (stream) (void)hipStreamDestroy(stream);
@@ -206,6 +315,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         HIPCHK(hipMalloc((void **)&d_err, 256));
         HIPCHK(hipMemset(d_err, 0, 256));
         HIPCHK(hipMalloc((void **)&d_T, sizeof(LwDev<R>)));
+        HIPCHK(hipMalloc((void **)&d_S, sizeof(SwDev<R>)));
         // Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
         const double adl[4] = {1.4315, 2.1219, 7., -25.584}, rdl[4] = {0.72192, 0.78996, 8.5, 40.404};
         for (int i = 0; i < 4; i++) { h_T.aam[i] = (R)(sizeof(R) == 4 ? (float)adl[i] : adl[i]); h_T.ram[i] = (R)(sizeof(R) == 4 ? (float)rdl[i] : rdl[i]); }
@@ -227,62 +337,17 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (B.realbytes != (int)sizeof(R))
             return fail(GEOSRAD_ETABLE, "table blob real size does not match the context's real_kind (use the _r4 blob for "
                                         "real_kind 4 and the _r8 blob for real_kind 8)");
-        std::vector<char> stage;
-        std::vector<std::pair<const R **, size_t>> fix;   // (pointer slot, byte offset)
-        std::string missing;
-        auto get = [&](const std::string &nm, size_t expect) -> const R * {
-            auto it = B.e.find(nm);
-            if (it == B.e.end() || it->second.kind != (int)sizeof(R) || (expect && it->second.count != expect)) {
-                missing += nm + " ";
-                return nullptr;
-            }
-            return (const R *)it->second.data;
-        };
-        auto reserve = [&](size_t nreal) -> size_t {
-            size_t off = (stage.size() + 15) & ~(size_t)15;
-            stage.resize(off + nreal * sizeof(R), 0);
-            return off;
-        };
-        auto at = [&](size_t off) -> R * { return (R *)(stage.data() + off); };
-        // Fortran (n1, ng) -> [n1][NGP]
-        auto tr2 = [&](const R **slot, const std::string &nm, int n1, int ng) {
-            const R *s = get(nm, (size_t)n1 * ng);
-            if (!s) return;
-            const int ngp = pad4(ng);
-            size_t off = reserve((size_t)n1 * ngp);
-            for (int g = 0; g < ng; g++)
-                for (int i = 0; i < n1; i++) at(off)[(size_t)i * ngp + g] = s[(size_t)g * n1 + i];
-            fix.push_back({slot, off});
-        };
-        // Fortran (nsp, 19, ng) -> [19][nsp][NGP]
-        auto tr3 = [&](const R **slot, const std::string &nm, int nsp, int ng) {
-            const R *s = get(nm, (size_t)nsp * 19 * ng);
-            if (!s) return;
-            const int ngp = pad4(ng);
-            size_t off = reserve((size_t)19 * nsp * ngp);
-            for (int g = 0; g < ng; g++)
-                for (int im = 0; im < 19; im++)
-                    for (int j = 0; j < nsp; j++) at(off)[((size_t)im * nsp + j) * ngp + g] = s[((size_t)g * 19 + im) * nsp + j];
-            fix.push_back({slot, off});
-        };
-        // Fortran (ng, m) -> [m][NGP]   (m = 1 for plain per-g vectors)
-        auto rows = [&](const R **slot, const std::string &nm, int ng, int m) {
-            const R *s = get(nm, (size_t)ng * m);
-            if (!s) return;
-            const int ngp = pad4(ng);
-            size_t off = reserve((size_t)m * ngp);
-            for (int j = 0; j < m; j++)
-                for (int g = 0; g < ng; g++) at(off)[(size_t)j * ngp + g] = s[(size_t)j * ng + g];
-            fix.push_back({slot, off});
-        };
-        auto raw = [&](const R **slot, const std::string &nm, size_t cnt) {
-            const R *s = get(nm, cnt);
-            if (!s) return;
-            size_t off = reserve(cnt);
-            memcpy(at(off), s, cnt * sizeof(R));
-            fix.push_back({slot, off});
-        };
-        auto scalar = [&](const std::string &nm) -> R { const R *s = get(nm, 1); return s ? *s : (R)0; };
+        TableStage<R> S(B);
+        std::string &missing = S.missing;
+        auto &fix = S.fix;
+        auto get = [&](const std::string &nm, size_t expect) { return S.get(nm, expect); };
+        auto reserve = [&](size_t nreal) { return S.reserve(nreal); };
+        auto at = [&](size_t off) { return S.at(off); };
+        auto tr2 = [&](const R **slot, const std::string &nm, int n1, int ng) { S.tr2(slot, nm, n1, ng); };
+        auto tr3 = [&](const R **slot, const std::string &nm, int nsp, int ng) { S.tr3(slot, nm, nsp, ng); };
+        auto rows = [&](const R **slot, const std::string &nm, int ng, int m) { S.rows(slot, nm, ng, m); };
+        auto raw = [&](const R **slot, const std::string &nm, size_t cnt) { S.raw(slot, nm, cnt); };
+        auto scalar = [&](const std::string &nm) { return S.scalar(nm); };
 
         static const int ng[17] = {0, 10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2};
         static const int nspa[17] = {0, 1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9};
@@ -365,9 +430,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (!missing.empty()) return fail(GEOSRAD_ETABLE, "missing/ill-shaped table entries: " + missing);
 
         if (d_tab) { HIPCHK(hipFree(d_tab)); d_tab = nullptr; }
-        tab_bytes = stage.size();
+        tab_bytes = S.stage.size();
         HIPCHK(hipMalloc((void **)&d_tab, tab_bytes));
-        HIPCHK(hipMemcpy(d_tab, stage.data(), tab_bytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_tab, S.stage.data(), tab_bytes, hipMemcpyHostToDevice));
         for (auto &f : fix) *f.first = (const R *)(d_tab + f.second);
         have_lw = true;
         return sync_T();
@@ -404,7 +469,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return sync_T();
     }
 
-    size_t workspace_bytes() const override { return ws_bytes + io_bytes + tab_bytes; }
+    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + io_bytes + tab_bytes + tab_sw_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
     struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *blkcloudy, *laycloudy; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
@@ -511,7 +576,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 static const int bstart[17] = {0, 10, 22, 38, 52, 68, 76, 88, 96, 108, 114, 122, 130, 134, 136, 138, 140};
                 const McSeg SG = make_segments(bstart, NB_LW, nlay, h_T.xcw != nullptr);
                 span_begin(3, st);
-                hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), NB_LW), dim3(64), 0, st, M, SG, (const LwDev<R> *)d_T);
+                hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), NB_LW), dim3(64), 0, st, M, SG, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
                 span_end(st);
             }
             span_begin(4, st);
@@ -536,10 +601,20 @@ template <typename R> struct Ctx : geosrad_ctx {
     {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamSynchronize(st));
-        uint32_t e = 0;
-        HIPCHK(hipMemcpy(&e, d_err, 4, hipMemcpyDeviceToHost));
-        if (!e) return GEOSRAD_OK;
-        HIPCHK(hipMemset(d_err, 0, 4));
+        uint32_t e2[2] = {0, 0};
+        HIPCHK(hipMemcpy(e2, d_err, 8, hipMemcpyDeviceToHost));
+        if (!e2[0] && !e2[1]) return GEOSRAD_OK;
+        HIPCHK(hipMemset(d_err, 0, 8));
+        if (e2[1]) {   // RRTMG_SW input assertions (SW/rrtmg_sw_rad.F90:365-383)
+            static const char *SW_NEG_NAMES[12] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cld", "ciwp", "clwp", "rei", "rel"};
+            for (int k = 0; k < 12; k++)
+                if (e2[1] & (1u << k)) return fail(GEOSRAD_EINPUT, std::string("negative values in input: ") + SW_NEG_NAMES[k]);
+            if (e2[1] & (1u << SWERR_PLEV)) return fail(GEOSRAD_EINPUT, "negative values in input: plev");
+            if (e2[1] & (1u << SWERR_ALB)) return fail(GEOSRAD_EINPUT, "negative values in input: surface albedo");
+            if (e2[1] & (1u << SWERR_AER)) return fail(GEOSRAD_EINPUT, "negative values in input: aerosol optical properties");
+            return fail(GEOSRAD_EINPUT, "device-side input check failed (rrtmg_sw)");
+        }
+        const uint32_t e = e2[0];
         for (int k = 0; k < 21; k++)
             if (e & (1u << k)) return fail(GEOSRAD_EINPUT, std::string("negative values in input: ") + LW_NEG_NAMES[k]);
         if (e & (1u << ERR_PRESSURE_ORDER)) return fail(GEOSRAD_EINPUT, "RRTMG LW pressure misordering");
@@ -619,6 +694,296 @@ template <typename R> struct Ctx : geosrad_ctx {
         return GEOSRAD_OK;
     }
 
+
+    // =====================================================================================================
+    // RRTMG_SW
+    // =====================================================================================================
+    int set_tables_sw(const void *blob, size_t nbytes) override
+    {
+        HIPCHK(hipSetDevice(device));
+        Blob B;
+        if (!B.parse(blob, nbytes)) return fail(GEOSRAD_ETABLE, B.err);
+        if (B.realbytes != (int)sizeof(R))
+            return fail(GEOSRAD_ETABLE, "table blob real size does not match the context's real_kind");
+        TableStage<R> S(B);
+        SwDev<R> &T = h_S;
+        memset(&T, 0, sizeof(T));
+        static const int ng[15] = {0, 6, 12, 8, 8, 10, 10, 2, 10, 8, 6, 6, 8, 6, 12};
+        static const int rowsa[15] = {0, 585, 585, 585, 585, 65, 585, 585, 65, 585, 65, 0, 65, 585, 65};
+        static const int rowsb[15] = {0, 235, 1175, 235, 235, 235, 1175, 235, 0, 235, 0, 0, 235, 1175, 235};
+        static const int nfor[15] = {0, 3, 4, 3, 3, 4, 4, 3, 3, 3, 0, 0, 0, 0, 4};
+        static const int nsrc[15] = {0, 1, 5, 9, 9, 1, 9, 9, 1, 9, 1, 1, 1, 5, 1};
+        char nm[64];
+        for (int b = 1; b <= NB_SW; b++) {
+            SwBandTab<R> &bt = T.b[b];
+            auto N = [&](const char *s) { snprintf(nm, sizeof nm, "b%02d_%s", b + 15, s); return std::string(nm); };
+            if (rowsa[b]) S.tr2(&bt.absa, N("absa"), rowsa[b], ng[b]);
+            if (rowsb[b]) S.tr2(&bt.absb, N("absb"), rowsb[b], ng[b]);
+            if (nfor[b]) { S.tr2(&bt.selfref, N("selfref"), 10, ng[b]); S.tr2(&bt.forref, N("forref"), nfor[b], ng[b]); }
+            S.rows(&bt.sflux, N("sfluxref"), ng[b], nsrc[b]); S.rows(&bt.irrad, N("irradnce"), ng[b], nsrc[b]);
+            S.rows(&bt.facb, N("facbrght"), ng[b], nsrc[b]); S.rows(&bt.snsp, N("snsptdrk"), ng[b], nsrc[b]);
+            const int jb = b + 15;
+            if (jb == 24) { S.rows(&bt.rayl, N("rayla"), ng[b], 9); S.rows(&bt.raylb, N("raylb"), ng[b], 1); }
+            else if (jb == 23 || jb == 25 || jb == 26 || jb == 27) S.rows(&bt.rayl, N("rayl"), ng[b], 1);
+            else S.splat(&bt.rayl, N("rayl"), ng[b]);
+            if (jb == 20) S.rows(&bt.x0, N("absch4"), ng[b], 1);
+            if (jb == 24 || jb == 25) { S.rows(&bt.x0, N("abso3a"), ng[b], 1); S.rows(&bt.x1, N("abso3b"), ng[b], 1); }
+            if (jb == 29) { S.rows(&bt.x0, N("absco2"), ng[b], 1); S.rows(&bt.x1, N("absh2o"), ng[b], 1); }
+        }
+        S.raw(&T.preflog, "preflog", 59); S.raw(&T.tref, "tref", 59);
+        S.raw(&T.extliq1, "extliq1", 58 * 14); S.raw(&T.ssaliq1, "ssaliq1", 58 * 14); S.raw(&T.asyliq1, "asyliq1", 58 * 14);
+        S.raw(&T.extice2, "extice2", 43 * 14); S.raw(&T.ssaice2, "ssaice2", 43 * 14); S.raw(&T.asyice2, "asyice2", 43 * 14);
+        S.raw(&T.extice3, "extice3", 46 * 14); S.raw(&T.ssaice3, "ssaice3", 46 * 14); S.raw(&T.asyice3, "asyice3", 46 * 14);
+        S.raw(&T.fdlice3, "fdlice3", 46 * 14);
+        S.raw(&T.extice4, "extice4", 200 * 14); S.raw(&T.ssaice4, "ssaice4", 200 * 14); S.raw(&T.asyice4, "asyice4", 200 * 14);
+        {
+            const char *bn[6] = {"abari", "bbari", "cbari", "dbari", "ebari", "fbari"};
+            R *dst[6] = {T.abari, T.bbari, T.cbari, T.dbari, T.ebari, T.fbari};
+            for (int k = 0; k < 6; k++) { const R *s = S.get(bn[k], 5); if (s) memcpy(dst[k], s, 5 * sizeof(R)); }
+        }
+        T.oneminus = S.scalar("oneminus"); T.grav = S.scalar("grav"); T.avogad = S.scalar("avogad"); T.rrsw_scon = S.scalar("rrsw_scon");
+        T.Iint = S.scalar("Iint"); T.Fint = S.scalar("Fint"); T.Sint = S.scalar("Sint");
+        T.Mg_avg = S.scalar("Mg_avg"); T.Mg_0 = S.scalar("Mg_0"); T.SB_avg = S.scalar("SB_avg"); T.SB_0 = S.scalar("SB_0");
+        {
+            int32_t icxa[14], ngb[112];
+            if (S.ints("icxa", 14, icxa)) for (int b = 1; b <= NB_SW; b++) T.icxa[b] = icxa[b - 1];
+            // the band <-> g-point map is compiled into the kernels; refuse tables that disagree
+            if (S.ints("ngb", 112, ngb)) {
+                int g = 0;
+                for (int b = 1; b <= NB_SW; b++) for (int k = 0; k < ng[b]; k++, g++) if (ngb[g] != b + 15) S.missing += "ngb(mismatch) ";
+            }
+        }
+        if (!S.missing.empty()) return fail(GEOSRAD_ETABLE, "missing/ill-shaped table entries: " + S.missing);
+        if (d_tab_sw) { HIPCHK(hipFree(d_tab_sw)); d_tab_sw = nullptr; }
+        tab_sw_bytes = S.stage.size();
+        HIPCHK(hipMalloc((void **)&d_tab_sw, tab_sw_bytes));
+        HIPCHK(hipMemcpy(d_tab_sw, S.stage.data(), tab_sw_bytes, hipMemcpyHostToDevice));
+        for (auto &f : S.fix) *f.first = (const R *)(d_tab_sw + f.second);
+        HIPCHK(hipMemcpy(d_S, &h_S, sizeof(SwDev<R>), hipMemcpyHostToDevice));
+        have_sw = true;
+        return GEOSRAD_OK;
+    }
+
+    struct WsSw { R *sc; uint32_t *scidx; uint8_t *colcloudy, *blkcloudy; R *alpha, *rcorr, *taucmc, *ssacmc, *asmcmc, *cotsum, *cell, *part, *bsfc, *cot; };
+    size_t ws_layout_sw(int nc, int nlay, WsSw *w, char *base) const
+    {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return base ? base + o : (char *)nullptr; };
+        const size_t cl = (size_t)nlay * nc;
+        char *p;
+        p = take(SW_NFIELD * cl * sizeof(R)); if (w) w->sc = (R *)p;
+        p = take(cl * 4); if (w) w->scidx = (uint32_t *)p;
+        p = take(nc); if (w) w->colcloudy = (uint8_t *)p;
+        p = take((size_t)(nc + 255) / 256); if (w) w->blkcloudy = (uint8_t *)p;
+        p = take(cl * sizeof(R)); if (w) w->alpha = (R *)p;
+        p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
+        p = take(NG_SW * cl * sizeof(R)); if (w) w->taucmc = (R *)p;
+        p = take(NG_SW * cl * sizeof(R)); if (w) w->ssacmc = (R *)p;
+        p = take(NG_SW * cl * sizeof(R)); if (w) w->asmcmc = (R *)p;
+        p = take((size_t)3 * NG_SW * nc * sizeof(R)); if (w) w->cotsum = (R *)p;
+        p = take((size_t)16 * NG_SW * cl * sizeof(R)); if (w) w->cell = (R *)p;
+        p = take((size_t)4 * NB_SW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
+        p = take((size_t)3 * NB_SW * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
+        p = take((size_t)8 * 3 * nc * sizeof(R)); if (w) w->cot = (R *)p;
+        return off;
+    }
+    int ensure_ws_sw(int nc, int nlay)
+    {
+        if (d_ws_sw && nc <= ws_sw_ncol && nlay == ws_sw_nlay) return GEOSRAD_OK;
+        const int want = (d_ws_sw && nlay == ws_sw_nlay && nc < ws_sw_ncol) ? ws_sw_ncol : nc;
+        if (d_ws_sw) { HIPCHK(hipFree(d_ws_sw)); d_ws_sw = nullptr; ws_sw_bytes = 0; }
+        const size_t need = ws_layout_sw(want, nlay, nullptr, nullptr);
+        hipError_t e = hipMalloc((void **)&d_ws_sw, need);
+        if (e != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the SW workspace failed (" + std::to_string(need >> 20) +
+                                                         " MiB); lower it with geosrad_set_chunk()");
+        ws_sw_bytes = need; ws_sw_ncol = want; ws_sw_nlay = nlay;
+        return GEOSRAD_OK;
+    }
+
+    // solar variability block of the driver (SW/rrtmg_sw_rad.F90:893-1127), scalars only
+    int sw_solar(double scon_d, double adjes_d, int isolvar, const R *bndscl, const R *indsolvar, SwSolar<R> &SV)
+    {
+        const SwDev<R> &T = h_S;
+        const R scon = (R)scon_d, adjes = (R)adjes_d;
+        R solvar[NB_SW + 1];
+        for (int b = 0; b <= NB_SW; b++) { solvar[b] = 1; SV.svar_bnd[b] = 1; SV.adjflux[b] = 1; }
+        SV.isolvar = isolvar; SV.svar_f = 1; SV.svar_s = 1; SV.svar_i = 1;
+        if (isolvar == 1)
+            return fail(GEOSRAD_EINPUT, "isolvar == 1 (averaged solar cycle) is not supported: GEOS_SolarGridComp rejects it as well");
+        if (isolvar != -1 && isolvar != 0 && isolvar != 2 && isolvar != 3) return fail(GEOSRAD_EINPUT, "invalid isolvar");
+        R ndx0 = T.Mg_avg, ndx1 = T.SB_avg;
+        if (isolvar == 2 && indsolvar) { ndx0 = indsolvar[0]; ndx1 = indsolvar[1]; }
+        if (scon == 0) {
+            if (isolvar == -1) { if (bndscl) for (int b = 1; b <= NB_SW; b++) solvar[b] = bndscl[b - 1]; }
+            else if (isolvar == 2) { SV.svar_f = (ndx0 - T.Mg_0) / (T.Mg_avg - T.Mg_0); SV.svar_s = (ndx1 - T.SB_0) / (T.SB_avg - T.SB_0); SV.svar_i = 1; }
+            else if (isolvar == 3) { if (bndscl) for (int b = 1; b <= NB_SW; b++) solvar[b] = bndscl[b - 1];
+                for (int b = 1; b <= NB_SW; b++) SV.svar_bnd[b] = solvar[b]; }
+        } else if (scon > 0) {
+            const R scon_int = T.Fint + T.Sint + T.Iint;
+            if (isolvar == -1) { for (int b = 1; b <= NB_SW; b++) solvar[b] = scon / T.rrsw_scon;
+                if (bndscl) for (int b = 1; b <= NB_SW; b++) solvar[b] = solvar[b] * bndscl[b - 1]; }
+            else if (isolvar == 0) { const R r = scon / scon_int; SV.svar_f = r; SV.svar_s = r; SV.svar_i = r; }
+            else if (isolvar == 2) { SV.svar_f = (ndx0 - T.Mg_0) / (T.Mg_avg - T.Mg_0); SV.svar_s = (ndx1 - T.SB_0) / (T.SB_avg - T.SB_0);
+                SV.svar_i = (scon - (SV.svar_f * T.Fint + SV.svar_s * T.Sint)) / T.Iint; }
+            else { for (int b = 1; b <= NB_SW; b++) solvar[b] = scon / scon_int;
+                if (bndscl) for (int b = 1; b <= NB_SW; b++) solvar[b] = solvar[b] * bndscl[b - 1];
+                for (int b = 1; b <= NB_SW; b++) SV.svar_bnd[b] = solvar[b]; }
+        } else return fail(GEOSRAD_EINPUT, "scon must be >= 0");
+        for (int b = 1; b <= NB_SW; b++) SV.adjflux[b] = adjes;
+        if (isolvar < 0) for (int b = 1; b <= NB_SW; b++) SV.adjflux[b] = SV.adjflux[b] * solvar[b];
+        return GEOSRAD_OK;
+    }
+
+    // ---- RRTMG_SW, device pointers -------------------------------------------------------------------------
+    int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
+               int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband,
+               const void *bndscl, const void *indsolvar, void *const *dbg) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (!have_sw) return fail(GEOSRAD_EINVAL, "RRTMG_SW tables not set: call geosrad_set_tables_sw first (rrtmg_sw_ini)");
+        if (ncol <= 0 || nlay < 4 || nlay > 203) return fail(GEOSRAD_EINVAL, "bad ncol/nlay (4 <= nlay <= mxlay = 203)");
+        if (iceflg < 1 || iceflg > 4) return fail(GEOSRAD_EINPUT, "cldprmc_sw: invalid iceflag");
+        if (liqflg != 1) return fail(GEOSRAD_EINPUT, "cldprmc_sw: invalid liqflag");
+        if (cloudLM == cloudMH) return fail(GEOSRAD_EINPUT, "invalid pressure super-layers!");
+        if (iaer != 0 && iaer != 10) return fail(GEOSRAD_EINPUT, "iaer must be 0 or 10");
+        for (int k = 0; k < S_NIN; k++)
+            if (!in[k] && !((k == S_TAUAER || k == S_SSAAER || k == S_ASMAER) && iaer != 10)) return fail(GEOSRAD_EINVAL, "null input array");
+        for (int k = 0; k < SO_DRBAND; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+        if (do_drfband && (!out[SO_DRBAND] || !out[SO_DFBAND])) return fail(GEOSRAD_EINVAL, "do_drfband set but drband/dfband null");
+        SwSolar<R> SV;
+        int rc = sw_solar(scon, adjes, isolvar, (const R *)bndscl, (const R *)indsolvar, SV);
+        if (rc) return rc;
+
+        // one band's [layer][g<=12][column] plane must stay below 4 GiB (32-bit byte offsets)
+        const long cap = (long)(0xFFFFFFFFull / ((unsigned long long)nlay * 12ull * sizeof(R))) & ~255L;
+        int nc_max = ncol < chunk ? ncol : chunk;
+        if ((long)nc_max > cap) nc_max = (int)cap;
+        rc = ensure_ws_sw(nc_max, nlay);
+        if (rc) return rc;
+
+        for (int c0 = 0; c0 < ncol; c0 += nc_max) {
+            const int nc = (ncol - c0) < nc_max ? (ncol - c0) : nc_max;
+            WsSw w;
+            ws_layout_sw(nc, nlay, &w, d_ws_sw);
+            SwArgs<R> A{};
+            A.ncol = nc; A.ld = ncol; A.nlay = nlay; A.iceflg = iceflg; A.liqflg = liqflg; A.doy = dyofyr; A.cloudLM = cloudLM;
+            A.cloudMH = cloudMH; A.iaer = iaer; A.normFlx = normFlx; A.do_drfband = do_drfband;
+            auto P = [&](int k) { return in[k] ? (const R *)in[k] + c0 : (const R *)nullptr; };
+            A.play = P(S_PLAY); A.plev = P(S_PLEV); A.tlay = P(S_TLAY); A.h2o = P(S_H2O); A.o3 = P(S_O3); A.co2 = P(S_CO2);
+            A.ch4 = P(S_CH4); A.o2 = P(S_O2); A.cld = P(S_CLD); A.ciwp = P(S_CIWP); A.clwp = P(S_CLWP); A.rei = P(S_REI);
+            A.rel = P(S_REL); A.zm = P(S_ZM); A.alat = P(S_ALAT);
+            A.tauaer = iaer == 10 ? P(S_TAUAER) : nullptr; A.ssaaer = iaer == 10 ? P(S_SSAAER) : nullptr;
+            A.asmaer = iaer == 10 ? P(S_ASMAER) : nullptr;
+            A.coszen = P(S_COSZEN); A.asdir = P(S_ASDIR); A.asdif = P(S_ASDIF); A.aldir = P(S_ALDIR); A.aldif = P(S_ALDIF);
+            A.sc = w.sc; A.scidx = w.scidx; A.colcloudy = w.colcloudy; A.blkcloudy = w.blkcloudy; A.alpha = w.alpha; A.rcorr = w.rcorr;
+            A.taucmc = w.taucmc; A.ssacmc = w.ssacmc; A.asmcmc = w.asmcmc; A.cotsum = w.cotsum; A.cell = w.cell; A.part = w.part;
+            A.bsfc = w.bsfc; A.cot = w.cot;
+            A.err = d_err + 1;
+            A.clearCounts = clearCounts + c0;
+            if (dbg) {
+                A.dbg_taug = (R *)dbg[0] + (size_t)c0 * NG_SW * nlay; A.dbg_taur = (R *)dbg[1] + (size_t)c0 * NG_SW * nlay;
+                A.dbg_ssi = (R *)dbg[2] + (size_t)c0 * NG_SW;
+            }
+            const dim3 blk(256);
+            const unsigned gx = (unsigned)((nc + 255) / 256);
+            HIPCHK(hipMemsetAsync(w.blkcloudy, 0, (size_t)(nc + 255) / 256, st));
+            span_begin(6, st); hipLaunchKernelGGL(k_sw_validate<R>, dim3(gx), blk, 0, st, A); span_end(st);
+            span_begin(7, st); hipLaunchKernelGGL(k_sw_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, (const SwDev<R> *)d_S); span_end(st);
+            span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,
+                               (const uint8_t *)A.colcloudy, (const LwDev<R> *)d_T, A.alpha, A.rcorr, (uint8_t *)nullptr); span_end(st);
+            McArgs<R> M{};
+            M.ncol = nc; M.ld = ncol; M.nlay = nlay; M.nsubcol = NG_SW; M.doy = dyofyr; M.cloudLM = cloudLM; M.cloudMH = cloudMH;
+            M.iceflg = iceflg; M.liqflg = liqflg;
+            M.so[0] = 4; M.so[1] = 3; M.so[2] = 2; M.so[3] = 1;        // seed_order=[4,3,2,1] (SW/rrtmg_sw_rad.F90:1401)
+            M.cwp_tiny = (R)1.e-20;
+            M.play = A.play; M.cldf = A.cld; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
+            M.alpha = A.alpha; M.rcorr = A.rcorr; M.colcloudy = A.colcloudy;
+            M.taucmc = A.taucmc; M.ssacmc = A.ssacmc; M.asmcmc = A.asmcmc; M.cotsum = A.cotsum; M.clearCounts = A.clearCounts; M.err = d_err + 1;
+            {
+                static const int bstart[15] = {0, 6, 18, 26, 34, 44, 54, 56, 66, 74, 80, 86, 94, 100, 112};
+                const McSeg SG = make_segments(bstart, NB_SW, nlay, h_T.xcw != nullptr);
+                span_begin(3, st);
+                hipLaunchKernelGGL((k_mcica<R, 2>), dim3((unsigned)((nc + 63) / 64), NB_SW), dim3(64), 0, st, M, SG, (const LwDev<R> *)d_T,
+                                   (const SwDev<R> *)d_S);
+                span_end(st);
+            }
+            span_begin(8, st);
+            if (dbg) {
+                hipLaunchKernelGGL((k_sw_bands<R, true, true>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+            } else {
+                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+            }
+            span_end(st);
+            SwOut<R> O{};
+            auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
+            O.swuflx = Q(SO_UFLX); O.swdflx = Q(SO_DFLX); O.swuflxc = Q(SO_UFLXC); O.swdflxc = Q(SO_DFLXC);
+            O.nirr = Q(SO_NIRR); O.nirf = Q(SO_NIRF); O.parr = Q(SO_PARR); O.parf = Q(SO_PARF); O.uvrr = Q(SO_UVRR); O.uvrf = Q(SO_UVRF);
+            O.fswband = Q(SO_FSWBAND);
+            for (int k = 0; k < 8; k++) O.cot[k] = Q(SO_COT0 + k);
+            O.drband = Q(SO_DRBAND); O.dfband = Q(SO_DFBAND);
+            span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx), blk, 0, st, A, O); span_end(st);
+        }
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    // ---- RRTMG_SW, host pointers ---------------------------------------------------------------------------
+    int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg, int dyofyr,
+                int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband, const void *bndscl,
+                const void *indsolvar, void *const *dbg) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || nlay <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay");
+        const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
+        size_t insz[S_NIN];
+        for (int k = 0; k < S_NIN; k++) insz[k] = cl;
+        insz[S_PLEV] = cv; insz[S_ALAT] = insz[S_COSZEN] = insz[S_ASDIR] = insz[S_ASDIF] = insz[S_ALDIR] = insz[S_ALDIF] = ncol;
+        insz[S_TAUAER] = insz[S_SSAAER] = insz[S_ASMAER] = cl * NB_SW;
+        size_t outsz[SO_NOUT];
+        for (int k = 0; k < SO_NOUT; k++) outsz[k] = ncol;
+        outsz[SO_UFLX] = outsz[SO_DFLX] = outsz[SO_UFLXC] = outsz[SO_DFLXC] = cv;
+        outsz[SO_FSWBAND] = outsz[SO_DRBAND] = outsz[SO_DFBAND] = (size_t)ncol * NB_SW;
+        size_t off = 0;
+        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
+        size_t ino[S_NIN], outo[SO_NOUT];
+        for (int k = 0; k < S_NIN; k++) {
+            const bool aer = (k == S_TAUAER || k == S_SSAAER || k == S_ASMAER);
+            ino[k] = (in[k] && !(aer && iaer != 10)) ? take(insz[k]) : (size_t)-1;
+        }
+        for (int k = 0; k < SO_NOUT; k++) outo[k] = take(outsz[k]);
+        const size_t cco = take((size_t)ncol * 4 * sizeof(int32_t) / sizeof(R) + 4);
+        size_t dbgo[3] = {0, 0, 0};
+        if (dbg) { dbgo[0] = take(cl * NG_SW); dbgo[1] = take(cl * NG_SW); dbgo[2] = take((size_t)ncol * NG_SW); }
+        int rc = ensure_io(off);
+        if (rc) return rc;
+        const void *din[S_NIN]; void *dout[SO_NOUT];
+        for (int k = 0; k < S_NIN; k++) {
+            din[k] = ino[k] != (size_t)-1 ? d_io + ino[k] : nullptr;
+            if (din[k]) HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
+        }
+        for (int k = 0; k < SO_NOUT; k++) dout[k] = (out[k] || k < SO_DRBAND) ? d_io + outo[k] : nullptr;
+        void *ddbg[3] = {d_io + dbgo[0], d_io + dbgo[1], d_io + dbgo[2]};
+        rc = sw_dev(stream, ncol, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
+                    (int32_t *)(d_io + cco), dout, do_drfband, bndscl, indsolvar, dbg ? ddbg : nullptr);
+        if (rc) return rc;
+        rc = check(stream);
+        if (rc) return rc;
+        for (int k = 0; k < SO_NOUT; k++) {
+            if (!out[k]) continue;
+            if ((k == SO_DRBAND || k == SO_DFBAND) && !do_drfband) continue;
+            HIPCHK(hipMemcpyAsync(out[k], dout[k], outsz[k] * sizeof(R), hipMemcpyDeviceToHost, stream));
+        }
+        if (clearCounts) HIPCHK(hipMemcpyAsync(clearCounts, d_io + cco, (size_t)ncol * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (dbg) {
+            HIPCHK(hipMemcpyAsync(dbg[0], ddbg[0], cl * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(dbg[1], ddbg[1], cl * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(dbg[2], ddbg[2], (size_t)ncol * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        return GEOSRAD_OK;
+    }
+
     // ---- stand-alone McICA generator, host pointers ------------------------------------------------------------------
     int mcica_host(int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play, const void *cldfrac,
                    const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so, int32_t *cldy, void *ciwp_s,
@@ -660,7 +1025,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         int nseg = nsubcol < 16 ? nsubcol : 16, sstart[17];
         for (int s = 0; s <= nseg; s++) sstart[s] = (int)((long)s * nsubcol / nseg);
         const McSeg SG = make_segments(sstart, nseg, nlay, h_T.xcw != nullptr);
-        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, stream, M, SG, (const LwDev<R> *)d_T);
+        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, stream, M, SG, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(cldy, d_io + o_cy, co * 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(ciwp_s, d_io + o_ci, co * sizeof(R), hipMemcpyDeviceToHost, stream));
@@ -728,6 +1093,85 @@ int geosrad_load_inhomogeneity(geosrad_ctx *c, int ih, const char *path)
 }
 int geosrad_set_corr_lengths(geosrad_ctx *c, const double *adl, const double *rdl) { return c ? c->set_corr(adl, rdl) : GEOSRAD_EINVAL; }
 
+
+int geosrad_set_tables_sw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_sw(blob, n) : GEOSRAD_EINVAL; }
+int geosrad_load_tables_sw(geosrad_ctx *c, const char *path)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    std::vector<char> buf;
+    int rc = read_file(c, path, buf);
+    return rc ? rc : c->set_tables_sw(buf.data(), buf.size());
+}
+
+#define SW_PACK()                                                                                                              \
+    const void *in[S_NIN] = {play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr, cld, ciwp, clwp, rei, rel, zm, alat, tauaer,     \
+                             ssaaer, asmaer, coszen, asdir, asdif, aldir, aldif};                                              \
+    void *out[SO_NOUT] = {swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, cotdtp, cotdhp, cotdmp,     \
+                          cotdlp, cotntp, cotnhp, cotnmp, cotnlp, drband, dfband}
+
+int geosrad_rrtmg_sw(geosrad_ctx *c, int rpart, int ncol, int nlay, double scon, double adjes, const void *coszen, int isolvar,
+                     const void *play, const void *plev, const void *tlay, const void *h2ovmr, const void *o3vmr, const void *co2vmr,
+                     const void *ch4vmr, const void *o2vmr, int iceflgsw, int liqflgsw, const void *cld, const void *ciwp,
+                     const void *clwp, const void *rei, const void *rel, int dyofyr, const void *zm, const void *alat, int iaer,
+                     const void *tauaer, const void *ssaaer, const void *asmaer, const void *asdir, const void *asdif,
+                     const void *aldir, const void *aldif, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *swuflx,
+                     void *swdflx, void *swuflxc, void *swdflxc, void *nirr, void *nirf, void *parr, void *parf, void *uvrr,
+                     void *uvrf, void *fswband, void *cotdtp, void *cotdhp, void *cotdmp, void *cotdlp, void *cotntp, void *cotnhp,
+                     void *cotnmp, void *cotnlp, int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    (void)rpart;
+    SW_PACK();
+    return c->sw_host(ncol, nlay, scon, adjes, isolvar, in, iceflgsw, liqflgsw, dyofyr, iaer, cloudLM, cloudMH, normFlx, clearCounts, out,
+                      do_drfband, bndscl, indsolvar, nullptr);
+}
+
+int geosrad_rrtmg_sw_dev(geosrad_ctx *c, void *stream, int rpart, int ncol, int nlay, double scon, double adjes, const void *coszen,
+                         int isolvar, const void *play, const void *plev, const void *tlay, const void *h2ovmr, const void *o3vmr,
+                         const void *co2vmr, const void *ch4vmr, const void *o2vmr, int iceflgsw, int liqflgsw, const void *cld,
+                         const void *ciwp, const void *clwp, const void *rei, const void *rel, int dyofyr, const void *zm,
+                         const void *alat, int iaer, const void *tauaer, const void *ssaaer, const void *asmaer, const void *asdir,
+                         const void *asdif, const void *aldir, const void *aldif, int cloudLM, int cloudMH, int normFlx,
+                         int32_t *clearCounts, void *swuflx, void *swdflx, void *swuflxc, void *swdflxc, void *nirr, void *nirf,
+                         void *parr, void *parf, void *uvrr, void *uvrf, void *fswband, void *cotdtp, void *cotdhp, void *cotdmp,
+                         void *cotdlp, void *cotntp, void *cotnhp, void *cotnmp, void *cotnlp, int do_drfband, void *drband,
+                         void *dfband, const void *bndscl, const void *indsolvar)
+{
+    if (!c || !clearCounts) return GEOSRAD_EINVAL;
+    (void)rpart;
+    SW_PACK();
+    return c->sw_dev((hipStream_t)stream, ncol, nlay, scon, adjes, isolvar, in, iceflgsw, liqflgsw, dyofyr, iaer, cloudLM, cloudMH, normFlx,
+                     clearCounts, out, do_drfband, bndscl, indsolvar, nullptr);
+}
+
+int geosrad_rrtmg_sw_taumol(geosrad_ctx *c, int ncol, int nlay, double scon, int isolvar, const void *play, const void *plev,
+                            const void *tlay, const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr,
+                            const void *o2vmr, const void *bndscl, const void *indsolvar, void *taug, void *taur, void *ssi)
+{
+    if (!c || !taug || !taur || !ssi || ncol <= 0 || nlay <= 0) return GEOSRAD_EINVAL;
+    // clear-sky run (zero cloud field, overhead sun, black surface); fluxes are discarded
+    const size_t esz = (size_t)c->real_kind;
+    const size_t cv = (size_t)ncol * (nlay + 1) * esz;
+    std::vector<char> zero(cv, 0), tens((size_t)ncol * nlay * esz, 0), one((size_t)ncol * esz, 0), scratch(4 * cv + (size_t)ncol * esz * (6 + 14 + 8));
+    for (size_t i = 0; i < (size_t)ncol * nlay; i++) { if (esz == 4) ((float *)tens.data())[i] = 10.f; else ((double *)tens.data())[i] = 10.; }
+    for (size_t i = 0; i < (size_t)ncol; i++) { if (esz == 4) ((float *)one.data())[i] = 1.f; else ((double *)one.data())[i] = 1.; }
+    std::vector<int32_t> cc((size_t)ncol * 4);
+    const void *cld = zero.data(), *ciwp = zero.data(), *clwp = zero.data(), *rei = tens.data(), *rel = tens.data(), *zm = zero.data(),
+               *alat = zero.data(), *tauaer = nullptr, *ssaaer = nullptr, *asmaer = nullptr, *coszen = one.data(), *asdir = zero.data(),
+               *asdif = zero.data(), *aldir = zero.data(), *aldif = zero.data();
+    char *s = scratch.data();
+    const size_t cn = (size_t)ncol * esz;
+    void *swuflx = s, *swdflx = s + cv, *swuflxc = s + 2 * cv, *swdflxc = s + 3 * cv;
+    char *q = s + 4 * cv;
+    void *nirr = q, *nirf = q + cn, *parr = q + 2 * cn, *parf = q + 3 * cn, *uvrr = q + 4 * cn, *uvrf = q + 5 * cn, *fswband = q + 6 * cn;
+    q += 20 * cn;
+    void *cotdtp = q, *cotdhp = q + cn, *cotdmp = q + 2 * cn, *cotdlp = q + 3 * cn, *cotntp = q + 4 * cn, *cotnhp = q + 5 * cn,
+         *cotnmp = q + 6 * cn, *cotnlp = q + 7 * cn, *drband = nullptr, *dfband = nullptr;
+    SW_PACK();
+    void *dbg[3] = {taug, taur, ssi};
+    return c->sw_host(ncol, nlay, scon, 1.0, isolvar, in, 3, 1, 1, 0, 1, 2, 0, cc.data(), out, 0, bndscl, indsolvar, dbg);
+}
+
 #define LW_PACK_IN()                                                                                                     \
     const void *in[I_NIN] = {play, plev, tlay, tlev, tsfc, emis, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, \
                              cfc12vmr, cfc22vmr, ccl4vmr, cldf, ciwp, clwp, rei, rel, tauaer, zm, alat}
@@ -768,12 +1212,12 @@ int geosrad_profile(geosrad_ctx *c, int enable)
     if (!c) return GEOSRAD_EINVAL;
     c->prof_collect();
     c->profiling = enable != 0;
-    for (int k = 0; k < 8; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    for (int k = 0; k < 12; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return GEOSRAD_OK;
 }
 int geosrad_profile_read(geosrad_ctx *c, int kernel_id, double *total_ms, long *launches)
 {
-    if (!c || kernel_id < 0 || kernel_id >= 8) return GEOSRAD_EINVAL;
+    if (!c || kernel_id < 0 || kernel_id >= 12) return GEOSRAD_EINVAL;
     (void)hipSetDevice(c->device);
     c->prof_collect();
     if (total_ms) *total_ms = c->prof_ms[kernel_id];
@@ -782,8 +1226,9 @@ int geosrad_profile_read(geosrad_ctx *c, int kernel_id, double *total_ms, long *
 }
 const char *geosrad_kernel_name(int kernel_id)
 {
-    static const char *nm[6] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce"};
-    return kernel_id >= 0 && kernel_id < 6 ? nm[kernel_id] : "";
+    static const char *nm[10] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce",
+                                 "k_sw_validate", "k_sw_setcoef", "k_sw_bands", "k_sw_reduce"};
+    return kernel_id >= 0 && kernel_id < 10 ? nm[kernel_id] : "";
 }
 
 int geosrad_check(geosrad_ctx *c, void *stream) { return c ? c->check((hipStream_t)stream) : GEOSRAD_EINVAL; }

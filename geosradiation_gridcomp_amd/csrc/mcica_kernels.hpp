@@ -200,6 +200,81 @@ GR_DEV R lw_cloud_tau(const LwDev<R> &T, int iceflag, int ib, R ciwp, R clwp, R 
     return tau;
 }
 
+// cldprmc_sw for one cloudy cell (SW/rrtmg_sw_cldprmc.F90:131-411): un-scaled tau (taormc) and the delta-scaled
+// tau / single-scattering albedo / asymmetry of the combined liquid + ice cloud.  jb = 16..29.
+template <typename R>
+GR_DEV void sw_cloud_optics(const SwDev<R> &S, int iceflag, int jb, R ciwp, R clwp, R radice, R radliq, R &taor, R &tauc, R &ssac,
+                            R &asmc)
+{
+    const R epsg = (R)1.e-06, cldmin = (R)1.e-20;
+    const int ib = jb - 16;      // 0-based column of the (n,16:29) tables
+    R extcoice = 0, ssacoice = 0, gice = 0, forwice = 0, extcoliq = 0, ssacoliq = 0, gliq = 0, forwliq = 0;
+#define LIN_T(tab, nmax) ((tab)[(size_t)ib * (nmax) + index - 1] + fint * ((tab)[(size_t)ib * (nmax) + index] - (tab)[(size_t)ib * (nmax) + index - 1]))
+    if (ciwp != 0) {
+        if (iceflag == 1) {
+            const int ic = S.icxa[jb - 15] - 1;
+            extcoice = S.abari[ic] + S.bbari[ic] / radice;
+            ssacoice = (R)1. - S.cbari[ic] - S.dbari[ic] * radice;
+            gice = S.ebari[ic] + S.fbari[ic] * radice;
+            if (gice > (R)1. - epsg) gice = (R)1. - epsg;
+            forwice = gice * gice;
+        } else if (iceflag == 2) {
+            const R factor = (radice - (R)2.) / (R)3.;
+            int index = (int)factor; if (index == 43) index = 42;
+            const R fint = factor - (R)index;
+            index = clampi(index, 1, 42);      // memory safety only: the reference does not range-check here
+            extcoice = LIN_T(S.extice2, 43); ssacoice = LIN_T(S.ssaice2, 43); gice = LIN_T(S.asyice2, 43);
+            forwice = gice * gice;
+        } else if (iceflag == 3) {
+            const R factor = (radice - (R)2.) / (R)3.;
+            int index = (int)factor; if (index == 46) index = 45;
+            const R fint = factor - (R)index;
+            index = clampi(index, 1, 45);
+            extcoice = LIN_T(S.extice3, 46); ssacoice = LIN_T(S.ssaice3, 46); gice = LIN_T(S.asyice3, 46);
+            const R fdelta = LIN_T(S.fdlice3, 46);
+            forwice = fdelta + (R)0.5 / ssacoice;
+            if (forwice > gice) forwice = gice;
+        } else {
+            const R factor = radice;
+            int index = (int)factor;
+            const R fint = factor - (R)index;
+            index = clampi(index, 1, 199);
+            extcoice = LIN_T(S.extice4, 200); ssacoice = LIN_T(S.ssaice4, 200); gice = LIN_T(S.asyice4, 200);
+            forwice = gice * gice;
+        }
+    }
+    if (clwp != 0) {
+        int index = (int)(radliq - (R)1.5);
+        if (index == 0) index = 1;
+        if (index == 58) index = 57;
+        const R fint = radliq - (R)1.5 - (R)index;
+        index = clampi(index, 1, 57);
+        extcoliq = LIN_T(S.extliq1, 58);
+        ssacoliq = LIN_T(S.ssaliq1, 58);
+        if (fint < 0 && ssacoliq > (R)1.) ssacoliq = S.ssaliq1[(size_t)ib * 58 + index - 1];
+        gliq = LIN_T(S.asyliq1, 58);
+        forwliq = gliq * gliq;
+    }
+#undef LIN_T
+    const R tauliqorig = clwp * extcoliq, tauiceorig = ciwp * extcoice;
+    taor = tauliqorig + tauiceorig;
+    const R ssaliq = ssacoliq * ((R)1. - forwliq) / ((R)1. - forwliq * ssacoliq);
+    const R ssaice = ssacoice * ((R)1. - forwice) / ((R)1. - forwice * ssacoice);
+    const R tauliq = ((R)1. - forwliq * ssacoliq) * tauliqorig;
+    const R tauice = ((R)1. - forwice * ssacoice) * tauiceorig;
+    const R scatliq = ssaliq * tauliq;
+    R scatice = ssaice * tauice;
+    R tc = tauliq + tauice;
+    if (tc == 0) tc = cldmin;
+    if (scatice == 0) scatice = cldmin;
+    tauc = tc;
+    ssac = (scatliq + scatice) / tc;
+    if (iceflag == 3)
+        asmc = ((R)1. / (scatliq + scatice)) * (scatliq * (gliq - forwliq) / ((R)1. - forwliq) + scatice * ((gice - forwice) / ((R)1. - forwice)));
+    else
+        asmc = (scatliq * (gliq - forwliq) / ((R)1. - forwliq) + scatice * (gice - forwice) / ((R)1. - forwice)) / (scatliq + scatice);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_mcica: one thread per (column, segment of sub-columns); blockIdx.y = segment.  The column's KISS stream is
 // seeded as in the reference and jumped ahead to the segment's first sub-column (see KissJump), then walked
@@ -208,6 +283,8 @@ GR_DEV R lw_cloud_tau(const LwDev<R> &T, int iceflag, int ib, R ciwp, R clwp, R 
 //          cldprmc: writes taucmc (band-major plane layout), ORs laycloudy[lay][col], adds clearCounts(ncol,4).
 //   MODE 1 (stand-alone generator API): up to 16 equal segments; writes cldy/ciwp_stoch/clwp_stoch Fortran
 //          (nlay,nsubcol,ncol).
+//   MODE 2 (RRTMG_SW): segments = the 14 bands (sub-column == g-point); fused generator + clearCounts + cldprmc_sw:
+//          writes taucmc / ssacmc / asmcmc planes, the PAR bands' super-layer sums of the un-scaled tau (cotsum).
 // Two passes per sub-column: pass 1 draws (cdf1,cdf2) for every layer and parks the cloud-presence
 // decision in the output cell; pass 2 draws (cdf2,cdf3) and finishes the cell.  No per-thread arrays.
 // ---------------------------------------------------------------------------------------------------
@@ -222,10 +299,12 @@ template <typename R> struct McArgs {
     R *taucmc; uint8_t *laycloudy; int32_t *clearCounts; uint32_t *err;
     // MODE 1
     int32_t *cldy; R *ciwp_s, *clwp_s;
+    // MODE 2
+    R *ssacmc, *asmcmc, *cotsum;
 };
 
 template <typename R, int MODE>
-__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev<R> *__restrict__ Tp)
+__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev<R> *__restrict__ Tp, const SwDev<R> *__restrict__ Sp)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int seg = blockIdx.y;
@@ -247,11 +326,15 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
     else { hi0 = 0; hi1 = M.cloudMH - 2; mi0 = M.cloudMH - 1; mi1 = M.cloudLM - 2; lo0 = M.cloudLM - 1; lo1 = nlay - 1; }
     int cnt_all = 0, cnt_hi = 0, cnt_mid = 0, cnt_lo = 0;
 
-    const int ib = MODE == 0 ? seg + 1 : 0;     // MODE 0: segment == band
+    const int ib = MODE == 0 ? seg + 1 : (MODE == 2 ? seg + 16 : 0);     // MODE 0 / 2: segment == band
+    const int bg0 = MODE == 0 ? lw_band_g0(ib) : (MODE == 2 ? sw_band_g0(ib) : 0);
+    const int bng = MODE == 0 ? lw_band_ng(ib) : (MODE == 2 ? sw_band_ng(ib) : 0);
+    constexpr bool PLANES = MODE == 0 || MODE == 2;
     for (int is = SG.start[seg]; is < SG.start[seg + 1]; is++) {
         // taucmc plane layout (see band_body): band-major, then [layer][g-in-band][column]
-        const size_t tb0 = MODE == 0 ? (size_t)lw_band_g0(ib) * nlay * n + (size_t)(is - lw_band_g0(ib)) * n + col : 0;
-        const size_t tbs = MODE == 0 ? (size_t)lw_band_ng(ib) * n : 0;     // + il * tbs
+        const size_t tb0 = PLANES ? (size_t)bg0 * nlay * n + (size_t)(is - bg0) * n + col : 0;
+        const size_t tbs = PLANES ? (size_t)bng * n : 0;     // + il * tbs
+        R cs_lo = 0, cs_mid = 0, cs_hi = 0;                  // MODE 2: super-layer sums of taormc (spcvmc :760-800)
         bool any_all = false, any_hi = false, any_mid = false, any_lo = false;
         // ---- pass 1: cloud presence with exponential overlap (:406-414) ----
         R cprev = 0;
@@ -279,12 +362,18 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
                     if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
                     M.taucmc[tb0 + (size_t)il * tbs] = tau;
                     if (tau > 0) M.laycloudy[w] = 1;
+                } else if (MODE == 2) {
+                    R taor = 0, tauc = 0, ssac = 1, asmc = 0;
+                    if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], taor, tauc, ssac, asmc);
+                    const size_t oc = tb0 + (size_t)il * tbs;
+                    M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
+                    if (il < M.cloudLM) cs_lo += taor; else if (il < M.cloudMH) cs_mid += taor; else cs_hi += taor;
                 } else {
                     const size_t o = ((size_t)col * M.nsubcol + is) * nlay + il;
                     M.cldy[o] = c ? 1 : 0; M.ciwp_s[o] = ci; M.clwp_s[o] = cl;
                 }
             } else {
-                if (MODE == 0) M.taucmc[tb0 + (size_t)il * tbs] = cloudy ? (R)1 : (R)0;
+                if (PLANES) M.taucmc[tb0 + (size_t)il * tbs] = cloudy ? (R)1 : (R)0;
                 else M.cldy[((size_t)col * M.nsubcol + is) * nlay + il] = cloudy ? 1 : 0;
             }
         }
@@ -297,8 +386,9 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
                 const size_t w = (size_t)il * n + col, a = (size_t)il * ld + col;
                 if (il > 0 && cdf2 < M.rcorr[w]) cdf3 = c3prev;
                 c3prev = cdf3;
-                const size_t oc = MODE == 0 ? tb0 + (size_t)il * tbs : ((size_t)col * M.nsubcol + is) * nlay + il;
-                const bool cloudy = MODE == 0 ? (M.taucmc[oc] != (R)0) : (M.cldy[oc] != 0);
+                const size_t oc = PLANES ? tb0 + (size_t)il * tbs : ((size_t)col * M.nsubcol + is) * nlay + il;
+                bool cloudy;
+                if constexpr (PLANES) cloudy = M.taucmc[oc] != (R)0; else cloudy = M.cldy[oc] != 0;
                 R ci = 0, cl = 0; bool c = false;
                 if (cloudy) {
                     const R cf = M.cldf[a];
@@ -316,17 +406,27 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
                     if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
                     M.taucmc[oc] = tau;
                     if (tau > 0) M.laycloudy[w] = 1;
+                } else if (MODE == 2) {
+                    R taor = 0, tauc = 0, ssac = 1, asmc = 0;
+                    if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], taor, tauc, ssac, asmc);
+                    M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
+                    if (il < M.cloudLM) cs_lo += taor; else if (il < M.cloudMH) cs_mid += taor; else cs_hi += taor;
                 } else {
                     M.cldy[oc] = c ? 1 : 0; M.ciwp_s[oc] = ci; M.clwp_s[oc] = cl;
                 }
             }
+        }
+        if (MODE == 2 && ib >= 24 && ib <= 26) {
+            M.cotsum[((size_t)0 * 112 + is) * n + col] = cs_lo;
+            M.cotsum[((size_t)1 * 112 + is) * n + col] = cs_mid;
+            M.cotsum[((size_t)2 * 112 + is) * n + col] = cs_hi;
         }
         if (!any_all) cnt_all++;
         if (!any_hi) cnt_hi++;
         if (!any_mid) cnt_mid++;
         if (!any_lo) cnt_lo++;
     }
-    if (MODE == 0) {
+    if (PLANES) {
         // integer adds: order-independent, bitwise reproducible (k_validate_pwv zeroed the cloudy columns' counts)
         atomicAdd(&M.clearCounts[(size_t)0 * ld + col], cnt_all);
         atomicAdd(&M.clearCounts[(size_t)1 * ld + col], cnt_hi);

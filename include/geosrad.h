@@ -6,6 +6,9 @@
  *   geosrad_rrtmg_lw[_dev]        <- rrtmg_lw_rad::rrtmg_lw
  *                                    GEOSirrad_GridComp/RRTMG/rrtmg_lw/gcm_model/src/rrtmg_lw_rad.F90:15-23,110-201
  *   geosrad_set_tables_lw         <- rrtmg_lw_init::rrtmg_lw_ini           .../src/rrtmg_lw_init.F90:22
+ *   geosrad_rrtmg_sw[_dev]        <- rrtmg_sw_rad::rrtmg_sw
+ *                                    GEOSsolar_GridComp/RRTMG/rrtmg_sw/gcm_model/src/rrtmg_sw_rad.F90:68-124
+ *   geosrad_set_tables_sw         <- rrtmg_sw_init::rrtmg_sw_ini           .../src/rrtmg_sw_init.F90:23
  *   geosrad_mcica[_dev]           <- cloud_subcol_gen::generate_stochastic_clouds
  *                                    GEOS_RadiationShared/cloud_subcol_gen.F90:132-137
  *   geosrad_clearcounts           <- cloud_subcol_gen::clearCounts_threeBand   .../cloud_subcol_gen.F90:611-614
@@ -57,7 +60,7 @@ int geosrad_create(geosrad_ctx **ctx, int device_id, int real_kind /* 4 | 8 */);
 int geosrad_destroy(geosrad_ctx *ctx);
 const char *geosrad_last_error(const geosrad_ctx *ctx);
 int geosrad_real_kind(const geosrad_ctx *ctx);
-/* max columns processed per internal batch (bounds the HBM workspace); default 65536 */
+/* max columns processed per internal batch (bounds the HBM workspace); default 131072 */
 int geosrad_set_chunk(geosrad_ctx *ctx, int max_columns);
 /* bytes of HBM workspace currently held */
 size_t geosrad_workspace_bytes(const geosrad_ctx *ctx);
@@ -66,6 +69,9 @@ size_t geosrad_workspace_bytes(const geosrad_ctx *ctx);
 /* what rrtmg_lw_ini leaves in rrlw_kgNN/rrlw_tbl/rrlw_wvn/rrlw_ref/rrlw_cld (rrtmg_lw_init.F90:22-165) */
 int geosrad_set_tables_lw(geosrad_ctx *ctx, const void *blob, size_t nbytes);
 int geosrad_load_tables_lw(geosrad_ctx *ctx, const char *path);
+/* what rrtmg_sw_ini leaves in rrsw_kgNN/rrsw_ref/rrsw_cld/rrsw_wvn/NRLSSI2 (SW/rrtmg_sw_init.F90:23-190) */
+int geosrad_set_tables_sw(geosrad_ctx *ctx, const void *blob, size_t nbytes);
+int geosrad_load_tables_sw(geosrad_ctx *ctx, const char *path);
 /* ih = 0 homogeneous (blob ignored), 1 beta, 2 gamma; blob = xcw(1000,140) table of that kind */
 int geosrad_set_inhomogeneity(geosrad_ctx *ctx, int ih, const void *xcw_blob, size_t nbytes);
 int geosrad_load_inhomogeneity(geosrad_ctx *ctx, int ih, const char *path);
@@ -113,7 +119,8 @@ int geosrad_rrtmg_lw_dev(geosrad_ctx *ctx, void *stream, int ncol, int nlay, int
 int geosrad_check(geosrad_ctx *ctx, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, around every kernel the *_dev entry points
- * enqueue (kernel ids 0..5 = k_validate_pwv, k_setcoef, k_overlap, k_mcica, k_lw_bands, k_lw_reduce).
+ * enqueue (kernel ids 0..5 = k_validate_pwv, k_setcoef, k_overlap, k_mcica, k_lw_bands, k_lw_reduce; 6..9 =
+ * k_sw_validate, k_sw_setcoef, k_sw_bands, k_sw_reduce; k_overlap / k_mcica are shared by LW and SW).
  * geosrad_profile(ctx, 1) resets and enables, geosrad_profile_read() waits for the recorded events and
  * returns the accumulated milliseconds and launch count of one kernel. */
 int geosrad_profile(geosrad_ctx *ctx, int enable);
@@ -130,6 +137,54 @@ int geosrad_rrtmg_lw_taumol(geosrad_ctx *ctx, int ncol, int nlay,
                             const void *n2ovmr, const void *o2vmr, const void *cfc11vmr, const void *cfc12vmr,
                             const void *cfc22vmr, const void *ccl4vmr, const void *tauaer,
                             void *taug, void *pfracs);
+
+/* ---- RRTMG_SW ------------------------------------------------------------------------------------------
+ * rrtmg_sw (SW/rrtmg_sw_rad.F90:68-124), same argument order without the MAPL handle / RC (the return code is
+ * the RC).  Real arrays, element type = real_kind, Fortran layouts:
+ *   coszen, alat, asdir, asdif, aldir, aldif (ncol); play, tlay, gases, cld, ciwp, clwp, rei, rel, zm (ncol,nlay);
+ *   plev (ncol,nlay+1); tauaer, ssaaer, asmaer (ncol,nlay,14) (read only when iaer == 10, else may be NULL);
+ *   swuflx, swdflx, swuflxc, swdflxc (ncol,nlay+1); nirr..uvrf, cot* (ncol); fswband, drband, dfband (ncol,14)
+ *   (drband/dfband written only when do_drfband != 0); clearCounts int32 (ncol,4).
+ *   scon, adjes: double here, rounded to real_kind like the reference's default-real dummy arguments.
+ *   bndscl (14 reals) and indsolvar (2 reals): HOST pointers in both variants, NULL = absent optional argument.
+ *   isolvar in {-1, 0, 2, 3}; 1 (solcycfrac) returns GEOSRAD_EINPUT -- GEOS_SolarGridComp.F90:6286-6292 rejects it too.
+ *   rpart (the reference's column-partition size) is accepted and ignored: the GPU batches internally. */
+int geosrad_rrtmg_sw(geosrad_ctx *ctx, int rpart, int ncol, int nlay, double scon, double adjes, const void *coszen, int isolvar,
+                     const void *play, const void *plev, const void *tlay,
+                     const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
+                     int iceflgsw, int liqflgsw,
+                     const void *cld, const void *ciwp, const void *clwp, const void *rei, const void *rel,
+                     int dyofyr, const void *zm, const void *alat,
+                     int iaer, const void *tauaer, const void *ssaaer, const void *asmaer,
+                     const void *asdir, const void *asdif, const void *aldir, const void *aldif,
+                     int cloudLM, int cloudMH, int normFlx,
+                     int32_t *clearCounts, void *swuflx, void *swdflx, void *swuflxc, void *swdflxc,
+                     void *nirr, void *nirf, void *parr, void *parf, void *uvrr, void *uvrf, void *fswband,
+                     void *cotdtp, void *cotdhp, void *cotdmp, void *cotdlp,
+                     void *cotntp, void *cotnhp, void *cotnmp, void *cotnlp,
+                     int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar);
+/* same, DEVICE pointers, asynchronous on `stream`; input assertions are reported by geosrad_check() */
+int geosrad_rrtmg_sw_dev(geosrad_ctx *ctx, void *stream, int rpart, int ncol, int nlay, double scon, double adjes,
+                         const void *coszen, int isolvar,
+                         const void *play, const void *plev, const void *tlay,
+                         const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
+                         int iceflgsw, int liqflgsw,
+                         const void *cld, const void *ciwp, const void *clwp, const void *rei, const void *rel,
+                         int dyofyr, const void *zm, const void *alat,
+                         int iaer, const void *tauaer, const void *ssaaer, const void *asmaer,
+                         const void *asdir, const void *asdif, const void *aldir, const void *aldif,
+                         int cloudLM, int cloudMH, int normFlx,
+                         int32_t *clearCounts, void *swuflx, void *swdflx, void *swuflxc, void *swdflxc,
+                         void *nirr, void *nirf, void *parr, void *parf, void *uvrr, void *uvrf, void *fswband,
+                         void *cotdtp, void *cotdhp, void *cotdmp, void *cotdlp,
+                         void *cotntp, void *cotnhp, void *cotnmp, void *cotnlp,
+                         int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar);
+/* Debug / test hook: taug, taur Fortran (nlay,112,ncol) and the solar source ssi (112,ncol) [sfluxzen when
+ * isolvar < 0] as the reference's taumol_sw leaves them (SW/rrtmg_sw_taumol.F90:27); host pointers. */
+int geosrad_rrtmg_sw_taumol(geosrad_ctx *ctx, int ncol, int nlay, double scon, int isolvar,
+                            const void *play, const void *plev, const void *tlay,
+                            const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
+                            const void *bndscl, const void *indsolvar, void *taug, void *taur, void *ssi);
 
 /* ---- McICA ------------------------------------------------------------------------------------------
  * generate_stochastic_clouds (cloud_subcol_gen.F90:132): profile inputs Fortran (nlay,dncol) there; here

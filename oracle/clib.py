@@ -33,6 +33,7 @@ def lib():
         _lib = ctypes.CDLL(so)
         for sfx in ("f32", "f64"):
             getattr(_lib, f"oracle_lw_set_table_{sfx}").argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+            getattr(_lib, f"oracle_sw_set_table_{sfx}").argtypes = [ctypes.c_char_p, ctypes.c_void_p]
             getattr(_lib, f"oracle_kiss_to_real_{sfx}").restype = ctypes.c_float if sfx == "f32" else ctypes.c_double
             _load_tables(sfx)
             set_inhomogeneity(0, sfx)
@@ -64,6 +65,12 @@ def _load_tables(sfx):
         a = np.asfortranarray(a)
         flat = np.ascontiguousarray(a.ravel(order="F"))
         _keep[(sfx, name)] = flat
+        setter(name.encode(), _p(flat))
+    _, t = read_blob(os.path.join(DATA, f"rrtmg_sw_{kind}.grtb"))
+    setter = getattr(_lib, f"oracle_sw_set_table_{sfx}")
+    for name, a in t.items():
+        flat = np.ascontiguousarray(np.asfortranarray(a).ravel(order="F"))
+        _keep[(sfx, "sw_" + name)] = flat
         setter(name.encode(), _p(flat))
 
 
@@ -171,3 +178,70 @@ def zcw_lookup(cdf, sigma, prec="f32"):
     c = _c(cdf, dt); s = _c(sigma, dt); z = np.zeros_like(c)
     getattr(L, f"oracle_zcw_lookup_{sfx}")(ctypes.c_int(c.size), _p(c), _p(s), _p(z))
     return z
+
+
+# ---- RRTMG_SW ---------------------------------------------------------------------------------------------------
+NG_SW = 112
+SW_IN2D = ["h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr"]
+
+
+def sw_setcoef_taumol(inp, isolvar=0, svar=(1.0, 1.0, 1.0), svar_bnd=None, prec="f32"):
+    L = lib()
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    nlay, ncol = inp["play"].shape
+    T = lambda k: _c(np.asarray(inp[k], dtype=dt).T, dt)
+    a = [T(k) for k in ("play", "tlay", "plev", "h2ovmr", "co2vmr", "o3vmr", "ch4vmr", "o2vmr")]
+    sv = np.array(svar, dtype=dt)
+    sb = np.ones((3, 29), dtype=dt) if svar_bnd is None else _c(svar_bnd, dt)
+    taug = np.zeros((ncol, NG_SW, nlay), dtype=dt); taur = np.zeros_like(taug)
+    ssi = np.zeros((ncol, NG_SW), dtype=dt); sfz = np.zeros_like(ssi)
+    colmol = np.zeros((ncol, nlay), dtype=dt); lt = np.zeros(ncol, dtype=np.int32)
+    getattr(L, f"oracle_sw_setcoef_taumol_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(nlay), *[_p(x) for x in a], ctypes.c_int(isolvar),
+                                                   _p(sv), _p(sb), _p(taug), _p(taur), _p(ssi), _p(sfz), _p(colmol), _p(lt))
+    return dict(taug=taug, taur=taur, ssi=ssi, sfluxzen=sfz, colmol=colmol, laytrop=lt)
+
+
+def sw_cldprmc(cldy, ciwpmc, clwpmc, rei, rel, iceflag=3, liqflag=1, prec="f32"):
+    L = lib()
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    ncol, ng, nlay = cldy.shape
+    T = lambda x: _c(np.asarray(x, dtype=dt).T, dt)
+    out = [np.zeros((ncol, ng, nlay), dtype=dt) for _ in range(4)]
+    rc = getattr(L, f"oracle_sw_cldprmc_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(nlay), ctypes.c_int(iceflag), ctypes.c_int(liqflag),
+                                                _p(_c(cldy, np.int32)), _p(_c(ciwpmc, dt)), _p(_c(clwpmc, dt)), _p(T(rei)), _p(T(rel)),
+                                                *[_p(o) for o in out])
+    if rc:
+        raise RuntimeError(f"oracle_sw_cldprmc rc={rc}")
+    return out
+
+
+def rrtmg_sw(inp, prec="f32", scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqflg=1, iaer=0, normFlx=0, do_drfband=False,
+             indsolvar=None, bndscl=None):
+    """Full rrtmg_sw restatement (rrtmg_sw_rad.F90:68).  `inp` from synth.make_columns (needs coszen, albedos)."""
+    L = lib()
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    nlay, ncol = inp["play"].shape
+    c = lambda k: _c(inp[k], dt)
+    plev = c("plev")
+    aer = [(_c(inp[k], dt) if iaer == 10 else np.zeros(1, dtype=dt)) for k in ("tauaer_sw", "ssaaer_sw", "asmaer_sw")]
+    out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
+    for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf"):
+        out[k] = np.zeros(ncol, dtype=dt)
+    out["fswband"] = np.zeros((14, ncol), dtype=dt)
+    out["cot"] = np.zeros((8, ncol), dtype=dt)
+    out["drband"] = np.zeros((14, ncol), dtype=dt); out["dfband"] = np.zeros((14, ncol), dtype=dt)
+    out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
+    R = ctypes.c_float if sfx == "f32" else ctypes.c_double
+    ci = ctypes.c_int
+    ind = None if indsolvar is None else _p(np.array(indsolvar, dtype=dt))
+    bs = None if bndscl is None else _p(np.array(bndscl, dtype=dt))
+    rc = getattr(L, f"oracle_rrtmg_sw_{sfx}")(
+        ci(ncol), ci(nlay), R(scon), R(adjes), _p(c("coszen")), ci(isolvar), _p(c("play")), _p(plev), _p(c("tlay")),
+        _p(c("h2ovmr")), _p(c("o3vmr")), _p(c("co2vmr")), _p(c("ch4vmr")), _p(c("o2vmr")), ci(iceflg), ci(liqflg),
+        _p(c("cldf")), _p(c("ciwp")), _p(c("clwp")), _p(c("rei")), _p(c("rel")), ci(int(inp["dyofyr"])), _p(c("zm")), _p(c("alat")),
+        ci(iaer), _p(aer[0]), _p(aer[1]), _p(aer[2]), _p(c("asdir")), _p(c("asdif")), _p(c("aldir")), _p(c("aldif")),
+        ci(int(inp["cloudLM"])), ci(int(inp["cloudMH"])), ci(normFlx), _p(out["clearCounts"]), _p(out["swuflx"]), _p(out["swdflx"]),
+        _p(out["swuflxc"]), _p(out["swdflxc"]), _p(out["nirr"]), _p(out["nirf"]), _p(out["parr"]), _p(out["parf"]), _p(out["uvrr"]),
+        _p(out["uvrf"]), _p(out["fswband"]), _p(out["cot"]), ci(1 if do_drfband else 0), _p(out["drband"]), _p(out["dfband"]), bs, ind)
+    out["rc"] = rc
+    return out

@@ -1,5 +1,5 @@
-/* oracle/lw_oracle.c -- TEST INFRASTRUCTURE ONLY.  Builds the plain-C restatement in both precisions
- * (see lw_oracle_impl.h for the reference citations).  gcc -O2 -ffp-contract=off -shared -fPIC. */
+/* oracle/lw_oracle.c -- TEST INFRASTRUCTURE ONLY.  Builds the plain-C restatements (RRTMG_LW + McICA:
+ * lw_oracle_impl.h; RRTMG_SW: sw_oracle_impl.h) in both precisions (see those files for the reference citations).  gcc -O2 -ffp-contract=off -shared -fPIC. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -12,7 +12,9 @@
 #define POW powf
 #define FMOD fmodf
 #define FABS fabsf
+#define SQRT sqrtf
 #include "lw_oracle_impl.h"
+#include "sw_oracle_impl.h"
 #undef REAL
 #undef SFX
 #undef EXP
@@ -20,6 +22,9 @@
 #undef POW
 #undef FMOD
 #undef FABS
+#undef SQRT
+#undef F2
+#undef F3
 
 #define REAL double
 #define SFX(x) x##_f64
@@ -28,4 +33,6 @@
 #define POW pow
 #define FMOD fmod
 #define FABS fabs
+#define SQRT sqrt
 #include "lw_oracle_impl.h"
+#include "sw_oracle_impl.h"

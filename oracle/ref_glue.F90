@@ -495,3 +495,194 @@ subroutine ref_lw_cldprmc(ncol, nlay, cldy, ciwpmc, clwpmc, reice, reliq, icefla
    cloudy = merge(1, 0, lc)
    deallocate(l)
 end subroutine ref_lw_cldprmc
+
+
+! ---------------------------------------------------------------------------------------------
+! RRTMG_SW: only the parts of the reference that compile without ESMF/MAPL
+!   rrtmg_sw_ini   SW/src/rrtmg_sw_init.F90:49      setcoef_sw  SW/src/rrtmg_sw_setcoef.F90:23
+!   taumol_sw      SW/src/rrtmg_sw_taumol.F90:27    cldprmc_sw  SW/src/rrtmg_sw_cldprmc.F90:36
+! (SW = GEOSsolar_GridComp/RRTMG/rrtmg_sw/gcm_model)
+! ---------------------------------------------------------------------------------------------
+
+subroutine ref_sw_ini() bind(C, name='ref_sw_ini')
+   use rrtmg_sw_init, only: rrtmg_sw_ini
+   call rrtmg_sw_ini
+end subroutine
+
+subroutine ref_sw_dump_tables(cpath, n) bind(C, name='ref_sw_dump_tables')
+   use iso_c_binding
+   use ref_glue_io
+   implicit none
+   character(kind=c_char), intent(in) :: cpath(*)
+   integer(c_int), value :: n
+   call open_blob(cpath, n)
+   call dump_common
+   call d16; call d17; call d18; call d19; call d20; call d21; call d22
+   call d23; call d24; call d25; call d26; call d27; call d28; call d29
+   call close_blob
+contains
+   subroutine dump_common
+      use parrrsw, only: nbndsw, ngptsw, jpb1, jpb2, rrsw_scon
+      use rrsw_wvn, only: ng, nspa, nspb, ngb, ngs, ngc, icxa, wavenum1, wavenum2
+      use rrsw_ref, only: pref, preflog, tref
+      use rrsw_con, only: oneminus, grav, avogad, pi
+      use rrsw_tbl, only: od_lo
+      use rrsw_cld, only: extliq1, ssaliq1, asyliq1, extice2, ssaice2, asyice2, extice3, ssaice3, asyice3, fdlice3, &
+         extice4, ssaice4, asyice4, abari, bbari, cbari, dbari, ebari, fbari
+      use NRLSSI2, only: Iint, Fint, Sint, Mg_avg, Mg_0, SB_avg, SB_0
+      call put('nbndsw', nbndsw); call put('ngptsw', ngptsw); call put('jpb1', jpb1); call put('jpb2', jpb2)
+      call put('ng', ng); call put('nspa', nspa); call put('nspb', nspb); call put('ngb', ngb); call put('ngs', ngs)
+      call put('ngc', ngc); call put('icxa', icxa); call put('wavenum1', wavenum1); call put('wavenum2', wavenum2)
+      call put('pref', pref); call put('preflog', preflog); call put('tref', tref)
+      call put('oneminus', oneminus); call put('grav', grav); call put('avogad', avogad); call put('pi', pi)
+      call put('od_lo', od_lo); call put('rrsw_scon', rrsw_scon)
+      call put('extliq1', extliq1); call put('ssaliq1', ssaliq1); call put('asyliq1', asyliq1)
+      call put('extice2', extice2); call put('ssaice2', ssaice2); call put('asyice2', asyice2)
+      call put('extice3', extice3); call put('ssaice3', ssaice3); call put('asyice3', asyice3); call put('fdlice3', fdlice3)
+      call put('extice4', extice4); call put('ssaice4', ssaice4); call put('asyice4', asyice4)
+      call put('abari', abari); call put('bbari', bbari); call put('cbari', cbari); call put('dbari', dbari)
+      call put('ebari', ebari); call put('fbari', fbari)
+      call put('Iint', Iint); call put('Fint', Fint); call put('Sint', Sint)
+      call put('Mg_avg', Mg_avg); call put('Mg_0', Mg_0); call put('SB_avg', SB_avg); call put('SB_0', SB_0)
+   end subroutine
+   subroutine d16
+      use rrsw_kg16
+      call put('b16_absa', absa); call put('b16_absb', absb); call put('b16_selfref', selfref); call put('b16_forref', forref)
+      call put('b16_sfluxref', sfluxref); call put('b16_irradnce', irradnce); call put('b16_facbrght', facbrght)
+      call put('b16_snsptdrk', snsptdrk); call put('b16_rayl', rayl)
+   end subroutine
+   subroutine d17
+      use rrsw_kg17
+      call put('b17_absa', absa); call put('b17_absb', absb); call put('b17_selfref', selfref); call put('b17_forref', forref)
+      call put('b17_sfluxref', sfluxref); call put('b17_irradnce', irradnce); call put('b17_facbrght', facbrght)
+      call put('b17_snsptdrk', snsptdrk); call put('b17_rayl', rayl)
+   end subroutine
+   subroutine d18
+      use rrsw_kg18
+      call put('b18_absa', absa); call put('b18_absb', absb); call put('b18_selfref', selfref); call put('b18_forref', forref)
+      call put('b18_sfluxref', sfluxref); call put('b18_irradnce', irradnce); call put('b18_facbrght', facbrght)
+      call put('b18_snsptdrk', snsptdrk); call put('b18_rayl', rayl)
+   end subroutine
+   subroutine d19
+      use rrsw_kg19
+      call put('b19_absa', absa); call put('b19_absb', absb); call put('b19_selfref', selfref); call put('b19_forref', forref)
+      call put('b19_sfluxref', sfluxref); call put('b19_irradnce', irradnce); call put('b19_facbrght', facbrght)
+      call put('b19_snsptdrk', snsptdrk); call put('b19_rayl', rayl)
+   end subroutine
+   subroutine d20
+      use rrsw_kg20
+      call put('b20_absa', absa); call put('b20_absb', absb); call put('b20_selfref', selfref); call put('b20_forref', forref)
+      call put('b20_sfluxref', sfluxref); call put('b20_irradnce', irradnce); call put('b20_facbrght', facbrght)
+      call put('b20_snsptdrk', snsptdrk); call put('b20_rayl', rayl); call put('b20_absch4', absch4)
+   end subroutine
+   subroutine d21
+      use rrsw_kg21
+      call put('b21_absa', absa); call put('b21_absb', absb); call put('b21_selfref', selfref); call put('b21_forref', forref)
+      call put('b21_sfluxref', sfluxref); call put('b21_irradnce', irradnce); call put('b21_facbrght', facbrght)
+      call put('b21_snsptdrk', snsptdrk); call put('b21_rayl', rayl)
+   end subroutine
+   subroutine d22
+      use rrsw_kg22
+      call put('b22_absa', absa); call put('b22_absb', absb); call put('b22_selfref', selfref); call put('b22_forref', forref)
+      call put('b22_sfluxref', sfluxref); call put('b22_irradnce', irradnce); call put('b22_facbrght', facbrght)
+      call put('b22_snsptdrk', snsptdrk); call put('b22_rayl', rayl)
+   end subroutine
+   subroutine d23
+      use rrsw_kg23
+      call put('b23_absa', absa); call put('b23_selfref', selfref); call put('b23_forref', forref)
+      call put('b23_sfluxref', sfluxref); call put('b23_irradnce', irradnce); call put('b23_facbrght', facbrght)
+      call put('b23_snsptdrk', snsptdrk); call put('b23_rayl', rayl)
+   end subroutine
+   subroutine d24
+      use rrsw_kg24
+      call put('b24_absa', absa); call put('b24_absb', absb); call put('b24_selfref', selfref); call put('b24_forref', forref)
+      call put('b24_sfluxref', sfluxref); call put('b24_irradnce', irradnce); call put('b24_facbrght', facbrght)
+      call put('b24_snsptdrk', snsptdrk); call put('b24_abso3a', abso3a); call put('b24_abso3b', abso3b)
+      call put('b24_rayla', rayla); call put('b24_raylb', raylb)
+   end subroutine
+   subroutine d25
+      use rrsw_kg25
+      call put('b25_absa', absa); call put('b25_sfluxref', sfluxref); call put('b25_irradnce', irradnce)
+      call put('b25_facbrght', facbrght); call put('b25_snsptdrk', snsptdrk); call put('b25_abso3a', abso3a)
+      call put('b25_abso3b', abso3b); call put('b25_rayl', rayl)
+   end subroutine
+   subroutine d26
+      use rrsw_kg26
+      call put('b26_sfluxref', sfluxref); call put('b26_irradnce', irradnce); call put('b26_facbrght', facbrght)
+      call put('b26_snsptdrk', snsptdrk); call put('b26_rayl', rayl)
+   end subroutine
+   subroutine d27
+      use rrsw_kg27
+      call put('b27_absa', absa); call put('b27_absb', absb); call put('b27_sfluxref', sfluxref); call put('b27_irradnce', irradnce)
+      call put('b27_facbrght', facbrght); call put('b27_snsptdrk', snsptdrk); call put('b27_rayl', rayl)
+   end subroutine
+   subroutine d28
+      use rrsw_kg28
+      call put('b28_absa', absa); call put('b28_absb', absb); call put('b28_sfluxref', sfluxref); call put('b28_irradnce', irradnce)
+      call put('b28_facbrght', facbrght); call put('b28_snsptdrk', snsptdrk); call put('b28_rayl', rayl)
+   end subroutine
+   subroutine d29
+      use rrsw_kg29
+      call put('b29_absa', absa); call put('b29_absb', absb); call put('b29_selfref', selfref); call put('b29_forref', forref)
+      call put('b29_sfluxref', sfluxref); call put('b29_irradnce', irradnce); call put('b29_facbrght', facbrght)
+      call put('b29_snsptdrk', snsptdrk); call put('b29_rayl', rayl); call put('b29_absh2o', absh2o); call put('b29_absco2', absco2)
+   end subroutine
+end subroutine ref_sw_dump_tables
+
+! setcoef_sw + taumol_sw on columns given in the reference's partition layout (nlay,ncol).  The dry-air /
+! gas column amounts that rrtmg_sw_sub forms inline before setcoef_sw (rrtmg_sw_rad.F90:1370-1387; that file
+! itself needs MAPL) are formed here the same way.
+subroutine ref_sw_setcoef_taumol(ncol, nlay, play, tlay, plev, h2ovmr, co2vmr, o3vmr, ch4vmr, o2vmr, isolvar, svar, svar_bnd, &
+      taug, taur, ssi, sfluxzen, o_colmol, o_laytrop) bind(C, name='ref_sw_setcoef_taumol')
+   use iso_c_binding
+   use parrrsw, only: ngptsw, jpband
+   use rrsw_con, only: grav, avogad
+   use rrtmg_sw_setcoef, only: setcoef_sw
+   use rrtmg_sw_taumol, only: taumol_sw
+   implicit none
+   integer(c_int), value :: ncol, nlay, isolvar
+   real, intent(in) :: play(nlay,ncol), tlay(nlay,ncol), plev(nlay+1,ncol)
+   real, intent(in), dimension(nlay,ncol) :: h2ovmr, co2vmr, o3vmr, ch4vmr, o2vmr
+   real, intent(in) :: svar(3), svar_bnd(jpband,3)
+   real, intent(out) :: taug(nlay,ngptsw,ncol), taur(nlay,ngptsw,ncol), ssi(ngptsw,ncol), sfluxzen(ngptsw,ncol)
+   real, intent(out) :: o_colmol(nlay,ncol)
+   integer(c_int), intent(out) :: o_laytrop(ncol)
+   real, parameter :: amd = 28.9660, amw = 18.0160
+   real, dimension(nlay,ncol) :: coldry, colh2o, colco2, colo3, colch4, colo2, colmol, fac00, fac01, fac10, fac11, &
+      selffac, selffrac, forfac, forfrac
+   integer, dimension(nlay,ncol) :: jp, jt, jt1, indself, indfor
+   integer :: laytrop(ncol), icol, ilay
+   colh2o = h2ovmr; colco2 = co2vmr; colo3 = o3vmr; colch4 = ch4vmr; colo2 = o2vmr
+   do icol = 1,ncol
+      do ilay = 1,nlay
+         coldry(ilay,icol) = (plev(ilay,icol)-plev(ilay+1,icol)) * 1.e3 * avogad / &
+            (1.e2 * grav * ((1.-colh2o(ilay,icol)) * amd + colh2o(ilay,icol) * amw) * &
+            (1. + colh2o(ilay,icol)))
+      enddo
+   enddo
+   colh2o = coldry * colh2o; colco2 = coldry * colco2; colo3 = coldry * colo3; colch4 = coldry * colch4; colo2 = coldry * colo2
+   call setcoef_sw(ncol, ncol, nlay, play, tlay, coldry, colch4, colco2, colh2o, colmol, colo2, colo3, &
+      laytrop, jp, jt, jt1, fac00, fac01, fac10, fac11, selffac, selffrac, indself, forfac, forfrac, indfor)
+   ssi = 0.; sfluxzen = 0.
+   call taumol_sw(ncol, ncol, nlay, colh2o, colco2, colch4, colo2, colo3, colmol, laytrop, jp, jt, jt1, &
+      fac00, fac01, fac10, fac11, selffac, selffrac, indself, forfac, forfrac, indfor, &
+      isolvar, svar(1), svar(2), svar(3), svar_bnd(:,1), svar_bnd(:,2), svar_bnd(:,3), ssi, sfluxzen, taug, taur)
+   o_colmol = colmol; o_laytrop = laytrop
+end subroutine ref_sw_setcoef_taumol
+
+subroutine ref_sw_cldprmc(ncol, nlay, iceflag, liqflag, cldy, ciwpmc, clwpmc, rei, rel, taormc, taucmc, ssacmc, asmcmc) &
+      bind(C, name='ref_sw_cldprmc')
+   use iso_c_binding
+   use parrrsw, only: ngptsw
+   use rrtmg_sw_cldprmc, only: cldprmc_sw
+   implicit none
+   integer(c_int), value :: ncol, nlay, iceflag, liqflag
+   integer(c_int), intent(in) :: cldy(nlay,ngptsw,ncol)
+   real, intent(in) :: ciwpmc(nlay,ngptsw,ncol), clwpmc(nlay,ngptsw,ncol), rei(nlay,ncol), rel(nlay,ncol)
+   real, intent(out), dimension(nlay,ngptsw,ncol) :: taormc, taucmc, ssacmc, asmcmc
+   logical, allocatable :: l(:,:,:)
+   allocate(l(nlay,ngptsw,ncol))
+   l = (cldy /= 0)
+   call cldprmc_sw(ncol, ncol, nlay, iceflag, liqflag, l, ciwpmc, clwpmc, rei, rel, taormc, taucmc, ssacmc, asmcmc)
+   deallocate(l)
+end subroutine ref_sw_cldprmc

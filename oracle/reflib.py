@@ -25,6 +25,7 @@ def lib(kind="r4"):
     if kind not in _libs:
         L = ctypes.CDLL(os.path.join(HERE, "_ref", f"libref_{kind}.so"))
         L.ref_lw_ini()
+        L.ref_sw_ini()
         _libs[kind] = L
     return _libs[kind]
 
@@ -161,3 +162,53 @@ def dump_lw_tables(path, kind="r4"):
 def dump_xcw(path, ih, kind="r4"):
     p = os.fsencode(path)
     lib(kind).ref_dump_xcw(p, ctypes.c_int(len(p)), ctypes.c_int(ih))
+
+
+# ---- RRTMG_SW parts (setcoef_sw / taumol_sw / cldprmc_sw: the reference files free of ESMF/MAPL) -------------------
+NG_SW = 112
+
+
+def dump_sw_tables(path, kind="r4"):
+    p = os.fsencode(path)
+    lib(kind).ref_sw_dump_tables(p, ctypes.c_int(len(p)))
+
+
+def sw_setcoef_taumol(inp, isolvar=0, svar=(1.0, 1.0, 1.0), svar_bnd=None, kind="r4"):
+    """setcoef_sw + taumol_sw.  Returns taug,taur numpy (ncol,112,nlay); ssi,sfluxzen (ncol,112); colmol (ncol,nlay)."""
+    L = lib(kind)
+    dt = dtype_of(kind)
+    nlay, ncol = inp["play"].shape
+    T = lambda k: _c(np.asarray(inp[k], dtype=dt).T, dt)
+    play, tlay, plev = T("play"), T("tlay"), T("plev")
+    g = [T(k) for k in ("h2ovmr", "co2vmr", "o3vmr", "ch4vmr", "o2vmr")]
+    sv = np.array(svar, dtype=dt)
+    sb = np.ones((3, 29), dtype=dt) if svar_bnd is None else _c(svar_bnd, dt)
+    taug = np.zeros((ncol, NG_SW, nlay), dtype=dt); taur = np.zeros_like(taug)
+    ssi = np.zeros((ncol, NG_SW), dtype=dt); sfz = np.zeros_like(ssi)
+    colmol = np.zeros((ncol, nlay), dtype=dt); lt = np.zeros(ncol, dtype=np.int32)
+    ci = ctypes.c_int
+    L.ref_sw_setcoef_taumol(ci(ncol), ci(nlay), _p(play), _p(tlay), _p(plev), *[_p(x) for x in g], ci(isolvar), _p(sv), _p(sb),
+                            _p(taug), _p(taur), _p(ssi), _p(sfz), _p(colmol), _p(lt))
+    return dict(taug=taug, taur=taur, ssi=ssi, sfluxzen=sfz, colmol=colmol, laytrop=lt)
+
+
+def sw_cldprmc(cldy, ciwpmc, clwpmc, rei, rel, iceflag=3, liqflag=1, kind="r4"):
+    """cldprmc_sw.  cldy etc. numpy (ncol,112,nlay); rei/rel numpy (nlay,ncol) [API layout].  Returns
+    taormc,taucmc,ssacmc,asmcmc numpy (ncol,112,nlay)."""
+    L = lib(kind)
+    dt = dtype_of(kind)
+    ncol, ng, nlay = cldy.shape
+    T = lambda x: _c(np.asarray(x, dtype=dt).T, dt)
+    out = [np.zeros((ncol, ng, nlay), dtype=dt) for _ in range(4)]
+    ci = ctypes.c_int
+    reiT, relT = T(rei), T(rel)
+    # the reference keeps ~8 automatic (nlay,ngptsw,pncol) arrays on the stack: call it in small partitions, as
+    # rrtmg_sw itself does (pncol = 2 by default, rrtmg_sw_rad.F90:386-390)
+    for c0 in range(0, ncol, 4):
+        c1 = min(ncol, c0 + 4)
+        o = [np.zeros((c1 - c0, ng, nlay), dtype=dt) for _ in range(4)]
+        L.ref_sw_cldprmc(ci(c1 - c0), ci(nlay), ci(iceflag), ci(liqflag), _p(_c(cldy[c0:c1], np.int32)), _p(_c(ciwpmc[c0:c1], dt)),
+                         _p(_c(clwpmc[c0:c1], dt)), _p(_c(reiT[c0:c1], dt)), _p(_c(relT[c0:c1], dt)), *[_p(x) for x in o])
+        for k in range(4):
+            out[k][c0:c1] = o[k]
+    return out
