@@ -25,6 +25,70 @@ CASES = {
 }
 
 
+SW_CASES = {
+    # name: (make_columns kwargs, ih)
+    "sw_stages_72": (dict(ncol=6, nlay=72, aerosol=True, cloudy_frac=0.9, start=300), 1),
+    "sw_stages_137": (dict(ncol=4, nlay=137, aerosol=False, cloudy_frac=0.9, start=7000), 2),
+}
+SW_SCON = 1361.0
+SW_INDSOLVAR = (0.1580, 80.0)
+SW_BNDSCL = np.linspace(0.9, 1.1, 14)
+
+
+def sw_solar_scalars(isolvar, dt, blob, scon=SW_SCON, indsolvar=SW_INDSOLVAR, bndscl=SW_BNDSCL):
+    """svar (f,s,i) and svar_bnd(3,29) exactly as the driver forms them (SW/rrtmg_sw_rad.F90:893-1127) in precision dt."""
+    R = dt
+    Fint, Sint, Iint = R(blob["Fint"]), R(blob["Sint"]), R(blob["Iint"])
+    svar = [R(1), R(1), R(1)]
+    sb = np.ones((3, 29), dtype=dt)
+    scon = R(scon)
+    scon_int = R(R(Fint + Sint) + Iint)
+    if isolvar == 0:
+        svar = [R(scon / scon_int)] * 3
+    elif isolvar == 2:
+        f = R(R(R(indsolvar[0]) - R(blob["Mg_0"])) / R(R(blob["Mg_avg"]) - R(blob["Mg_0"])))
+        s_ = R(R(R(indsolvar[1]) - R(blob["SB_0"])) / R(R(blob["SB_avg"]) - R(blob["SB_0"])))
+        i_ = R(R(scon - R(R(f * Fint) + R(s_ * Sint))) / Iint)
+        svar = [f, s_, i_]
+    elif isolvar == 3:
+        for b in range(16, 30):
+            sb[:, b - 1] = R(R(scon / scon_int) * R(bndscl[b - 16]))
+    return svar, sb
+
+
+def main_sw():
+    from geosradiation_gridcomp_amd.tableblob import read_blob
+    from geosradiation_gridcomp_amd import _lib
+    for name, (kw, ih) in SW_CASES.items():
+        inp = synth.make_columns(**kw)
+        out = {"kw_json": np.array(repr(kw)), "ih": np.int32(ih), "scon": np.float64(SW_SCON), "indsolvar": np.array(SW_INDSOLVAR),
+               "bndscl": SW_BNDSCL}
+        for kind in ("r4", "r8"):
+            dt = reflib.dtype_of(kind)
+            _, blob = read_blob(os.path.join(_lib.DATA, f"rrtmg_sw_{kind}.grtb"))
+            # setcoef_sw + taumol_sw: optical depths once, solar source for every isolvar GEOS accepts
+            for isol in (0, -1, 2, 3):
+                svar, sb = sw_solar_scalars(isol, dt, blob)
+                t = reflib.sw_setcoef_taumol(inp, isolvar=isol, svar=svar, svar_bnd=sb, kind=kind)
+                if isol == 0:
+                    out[f"{kind}_taug"] = t["taug"]; out[f"{kind}_taur"] = t["taur"]; out[f"{kind}_laytrop"] = t["laytrop"]
+                out[f"{kind}_ssi_isolvar{isol}".replace("-", "m")] = t["sfluxzen"] if isol < 0 else t["ssi"]
+            # McICA sub-columns with the SW seeding, then cldprmc_sw for every ice parameterisation (first 2 columns)
+            reflib.set_inhomogeneity(ih, kind)
+            n2 = 2
+            sub = {k: (v[..., :n2] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == kw["ncol"] else v) for k, v in inp.items()}
+            cl, ci_s, cl_s = reflib.mcica(sub["zm"], sub["alat"], int(inp["dyofyr"]), sub["play"], sub["cldf"], sub["ciwp"], sub["clwp"], 112,
+                                          seed_order=(4, 3, 2, 1), kind=kind)
+            reflib.set_inhomogeneity(0, kind)
+            out[f"{kind}_mc_cldy"] = cl.astype(np.uint8); out[f"{kind}_mc_ciwp"] = ci_s; out[f"{kind}_mc_clwp"] = cl_s
+            for iceflag in (1, 2, 3, 4):
+                r = reflib.sw_cldprmc(cl, ci_s, cl_s, sub["rei"], sub["rel"], iceflag=iceflag, kind=kind)
+                for nm, a in zip(("taormc", "taucmc", "ssacmc", "asmcmc"), r):
+                    out[f"{kind}_ice{iceflag}_{nm}"] = a
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, os.path.getsize(os.path.join(HERE, name + ".npz")))
+
+
 def main():
     for name, (kw, ih, bo) in CASES.items():
         inp = synth.make_columns(**kw)
@@ -55,4 +119,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    if "sw" not in sys.argv[1:]:
+        main()
+    if "lw" not in sys.argv[1:]:
+        main_sw()
