@@ -3,15 +3,20 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch of synthetic columns resident in HBM.  Workload at
-N = 1 is BASELINE.json configs[1]: 100 000 clear-sky columns, 72 layers, RRTMG_LW (140 g-points).
-Columns shard embarrassingly: every rank owns its own 100 000-column batch (weak scaling), there is no
-data-path collective; the only collectives are the timing barrier and the max-over-ranks of the time.
+A "step" is one pass of the hot path over one batch of synthetic columns resident in HBM.  BASELINE.json's
+metric is "columns/sec (LW+SW, 72 layers)"; it is quoted on configs[3] (C360 tile = 777 600 columns over 8
+GPUs, full LW+SW with McICA clouds + aerosols).  The default workload is that configuration's per-GPU share:
+97 200 columns/GPU, 72 layers, RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points, every column lit), 60 % of
+the columns cloudy (McICA, ih = 1), aerosols on -- so the driver's N = 8 weak-scaling run IS configs[3].
+`--scheme lw --cloudy 0 --no-aerosol --ncol 100000` reproduces configs[1] (RRTMG_LW clear-sky).
+Columns shard embarrassingly: every rank owns its own batch (weak scaling), there is no data-path
+collective; the only collectives are the timing barrier and the max-over-ranks of the time.
 
 One JSON line is printed by rank 0 (contract in the task statement), with
-  roofline     : dominant kernel (k_lw_bands) timed live with HIP events on the launch stream
-  cpu_baseline : the reference's own Fortran (oracle/_ref, kind "reference") -- or the plain-C oracle
-                 (kind "port") when _ref is absent -- timed on the host cores on a bounded sample.
+  roofline     : the kernel with the largest share of the step, timed live with HIP events on the launch stream
+  cpu_baseline : RRTMG_LW = the reference's own Fortran (oracle/_ref); RRTMG_SW = the plain-C oracle (the
+                 reference's rrtmg_sw driver needs ESMF/MAPL and cannot be built here) -- timed on the host
+                 cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -37,6 +42,18 @@ def algorithmic_bytes_lw(nlay, real_bytes, aerosol):
     return (n_in + n_out) * real_bytes
 
 
+def algorithmic_bytes_sw(nlay, real_bytes, aerosol):
+    """17 452 B/column with the 3 aerosol arrays, 5 356 without, fp32 @72 layers"""
+    n_in = 13 * nlay + (nlay + 1) + 6 + (3 * 14 * nlay if aerosol else 0)
+    n_out = 4 * (nlay + 1) + 6 + 14 + 8 + 4
+    return (n_in + n_out) * real_bytes
+
+
+SW_IN = ["coszen", "asdir", "asdif", "aldir", "aldif"]
+SW_AER = ["tauaer_sw", "ssaaer_sw", "asmaer_sw"]
+SW_OUT1 = ["nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "cotdtp", "cotdhp", "cotdmp", "cotdlp", "cotntp", "cotnhp", "cotnmp", "cotnlp"]
+
+
 def shard_start(rank, ncol_per_gpu):
     """first global column of a rank's batch: contiguous blocks, rank-major (no overlap, no exchange)"""
     return rank * ncol_per_gpu
@@ -54,40 +71,58 @@ def max_over_ranks(seconds, world, device):
 
 
 def _cpu_worker(args):
-    kind, start, ncol, nlay = args
+    lw_kind, scheme, start, ncol, nlay, cloudy, aerosol = args
     from geosradiation_gridcomp_amd import synth
-    inp = synth.make_columns(ncol, nlay, start=start)
-    if kind == "reference":
-        from oracle import reflib
-        reflib.lib("r4")
-        t = time.perf_counter()
-        reflib.rrtmg_lw(inp, "r4", psize=4)        # GEOS default RRTMGLW_PARTITION_SIZE=4 (IRR:3185)
-        return time.perf_counter() - t
     from oracle import clib
-    clib.lib()
-    t = time.perf_counter()
-    clib.rrtmg_lw(inp, "f32")
-    return time.perf_counter() - t
+    inp = synth.make_columns(ncol, nlay, start=start, cloudy_frac=cloudy, aerosol=aerosol)
+    ih = 1 if cloudy > 0 else 0
+    t_lw = t_sw = 0.0
+    if "lw" in scheme:
+        if lw_kind == "reference":
+            from oracle import reflib
+            reflib.lib("r4"); reflib.set_inhomogeneity(ih, "r4")
+            t = time.perf_counter()
+            reflib.rrtmg_lw(inp, "r4", psize=4)        # GEOS default RRTMGLW_PARTITION_SIZE=4 (IRR:3185)
+            t_lw = time.perf_counter() - t
+        else:
+            clib.lib(); clib.set_inhomogeneity(ih, "f32")
+            t = time.perf_counter()
+            clib.rrtmg_lw(inp, "f32")
+            t_lw = time.perf_counter() - t
+    if "sw" in scheme:
+        clib.lib(); clib.set_inhomogeneity(ih, "f32")
+        t = time.perf_counter()
+        clib.rrtmg_sw(inp, prec="f32", iaer=10 if aerosol else 0, normFlx=1)
+        t_sw = time.perf_counter() - t
+    return t_lw, t_sw
 
 
-def cpu_baseline(nlay, per_core=8192):
-    """Time the CPU reference on all host cores (one process per core: the reference keeps module state)."""
+def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
+    """Time the CPU baseline on all host cores (one process per core: the reference keeps module state)."""
     import multiprocessing as mp
     from oracle import reflib
-    kind = "reference" if reflib.available("r4") else "port"
+    lw_kind = "reference" if reflib.available("r4") else "port"
+    kind = lw_kind if scheme == "lw" else "port"
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     ctx = mp.get_context("fork")
-    jobs = [(kind, 10_000_000 + i * per_core, per_core, nlay) for i in range(cores)]
+    jobs = [(lw_kind, scheme, 10_000_000 + i * per_core, per_core, nlay, cloudy, aerosol) for i in range(cores)]
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         per = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
-    busy = max(per)
+    busy = max(a + b for a, b in per)
+    lw_s = sum(a for a, _ in per) / len(per); sw_s = sum(b for _, b in per) / len(per)
+    legs = []
+    if "lw" in scheme:
+        legs.append(f"rrtmg_lw = {'reference Fortran (oracle/_ref), psize=4' if lw_kind == 'reference' else 'plain-C oracle'} "
+                    f"{per_core / lw_s:.0f} col/s/core")
+    if "sw" in scheme:
+        legs.append(f"rrtmg_sw = plain-C oracle (reference driver needs ESMF/MAPL: unbuildable here) {per_core / sw_s:.0f} col/s/core")
     return {"value": cores * per_core / busy, "unit": "columns/s", "cores": cores, "kind": kind,
-            "sample": f"{cores} processes x {per_core} clear-sky 72-layer columns of the bench workload, rrtmg_lw psize=4, "
-                      f"slowest process {busy:.2f} s (pool wall {wall:.2f} s incl. input generation)",
-            "single_core_columns_per_s": per_core / (sum(per) / len(per))}
+            "sample": f"{cores} processes x {per_core} columns of the bench workload ({nlay} layers, cloudy fraction {cloudy}, "
+                      f"aerosol {aerosol}); " + "; ".join(legs) + f"; slowest process {busy:.2f} s (pool wall {wall:.2f} s incl. input generation)",
+            "single_core_columns_per_s": per_core / (lw_s + sw_s)}
 
 
 def main():
@@ -95,13 +130,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ncol", type=int, default=100_000, help="columns per GPU")
+    ap.add_argument("--ncol", type=int, default=97_200, help="columns per GPU (default: C360 tile / 8)")
     ap.add_argument("--nlay", type=int, default=72)
     ap.add_argument("--real", type=int, default=4, choices=[4, 8], help="arithmetic type: 4 = the reference's default real")
-    ap.add_argument("--cloudy", type=float, default=0.0, help="fraction of cloudy columns (0 = configs[1] clear-sky)")
-    ap.add_argument("--aerosol", action="store_true")
+    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw"])
+    ap.add_argument("--cloudy", type=float, default=0.6, help="fraction of cloudy columns (0 = clear-sky)")
+    ap.add_argument("--no-aerosol", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     a = ap.parse_args()
+    aerosol = not a.no_aerosol
+    do_lw, do_sw = "lw" in a.scheme, "sw" in a.scheme
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,7 +147,7 @@ def main():
 
     cpu = None
     if rank == 0 and a.gpus == 1 and not a.no_cpu:
-        cpu = cpu_baseline(a.nlay)              # before any GPU initialisation in this process (fork pool)
+        cpu = cpu_baseline(a.nlay, a.scheme, a.cloudy, aerosol)     # before any GPU initialisation in this process (fork pool)
 
     import torch
     import torch.distributed as dist
@@ -124,21 +162,31 @@ def main():
 
     # ---- inputs resident in HBM -------------------------------------------------------------------------------
     ncol, nlay = a.ncol, a.nlay
-    inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=a.aerosol)
+    inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
     tdt = torch.float32 if a.real == 4 else torch.float64
-    names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + LW_IN2D + (["tauaer"] if a.aerosol else [])
+    names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + LW_IN2D + (["tauaer"] if aerosol else [])
+    if do_sw:
+        names += SW_IN + (SW_AER if aerosol else [])
     d = {k: torch.from_numpy(np.ascontiguousarray(inp[k])).to(dev, dtype=tdt) for k in names}
-    for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs"):
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs", "swuflx", "swdflx", "swuflxc", "swdflxc"):
         d[k] = torch.zeros((nlay + 1, ncol), device=dev, dtype=tdt)
+    for k in SW_OUT1:
+        d[k] = torch.zeros(ncol, device=dev, dtype=tdt)
+    d["fswband"] = torch.zeros((14, ncol), device=dev, dtype=tdt)
     d["clearCounts"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
+    d["clearCounts_sw"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
     ptr = {k: v.data_ptr() for k, v in d.items()}
 
     ctx = Context(a.real, device=local_rank)
     ctx.set_inhomogeneity(1 if a.cloudy > 0 else 0)          # GEOS default RAD_CONDENSATE_INHOMOGENEITY=1
     stream = torch.cuda.current_stream().cuda_stream
+    doy, lm, mh = int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"])
 
     def step():
-        ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]))
+        if do_lw:
+            ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
+        if do_sw:      # GEOS call: isolvar 0 scaled to scon, normalised fluxes (SOL:6230-6300)
+            ctx.rrtmg_sw_dev(stream, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 10 if aerosol else 0, lm, mh, normFlx=1)
 
     for _ in range(a.warmup):
         step()
@@ -163,25 +211,39 @@ def main():
     if rank == 0:
         total_cols = world * ncol * a.steps
         value = total_cols / elapsed
-        ms, n = prof["k_lw_bands"]
-        abytes = algorithmic_bytes_lw(nlay, a.real, a.aerosol)
+        # dominant kernel = largest total time; its algorithmic bytes are those of the solver it belongs to
+        # (compulsory bytes at the solver API, every input read once + every output written once)
+        cand = {k: v for k, v in prof.items() if k in ("k_lw_bands", "k_sw_bands") and v[1] > 0}
+        kname = max(cand, key=lambda k: cand[k][0])
+        ms, n = prof[kname]
+        launches_per_step = n / a.steps
+        abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(nlay, a.real, aerosol)
         per_launch_s = (ms / max(n, 1)) * 1e-3
-        achieved = abytes * ncol / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        achieved = abytes * (ncol / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
+                   "sw": "RRTMG_SW (112 g-points)"}[a.scheme]
+        if a.scheme == "lw" and a.cloudy == 0 and not aerosol:
+            wl = "BASELINE configs[1]: %d columns/GPU, %d layers, RRTMG_LW 140 g-points clear-sky" % (ncol, nlay)
+        else:
+            wl = ("%sper-GPU share: %d columns/GPU, %d layers, %s, McICA clouds on %.0f %% of the columns (ih=1), aerosols %s, "
+                  "every column lit" % ("BASELINE configs[3] (C360 tile / 8 GPUs) " if ncol == 97_200 and a.scheme == "lwsw" else "",
+                                         ncol, nlay, schemes, 100 * a.cloudy, "on" if aerosol else "off"))
         out = {
-            "metric": "columns/sec", "value": value, "unit": "columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": "columns/sec (LW+SW, 72 layers)" if a.scheme == "lwsw" else "columns/sec", "value": value, "unit": "columns/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.real == 4 else "f64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: %d columns/GPU, %d layers, RRTMG_LW 140 g-points clear-sky" % (ncol, nlay))
-                       if a.cloudy == 0 and not a.aerosol else
-                       ("%d columns/GPU, %d layers, RRTMG_LW + McICA (ih=1), cloudy fraction %.2f, aerosol %s" % (ncol, nlay, a.cloudy, a.aerosol)),
-                       "schemes": "RRTMG_LW (SW / Chou paths: later rounds)", "columns_per_gpu": ncol, "layers": nlay,
+            "config": {"workload": wl, "schemes": schemes + " (Chou irrad/sorad: later rounds)", "columns_per_gpu": ncol, "layers": nlay,
+                       "cloudy_fraction": a.cloudy, "aerosol": aerosol,
                        "sharding": "independent column batches per GPU, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_lw_bands", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
+                         "columns_per_launch": ncol / launches_per_step,
                          "note": "fused k-distribution + two-stream sweep is FP32/latency bound (~170 FLOP per algorithmic byte, "
-                                 "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small"},
-            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
+                                 "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small; `traffic` (PMC) is in "
+                                 "profiles/"},
+            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
