@@ -5,7 +5,7 @@ module geosrad_c
    use iso_fortran_env, only : error_unit
    implicit none
    private
-   public :: geosrad_ctx_handle, geosrad_fail, geosrad_data_path
+   public :: geosrad_ctx_handle, geosrad_fail, geosrad_warn, geosrad_data_path, geosrad_load_tables_sw, geosrad_rrtmg_sw
    public :: geosrad_create, geosrad_destroy, geosrad_last_error, geosrad_load_tables_lw, geosrad_load_inhomogeneity
    public :: geosrad_set_corr_lengths, geosrad_rrtmg_lw, geosrad_mcica, geosrad_clearcounts
 
@@ -23,6 +23,25 @@ module geosrad_c
       end function
       integer(c_int) function geosrad_load_tables_lw(ctx, path) bind(C, name='geosrad_load_tables_lw')
          import; type(c_ptr), value :: ctx; character(kind=c_char), intent(in) :: path(*)
+      end function
+      integer(c_int) function geosrad_load_tables_sw(ctx, path) bind(C, name='geosrad_load_tables_sw')
+         import :: c_int, c_ptr, c_char
+         type(c_ptr), value :: ctx
+         character(kind=c_char) :: path(*)
+      end function
+      integer(c_int) function geosrad_rrtmg_sw(ctx, rpart, ncol, nlay, scon, adjes, coszen, isolvar, play, plev, tlay, &
+            h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr, iceflgsw, liqflgsw, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, &
+            iaer, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, clearCounts, &
+            swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, &
+            cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, do_drfband, drband, dfband, bndscl, indsolvar) &
+            bind(C, name='geosrad_rrtmg_sw')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: rpart, ncol, nlay, isolvar, iceflgsw, liqflgsw, dyofyr, iaer, cloudLM, cloudMH, normFlx, do_drfband
+         real(c_double), value :: scon, adjes
+         type(c_ptr), value :: coszen, play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr, cld, ciwp, clwp, rei, rel, zm, alat, &
+            tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, clearCounts, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, &
+            parf, uvrr, uvrf, fswband, cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, drband, dfband, bndscl, indsolvar
       end function
       integer(c_int) function geosrad_load_inhomogeneity(ctx, ih, path) bind(C, name='geosrad_load_inhomogeneity')
          import; type(c_ptr), value :: ctx; integer(c_int), value :: ih; character(kind=c_char), intent(in) :: path(*)
@@ -89,6 +108,24 @@ contains
       if (stat /= 0) error stop 'geosrad: set GEOSRAD_DATA to the directory holding the *.grtb coefficient tables'
       p = trim(dir) // '/' // name // c_null_char
    end function
+
+   ! message of the last failure on stderr, without stopping (callers that follow MAPL's RC convention)
+   subroutine geosrad_warn(where)
+      character(*), intent(in) :: where
+      character(kind=c_char), pointer :: s(:)
+      type(c_ptr) :: cp
+      integer :: n
+      cp = geosrad_last_error(ctx)
+      n = 0
+      if (c_associated(cp)) then
+         call c_f_pointer(cp, s, [1024])
+         do while (n < 1024)
+            if (s(n+1) == c_null_char) exit
+            n = n + 1
+         end do
+         write(error_unit,'(3a,1024a1)') ' ', where, ': ', s(1:n)
+      end if
+   end subroutine
 
    ! mirror of the reference's `error stop <message>`
    subroutine geosrad_fail(where)

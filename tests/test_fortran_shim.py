@@ -1,4 +1,4 @@
-"""GPU: the Fortran drop-in boundary.  lw_driver.F90 calls `rrtmg_lw_ini` / `rrtmg_lw` / `set_inhomogeneity` with
+"""GPU: the Fortran drop-in boundary (LW and SW).  lw_driver.F90 calls `rrtmg_lw_ini` / `rrtmg_lw` / `set_inhomogeneity` with
 the reference's own module names and signatures (as GEOS_IrradGridComp's LW_Driver does) but is linked against
 the ISO_C_BINDING shim modules over libgeosrad.so; its fluxes must match the reference's golden vectors."""
 import os
@@ -36,3 +36,61 @@ def test_fortran_caller_gets_reference_fluxes(tmp_path, name, kind):
         tol = {"r8": 1e-8, "r4": 2e-5}[kind] if "dTs" in k else {"r8": 1e-6, "r4": 2e-3}[kind]
         assert np.abs(flux[i] - g[f"{kind}_{k}"].astype(np.float64)).max() <= tol, k
     assert np.abs(cc - g[f"{kind}_clearCounts"]).max() <= (0 if kind == "r8" else 1)
+
+
+SW_ORDER = ["coszen", "play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel",
+            "zm", "alat", "tauaer_sw", "ssaaer_sw", "asmaer_sw", "asdir", "asdif", "aldir", "aldif"]
+
+
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_sw_caller_matches_oracle(tmp_path, kind):
+    """sw_driver.F90 calls rrtmg_sw_ini / rrtmg_sw(MAPL, rpart, ncol, nlay, scon, ...) with the reference's module names,
+    argument order and RC convention (as GEOS_SolarGridComp.F90:6225,6331 does), linked against the shim modules."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    exe = os.path.join(FDIR, "bin", f"sw_driver_{kind}")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    ncol, nlay, ih = 40, 72, 1
+    inp = synth.make_columns(ncol, nlay, start=606, aerosol=True, cloudy_frac=0.6)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+
+    def run(isolvar, scon):
+        with open(fin, "wb") as f:
+            np.array([ncol, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]), 10, 1, isolvar], dtype=np.int32).tofile(f)
+            np.array([scon], dtype=np.float32).tofile(f)
+            for k in SW_ORDER:
+                np.ascontiguousarray(inp[k], dtype=np.float32).tofile(f)
+        env = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
+        subprocess.check_call([exe, str(fin), str(fout)], env=env)
+        raw = np.fromfile(fout, dtype=np.uint8)
+        rc = int(raw[:4].view(np.int32)[0])
+        return rc, raw[4:]
+
+    rc, raw = run(0, 1361.0)
+    assert rc == 0
+    nl = (nlay + 1) * ncol
+    off = 0
+
+    def take(n, shape):
+        nonlocal off
+        a = raw[off: off + n * 8].view(np.float64).reshape(shape); off += n * 8
+        return a
+    got = {k: take(nl, (nlay + 1, ncol)) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
+    got["nirr"] = take(ncol, (ncol,)); got["parf"] = take(ncol, (ncol,))
+    for k in ("fswband", "drband", "dfband"):
+        got[k] = take(14 * ncol, (14, ncol))
+    cot0 = take(ncol, (ncol,))
+    cc = raw[off:].view(np.int32).reshape(4, ncol)
+    clib.set_inhomogeneity(ih, kind)
+    o = clib.rrtmg_sw(inp, prec=kind, iaer=10, normFlx=1, do_drfband=True)
+    clib.set_inhomogeneity(0, kind)
+    same = (cc == o["clearCounts"]).all(axis=0)
+    assert same.all() if kind == "r8" else same.mean() > 0.9
+    tol = 1e-9 if kind == "r8" else 5e-3          # normalised fluxes (TOA down = 1); fp32: see tests/test_gpu_sw.py
+    for k, v in got.items():
+        assert np.abs(v - o[k].astype(np.float64))[..., same].max() <= tol, k
+    assert np.abs(cot0 - o["cot"][0])[same].max() <= (1e-9 if kind == "r8" else 1e-4) * max(1.0, o["cot"][0].max())
+    # RC convention: the reference's _FAIL paths return a non-zero RC instead of stopping (GEOS rejects isolvar 1 itself)
+    rc, _ = run(1, 1361.0)
+    assert rc != 0

@@ -171,12 +171,20 @@ def test_sw_full_size_properties(gpu_ctx):
     assert (o["clearCounts"][:, clear] == 112).all() and (o["clearCounts"][0, ~clear] < 112).all()
     for up, dn in (("swuflx", "swdflx"), ("swuflxc", "swdflxc")):
         net = o[dn].astype(np.float64) - o[up]
-        assert (np.diff(net, axis=0) >= -1e-2 * o[dn][72]).all()       # the atmosphere only absorbs (fp32: see header)
+        viol = (np.diff(net, axis=0) < -1e-3 * o[dn][72]).any(axis=0)      # the atmosphere only absorbs ...
+        assert viol.mean() <= 1e-3, viol.mean()                              # ... except near the fp32 singularity (header)
     sfc_dn = o["swdflx"][0].astype(np.float64)
     part = sum(o[k].astype(np.float64) for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf"))
     np.testing.assert_allclose(part, sfc_dn, rtol=2e-5, atol=1e-3)
     np.testing.assert_allclose(o["fswband"].astype(np.float64).sum(axis=0), sfc_dn - o["swuflx"][0], rtol=2e-5, atol=2e-3)
     np.testing.assert_allclose((o["drband"].astype(np.float64) + o["dfband"]).sum(axis=0), sfc_dn, rtol=2e-5, atol=1e-3)
+    # in double precision the property is exact: net flux never increases downwards (4096 of the columns)
+    sub = sub_columns(inp, 4096)
+    gpu_ctx[8].set_inhomogeneity(1)
+    o8 = gpu_ctx[8].rrtmg_sw_columns(sub)
+    gpu_ctx[8].set_inhomogeneity(0)
+    for up, dn in (("swuflx", "swdflx"), ("swuflxc", "swdflxc")):
+        assert (np.diff(o8[dn] - o8[up], axis=0) >= -1e-9 * o8[dn][72]).all()
     # column independence: any shard equals the same columns computed alone, bitwise
     sl = slice(54_321, 54_321 + 257)
     shard = synth.make_columns(257, 72, start=54_321, cloudy_frac=0.3)
