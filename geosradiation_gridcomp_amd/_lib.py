@@ -30,8 +30,19 @@ def build(force=False):
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", os.path.join(CSRC, "geosrad.hip"), "-o", SO]
-    subprocess.check_call(cmd)
+    # one source, three objects compiled in parallel: fp32 kernels, fp64 kernels, the extern "C" layer
+    src = os.path.join(CSRC, "geosrad.hip")
+    objdir = os.path.join(os.path.dirname(HERE), "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    jobs = []
+    for part in (4, 8, 0):
+        obj = os.path.join(objdir, f"geosrad_part{part}.o")
+        jobs.append((obj, subprocess.Popen([hipcc, *flags, f"-DGEOSRAD_PART={part}", "-c", src, "-o", obj])))
+    for obj, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, pr.args)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _ in jobs], "-o", SO])
     return SO
 
 

@@ -237,6 +237,7 @@ struct geosrad_ctx {
     }
     int fail(int code, const std::string &msg) { last_error = msg; return code; }
     virtual ~geosrad_ctx() {}
+    virtual int init() = 0;
     virtual int set_tables_lw(const void *blob, size_t n) = 0;
     virtual int set_inhomogeneity(int ih, const void *blob, size_t n) = 0;
     virtual int set_corr(const double *adl, const double *rdl) = 0;
@@ -271,6 +272,13 @@ enum LwIn { I_PLAY, I_PLEV, I_TLAY, I_TLEV, I_TSFC, I_EMIS, I_H2O, I_O3, I_CO2, 
             I_CCL4, I_CLDF, I_CIWP, I_CLWP, I_REI, I_REL, I_TAUAER, I_ZM, I_ALAT, I_NIN };
 enum LwOutIx { O_UFLX, O_DFLX, O_UFLXC, O_DFLXC, O_DUFLX, O_DUFLXC, O_OLRB, O_DOLRB, O_NOUT };
 
+// The library is built from this one source as three objects compiled in parallel (GEOSRAD_PART = 4: the fp32
+// instantiation of Ctx and of every kernel, 8: the fp64 one, 0: the extern "C" layer); without GEOSRAD_PART it is
+// a single translation unit.
+geosrad_ctx *geosrad_new_ctx_f32();
+geosrad_ctx *geosrad_new_ctx_f64();
+
+#if !defined(GEOSRAD_PART) || GEOSRAD_PART != 0
 namespace {
 
 template <typename R> struct Ctx : geosrad_ctx {
@@ -308,7 +316,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    int init()
+    int init() override
     {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -472,7 +480,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + io_bytes + tab_bytes + tab_sw_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
-    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *blkcloudy, *laycloudy; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
+    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
     static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t ws_layout(int nc, int nlay, Ws *w, char *base) const
     {
@@ -484,7 +492,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(cl * 4); if (w) w->scidx = (uint32_t *)p;
         p = take((size_t)nc * sizeof(R)); if (w) w->pwvcm = (R *)p;
         p = take(nc); if (w) w->colcloudy = (uint8_t *)p;
-        p = take((size_t)(nc + 255) / 256); if (w) w->blkcloudy = (uint8_t *)p;
+        p = take((size_t)nc * 4); if (w) w->perm = (int32_t *)p;
+        p = take(4); if (w) w->nclear = (int32_t *)p;
         p = take(cl); if (w) w->laycloudy = (uint8_t *)p;
         p = take(cl * sizeof(R)); if (w) w->alpha = (R *)p;
         p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
@@ -549,7 +558,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.cfc11 = P(I_CFC11); A.cfc12 = P(I_CFC12); A.cfc22 = P(I_CFC22); A.ccl4 = P(I_CCL4);
             A.cldf = P(I_CLDF); A.ciwp = P(I_CIWP); A.clwp = P(I_CLWP); A.rei = P(I_REI); A.rel = P(I_REL);
             A.tauaer = P(I_TAUAER); A.zm = P(I_ZM); A.alat = P(I_ALAT);
-            A.sc = w.sc; A.scidx = w.scidx; A.pwvcm = w.pwvcm; A.colcloudy = w.colcloudy; A.blkcloudy = w.blkcloudy; A.laycloudy = w.laycloudy;
+            A.sc = w.sc; A.scidx = w.scidx; A.pwvcm = w.pwvcm; A.colcloudy = w.colcloudy; A.perm = w.perm; A.nclear = w.nclear; A.laycloudy = w.laycloudy;
             A.taucmc = w.taucmc; A.alpha = w.alpha; A.rcorr = w.rcorr; A.s1 = w.s1; A.s2 = w.s2; A.part = w.part;
             A.err = d_err;
             A.dbg_taug = dbg_taug ? (R *)dbg_taug + (size_t)c0 * NG_LW * nlay : nullptr;
@@ -558,19 +567,19 @@ template <typename R> struct Ctx : geosrad_ctx {
 
             const dim3 blk(256);
             const unsigned gx = (unsigned)((nc + 255) / 256);
-            HIPCHK(hipMemsetAsync(w.blkcloudy, 0, (size_t)(nc + 255) / 256, st));
-            span_begin(0, st); hipLaunchKernelGGL(k_validate_pwv<R>, dim3(gx), blk, 0, st, A, d_T); span_end(st);
+            span_begin(0, st); hipLaunchKernelGGL(k_validate_pwv<R>, dim3(gx), blk, 0, st, A, d_T);
+            hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, st, nc, (const uint8_t *)w.colcloudy, w.perm, w.nclear); span_end(st);
             span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, d_T); span_end(st);
             // McICA + cloud optics (threads of clear columns exit at once)
             span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,
-                               (const uint8_t *)A.colcloudy, (const LwDev<R> *)d_T, A.alpha, A.rcorr, A.laycloudy); span_end(st);
+                               (const int32_t *)w.perm, (const int32_t *)w.nclear, (const LwDev<R> *)d_T, A.alpha, A.rcorr, A.laycloudy); span_end(st);
             McArgs<R> M{};
             M.ncol = nc; M.ld = ncol; M.nlay = nlay; M.nsubcol = NG_LW; M.doy = dyofyr; M.cloudLM = cloudLM; M.cloudMH = cloudMH;
             M.iceflg = iceflg; M.liqflg = liqflg;
             M.so[0] = 1; M.so[1] = 2; M.so[2] = 3; M.so[3] = 4;        // seed_order=[1,2,3,4] (rrtmg_lw_rad.F90:546)
             M.cwp_tiny = (R)1.e-20;                                       // rrtmg_lw_rad.F90:544
             M.play = A.play; M.cldf = A.cldf; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
-            M.alpha = A.alpha; M.rcorr = A.rcorr; M.colcloudy = A.colcloudy;
+            M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
             M.taucmc = A.taucmc; M.laycloudy = A.laycloudy; M.clearCounts = A.clearCounts; M.err = d_err;
             {
                 static const int bstart[17] = {0, 10, 22, 38, 52, 68, 76, 88, 96, 108, 114, 122, 130, 134, 136, 138, 140};
@@ -764,7 +773,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return GEOSRAD_OK;
     }
 
-    struct WsSw { R *sc; uint32_t *scidx; uint8_t *colcloudy, *blkcloudy; R *alpha, *rcorr, *taucmc, *ssacmc, *asmcmc, *cotsum, *cell, *part, *bsfc, *cot; };
+    struct WsSw { R *sc; uint32_t *scidx; uint8_t *colcloudy; int32_t *perm, *nclear; R *alpha, *rcorr, *taucmc, *ssacmc, *asmcmc, *cotsum, *cell, *part, *bsfc, *cot; };
     size_t ws_layout_sw(int nc, int nlay, WsSw *w, char *base) const
     {
         size_t off = 0;
@@ -774,7 +783,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(SW_NFIELD * cl * sizeof(R)); if (w) w->sc = (R *)p;
         p = take(cl * 4); if (w) w->scidx = (uint32_t *)p;
         p = take(nc); if (w) w->colcloudy = (uint8_t *)p;
-        p = take((size_t)(nc + 255) / 256); if (w) w->blkcloudy = (uint8_t *)p;
+        p = take((size_t)nc * 4); if (w) w->perm = (int32_t *)p;
+        p = take(4); if (w) w->nclear = (int32_t *)p;
         p = take(cl * sizeof(R)); if (w) w->alpha = (R *)p;
         p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
         p = take(NG_SW * cl * sizeof(R)); if (w) w->taucmc = (R *)p;
@@ -875,7 +885,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.tauaer = iaer == 10 ? P(S_TAUAER) : nullptr; A.ssaaer = iaer == 10 ? P(S_SSAAER) : nullptr;
             A.asmaer = iaer == 10 ? P(S_ASMAER) : nullptr;
             A.coszen = P(S_COSZEN); A.asdir = P(S_ASDIR); A.asdif = P(S_ASDIF); A.aldir = P(S_ALDIR); A.aldif = P(S_ALDIF);
-            A.sc = w.sc; A.scidx = w.scidx; A.colcloudy = w.colcloudy; A.blkcloudy = w.blkcloudy; A.alpha = w.alpha; A.rcorr = w.rcorr;
+            A.sc = w.sc; A.scidx = w.scidx; A.colcloudy = w.colcloudy; A.perm = w.perm; A.nclear = w.nclear; A.alpha = w.alpha; A.rcorr = w.rcorr;
             A.taucmc = w.taucmc; A.ssacmc = w.ssacmc; A.asmcmc = w.asmcmc; A.cotsum = w.cotsum; A.cell = w.cell; A.part = w.part;
             A.bsfc = w.bsfc; A.cot = w.cot;
             A.err = d_err + 1;
@@ -886,18 +896,18 @@ template <typename R> struct Ctx : geosrad_ctx {
             }
             const dim3 blk(256);
             const unsigned gx = (unsigned)((nc + 255) / 256);
-            HIPCHK(hipMemsetAsync(w.blkcloudy, 0, (size_t)(nc + 255) / 256, st));
-            span_begin(6, st); hipLaunchKernelGGL(k_sw_validate<R>, dim3(gx), blk, 0, st, A); span_end(st);
+            span_begin(6, st); hipLaunchKernelGGL(k_sw_validate<R>, dim3(gx), blk, 0, st, A);
+            hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, st, nc, (const uint8_t *)w.colcloudy, w.perm, w.nclear); span_end(st);
             span_begin(7, st); hipLaunchKernelGGL(k_sw_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, (const SwDev<R> *)d_S); span_end(st);
             span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,
-                               (const uint8_t *)A.colcloudy, (const LwDev<R> *)d_T, A.alpha, A.rcorr, (uint8_t *)nullptr); span_end(st);
+                               (const int32_t *)w.perm, (const int32_t *)w.nclear, (const LwDev<R> *)d_T, A.alpha, A.rcorr, (uint8_t *)nullptr); span_end(st);
             McArgs<R> M{};
             M.ncol = nc; M.ld = ncol; M.nlay = nlay; M.nsubcol = NG_SW; M.doy = dyofyr; M.cloudLM = cloudLM; M.cloudMH = cloudMH;
             M.iceflg = iceflg; M.liqflg = liqflg;
             M.so[0] = 4; M.so[1] = 3; M.so[2] = 2; M.so[3] = 1;        // seed_order=[4,3,2,1] (SW/rrtmg_sw_rad.F90:1401)
             M.cwp_tiny = (R)1.e-20;
             M.play = A.play; M.cldf = A.cld; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
-            M.alpha = A.alpha; M.rcorr = A.rcorr; M.colcloudy = A.colcloudy;
+            M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
             M.taucmc = A.taucmc; M.ssacmc = A.ssacmc; M.asmcmc = A.asmcmc; M.cotsum = A.cotsum; M.clearCounts = A.clearCounts; M.err = d_err + 1;
             {
                 static const int bstart[15] = {0, 6, 18, 26, 34, 44, 54, 56, 66, 74, 80, 86, 94, 100, 112};
@@ -1014,7 +1024,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             HIPCHK(hipMemcpyAsync(d_io + dst[k], src[k], (k == 5 ? (size_t)ncol : cl) * sizeof(R), hipMemcpyHostToDevice, stream));
         const unsigned gx = (unsigned)((ncol + 255) / 256);
         hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), dim3(256), 0, stream, ncol, ncol, nlay, doy, (const R *)(d_io + o_z),
-                           (const R *)(d_io + o_a), (const uint8_t *)nullptr, (const LwDev<R> *)d_T, (R *)(d_io + o_al), (R *)(d_io + o_rc), (uint8_t *)nullptr);
+                           (const R *)(d_io + o_a), (const int32_t *)nullptr, (const int32_t *)nullptr, (const LwDev<R> *)d_T, (R *)(d_io + o_al), (R *)(d_io + o_rc), (uint8_t *)nullptr);
         McArgs<R> M{};
         M.ncol = ncol; M.ld = ncol; M.nlay = nlay; M.nsubcol = nsubcol; M.doy = doy; M.cloudLM = 1; M.cloudMH = 2;
         for (int k = 0; k < 4; k++) M.so[k] = sov[k];
@@ -1037,6 +1047,15 @@ template <typename R> struct Ctx : geosrad_ctx {
 
 }  // namespace
 
+#if !defined(GEOSRAD_PART) || GEOSRAD_PART == 4
+geosrad_ctx *geosrad_new_ctx_f32() { return new Ctx<float>(); }
+#endif
+#if !defined(GEOSRAD_PART) || GEOSRAD_PART == 8
+geosrad_ctx *geosrad_new_ctx_f64() { return new Ctx<double>(); }
+#endif
+#endif   // GEOSRAD_PART != 0
+
+#if !defined(GEOSRAD_PART) || GEOSRAD_PART == 0
 // ---------------------------------------------------------------------------------------------------
 // extern "C"
 // ---------------------------------------------------------------------------------------------------
@@ -1048,9 +1067,9 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return GEOSRAD_ENODEV;
-    geosrad_ctx *c = real_kind == 4 ? (geosrad_ctx *)new Ctx<float>() : (geosrad_ctx *)new Ctx<double>();
+    geosrad_ctx *c = real_kind == 4 ? geosrad_new_ctx_f32() : geosrad_new_ctx_f64();
     c->device = device_id; c->real_kind = real_kind;
-    int rc = real_kind == 4 ? static_cast<Ctx<float> *>(c)->init() : static_cast<Ctx<double> *>(c)->init();
+    int rc = c->init();
     if (rc) { delete c; return rc; }
     *out = c;
     return GEOSRAD_OK;
@@ -1286,3 +1305,4 @@ int geosrad_clearcounts(geosrad_ctx *c, int ncol, int nsubcol, int nlay, int clo
 }
 
 }  // extern "C"
+#endif   // GEOSRAD_PART == 0

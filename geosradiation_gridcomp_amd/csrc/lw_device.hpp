@@ -81,7 +81,8 @@ template <typename R> struct LwArgs {
     uint32_t *scidx;             // [nlay][ncol]
     R *pwvcm;                    // [ncol]
     uint8_t *colcloudy;          // [ncol]  any cldf > 0 in the column
-    uint8_t *blkcloudy;          // [ceil(ncol/256)] any cloudy column in the 256-column block
+    int32_t *perm;               // [ncol]  compacted position -> column of the batch: clear columns first, then cloudy (stable)
+    int32_t *nclear;             // [1]     number of clear columns of the batch
     uint8_t *laycloudy;          // [nlay][ncol]  optically cloudy for ANY g-point (cldprmc's `cloudy`)
     R *taucmc;                   // [140][nlay][ncol]
     R *alpha, *rcorr;            // [nlay][ncol] inter-layer overlap correlations (cloud_subcol_gen.F90:314-321)

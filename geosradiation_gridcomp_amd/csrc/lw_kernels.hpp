@@ -93,7 +93,6 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
     const R wvsh = (amw * wvttl) / (amd * amttl);
     A.pwvcm[col] = wvsh * ((R)1.e3 * A.plev[col]) / ((R)1.e2 * grav);
     A.colcloudy[col] = cloudy ? 1 : 0;
-    if (cloudy) A.blkcloudy[blockIdx.x] = 1;   // zeroed by the host before the launch; same-value race is benign
     // clear column: all sub-columns clear in every super-layer (cloud_subcol_gen.F90:649-659);
     // cloudy column: k_mcica's (column, band) threads add their counts
     for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = cloudy ? 0 : NG_LW;
@@ -111,6 +110,40 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_partition: stable partition of the batch's columns into clear | cloudy (one 1024-thread block).
+// Every later kernel works on COMPACTED positions: workspace arrays are indexed by the position, API arrays
+// by perm[position].  256-column blocks are then homogeneous (at most one mixed block), so clear blocks run the
+// cheaper clear-sky instantiation whatever the spatial distribution of the cloudy columns, and no wave
+// carries idle cloudy-only work for its clear lanes.  Columns are independent: the permutation does not touch results.
+// ---------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(1024) k_partition(int ncol, const uint8_t *__restrict__ colcloudy, int32_t *__restrict__ perm,
+                                                    int32_t *__restrict__ nclear)
+{
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x;
+    const int chunk = (ncol + 1023) / 1024;
+    const int b = t * chunk, e = (b + chunk < ncol) ? b + chunk : ncol;
+    int c = 0;
+    for (int i = b; i < e; i++) c += colcloudy[i] != 0;
+    cnt[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive Hillis-Steele scan
+        const int v = t >= d ? cnt[t - d] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    const int ncloudy = cnt[1023];
+    const int ncl = ncol - ncloudy;
+    int cbefore = cnt[t] - c;                       // cloudy columns before this thread's chunk
+    for (int i = b; i < e; i++) {
+        if (colcloudy[i]) { perm[ncl + cbefore] = i; cbefore++; }
+        else perm[i - cbefore] = i;
+    }
+    if (t == 0) *nclear = ncl;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_setcoef: one thread per (layer, column); blockIdx.y = layer.  LW/rrtmg_lw_setcoef.F90:401-579
 // (everything that does not depend on the band; Planck terms are interpolated inside the band kernel).
 // ---------------------------------------------------------------------------------------------------
@@ -121,7 +154,7 @@ __global__ void __launch_bounds__(256) k_setcoef(LwArgs<R> A, const LwDev<R> *__
     const int lay = blockIdx.y;
     if (col >= A.ncol) return;
     const int ld = A.ld, n = A.ncol, nlay = A.nlay;
-    const size_t i = (size_t)lay * ld + col;
+    const size_t i = (size_t)lay * ld + A.perm[col];          // API arrays: original column; workspace: compacted position
     const R amd = (R)28.9660, amw = (R)18.0160;
     const R stpfac = (R)296. / (R)1013.;
     const R pavel = A.play[i], tavel = A.tlay[i], h2o = A.h2o[i];
@@ -902,7 +935,7 @@ struct Band16 {  // 2600-3250: h2o,ch4 | ch4 (:2871-3126)
 // ---------------------------------------------------------------------------------------------------
 // Fused taumol + rtrnmc for one (column, band): LW/rrtmg_lw_rtrnmc.F90:164-388.
 // ---------------------------------------------------------------------------------------------------
-template <typename R> GR_DEV void load_layer(const LwArgs<R> &A, int lay, int col, Layer<R> &L)
+template <typename R> GR_DEV void load_layer(const LwArgs<R> &A, int lay, int col, int pc, Layer<R> &L)
 {
     // uniform (SGPR) field base + one shared 32-bit per-lane byte offset
     const uint32_t cell = (uint32_t)lay * (uint32_t)A.ncol + (uint32_t)col;
@@ -917,7 +950,7 @@ template <typename R> GR_DEV void load_layer(const LwArgs<R> &A, int lay, int co
     const uint32_t p = ldg(A.scidx, cell * 4u);
     L.jp = p & 63; L.jt = (p >> 6) & 7; L.jt1 = (p >> 9) & 7; L.indfor = (p >> 12) & 3; L.indself = (p >> 14) & 15;
     L.indminor = (p >> 18) & 31; L.lower = (p >> 23) & 1;
-    L.ab = ((uint32_t)lay * (uint32_t)A.ld + (uint32_t)col) * (uint32_t)sizeof(R);
+    L.ab = ((uint32_t)lay * (uint32_t)A.ld + (uint32_t)pc) * (uint32_t)sizeof(R);      // API arrays: original column
     L.pavel = ldg(A.play, L.ab);
 }
 
@@ -942,7 +975,7 @@ template <typename R> GR_DEV R planck_at(const R *__restrict__ totplnk, int ib, 
 // CLD = true : general case, per-lane `ccol` predicate, separate clear-sky stream once the streams part.
 // DBG = true : additionally dumps taug/pfracs in the reference's (nlay,140,ncol) layout (test hook only).
 template <typename R, typename BAND, bool CLD, bool DBG>
-GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
+GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear)
 {
     constexpr int NG = BAND::NG, IB = BAND::IB, G0 = BAND::G0;
     constexpr int W = NG >= 4 ? 4 : 2;
@@ -953,7 +986,9 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
     const R bpade = T.bpade, tblint = (R)NTBL;
     const R sumfac = (R)0.5 * T.delwave[IB] * T.fluxfac;
     const uint32_t ucol = (uint32_t)col;
-    const uint32_t cb = ucol * (uint32_t)sizeof(R);       // byte offset of this column in a row of reals
+    const uint32_t cb = ucol * (uint32_t)sizeof(R);       // byte offset of this position in a workspace row of reals
+    const int pc = ldg(A.perm, ucol * 4u);                // original column: index into the API arrays
+    const uint32_t cba = (uint32_t)pc * (uint32_t)sizeof(R);
 
     // diffusivity angle (:177-186)
     R secdiff = (R)1.66;
@@ -961,10 +996,14 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
         constexpr double a0[17] = {0, 1.66, 1.55, 1.58, 1.66, 1.54, 1.454, 1.89, 1.33, 1.668, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66};
         constexpr double a1[17] = {0, 0.00, 0.25, 0.22, 0.00, 0.13, 0.446, -0.10, 0.40, -0.006, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
         constexpr double a2[17] = {0, 0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.19, -0.062, 0.414, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
-        secdiff = (R)a0[IB] + (R)a1[IB] * gr_exp<R>((R)a2[IB] * ldg(A.pwvcm, cb));
+        secdiff = (R)a0[IB] + (R)a1[IB] * gr_exp<R>((R)a2[IB] * ldg(A.pwvcm, cba));
         secdiff = secdiff > (R)1.80 ? (R)1.80 : (secdiff < (R)1.50 ? (R)1.50 : secdiff);
     }
-    const bool ccol = CLD && ldg(A.colcloudy, ucol) != 0;
+    // CLD kernels only see cloudy columns (DBG: all columns), so this is true there; it is deliberately left a run-time
+    // value: as a compile-time constant the if-converted code needs 290 registers and halves the occupancy
+    int ncl_opaque = nclear;
+    asm volatile("" : "+s"(ncl_opaque));        // hides the fact from the optimiser (the caller already tested col >= nclear)
+    const bool ccol = CLD && col >= ncl_opaque;
 
     // uniform bases
     const size_t bandoff = (size_t)G0 * nlay * n;                         // this band's sub-array of the cell planes
@@ -976,8 +1015,8 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
 #define PART(kind, lev, val) stg(part + (size_t)(kind) * qs + (size_t)(lev) * n, cb, (R)(val))
 
     // surface terms (:319-333), needed when the down sweep reaches layer 0
-    const R semis = ldg(A.emis + (size_t)(IB - 1) * ld, cb);
-    const R tb = ldg(A.tsfc, cb);
+    const R semis = ldg(A.emis + (size_t)(IB - 1) * ld, cba);
+    const R tb = ldg(A.tsfc, cba);
     const R plankbnd = semis * planck_at<R>(T.totplnk, IB, tb);
     const R dplankbnd = dudTs ? semis * planck_at<R>(T.totplnkderiv, IB, tb) : (R)0;
     const R reflect = (R)1. - semis;
@@ -991,10 +1030,10 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
     R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
 
     // ---- downward sweep, top layer -> surface ------------------------------------------------------
-    R plk_up = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)nlay * ld, cb));   // level above the current layer
+    R plk_up = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)nlay * ld, cba));   // level above the current layer
     for (int lay = nlay - 1; lay >= 0; lay--) {
         Layer<R> L;
-        load_layer<R>(A, lay, col, L);
+        load_layer<R>(A, lay, col, pc, L);
         Prep<R> P;
         BAND::template prep<R>(T, A, L, P);
         const R ta = A.tauaer ? ldg(A.tauaer + (size_t)(IB - 1) * nlay * ld, L.ab) : (R)0;
@@ -1018,7 +1057,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col)
                 const int g = q * W + j;
                 if (g >= NG) continue;   // padding of the last group
                 if (DBG) {
-                    const size_t o = ((size_t)col * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
+                    const size_t o = ((size_t)pc * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
                     A.dbg_taug[o] = tau[j] + ta;
                     A.dbg_pfracs[o] = pf[j];
                 }
@@ -1137,7 +1176,7 @@ __host__ __device__ constexpr int lw_band_ng(int ib)
 }
 
 // blockIdx.y selects the band.  Two instantiations are launched back to back: CLD = false handles the
-// 256-column blocks in which k_validate_pwv found no cloud at all (blkcloudy == 0), CLD = true the others;
+// 256-column blocks of compacted positions that hold clear columns only, CLD = true the others (k_partition);
 // a block of the wrong kind exits immediately, so each kernel keeps the register budget of its own path.
 // T is passed BY VALUE: table pointers that arrive as kernel arguments are known to be global-address-space
 // and wave-uniform, so a table row fetch is `global_load_dwordx4 v, voff, s[base:base+1]`; behind a
@@ -1145,26 +1184,32 @@ __host__ __device__ constexpr int lw_band_ng(int ib)
 template <typename R, bool CLD, bool DBG>
 __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
 {
-    if (!DBG && (A.blkcloudy[blockIdx.x] != 0) != CLD) return;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nclear = *A.nclear;
+    // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
+    // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
+    const int bstart = (int)(blockIdx.x * blockDim.x);
+    const int bend = bstart + (int)blockDim.x < A.ncol ? bstart + (int)blockDim.x : A.ncol;
+    if (!DBG && (CLD ? bend <= nclear : bstart >= nclear)) return;
+    const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
+    if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
     switch (LW_BAND_ORDER[blockIdx.y]) {
-        case 1: band_body<R, Band1, CLD, DBG>(A, T, col); break;
-        case 2: band_body<R, Band2, CLD, DBG>(A, T, col); break;
-        case 3: band_body<R, Band3, CLD, DBG>(A, T, col); break;
-        case 4: band_body<R, Band4, CLD, DBG>(A, T, col); break;
-        case 5: band_body<R, Band5, CLD, DBG>(A, T, col); break;
-        case 6: band_body<R, Band6, CLD, DBG>(A, T, col); break;
-        case 7: band_body<R, Band7, CLD, DBG>(A, T, col); break;
-        case 8: band_body<R, Band8, CLD, DBG>(A, T, col); break;
-        case 9: band_body<R, Band9, CLD, DBG>(A, T, col); break;
-        case 10: band_body<R, Band10, CLD, DBG>(A, T, col); break;
-        case 11: band_body<R, Band11, CLD, DBG>(A, T, col); break;
-        case 12: band_body<R, Band12, CLD, DBG>(A, T, col); break;
-        case 13: band_body<R, Band13, CLD, DBG>(A, T, col); break;
-        case 14: band_body<R, Band14, CLD, DBG>(A, T, col); break;
-        case 15: band_body<R, Band15, CLD, DBG>(A, T, col); break;
-        default: band_body<R, Band16, CLD, DBG>(A, T, col); break;
+        case 1: band_body<R, Band1, CLD, DBG>(A, T, col, nclear); break;
+        case 2: band_body<R, Band2, CLD, DBG>(A, T, col, nclear); break;
+        case 3: band_body<R, Band3, CLD, DBG>(A, T, col, nclear); break;
+        case 4: band_body<R, Band4, CLD, DBG>(A, T, col, nclear); break;
+        case 5: band_body<R, Band5, CLD, DBG>(A, T, col, nclear); break;
+        case 6: band_body<R, Band6, CLD, DBG>(A, T, col, nclear); break;
+        case 7: band_body<R, Band7, CLD, DBG>(A, T, col, nclear); break;
+        case 8: band_body<R, Band8, CLD, DBG>(A, T, col, nclear); break;
+        case 9: band_body<R, Band9, CLD, DBG>(A, T, col, nclear); break;
+        case 10: band_body<R, Band10, CLD, DBG>(A, T, col, nclear); break;
+        case 11: band_body<R, Band11, CLD, DBG>(A, T, col, nclear); break;
+        case 12: band_body<R, Band12, CLD, DBG>(A, T, col, nclear); break;
+        case 13: band_body<R, Band13, CLD, DBG>(A, T, col, nclear); break;
+        case 14: band_body<R, Band14, CLD, DBG>(A, T, col, nclear); break;
+        case 15: band_body<R, Band15, CLD, DBG>(A, T, col, nclear); break;
+        default: band_body<R, Band16, CLD, DBG>(A, T, col, nclear); break;
     }
 }
 
@@ -1185,7 +1230,8 @@ __global__ void __launch_bounds__(256) k_lw_reduce(LwArgs<R> A, LwOut<R> O)
     const int lev = blockIdx.y;
     if (col >= A.ncol) return;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
-    const bool ccol = A.colcloudy[col] != 0;
+    const bool ccol = col >= *A.nclear;
+    const int pc = A.perm[col];
     const size_t qs = (size_t)NB_LW * (nlay + 1) * n;
     const R *p = A.part + (size_t)lev * n + col;
     R s[6] = {0, 0, 0, 0, 0, 0};
@@ -1201,15 +1247,15 @@ __global__ void __launch_bounds__(256) k_lw_reduce(LwArgs<R> A, LwOut<R> O)
         }
     }
     if (!ccol) { s[1] = s[0]; s[3] = s[2]; s[5] = s[4]; }
-    const size_t i = (size_t)lev * ld + col;
+    const size_t i = (size_t)lev * ld + pc;
     O.dflx[i] = s[0]; O.dflxc[i] = s[1]; O.uflx[i] = s[2]; O.uflxc[i] = s[3];
     if (A.dudTs) { O.duflx_dTs[i] = s[4]; O.duflxc_dTs[i] = s[5]; }
     if (lev == nlay) {
         for (int ib = 0; ib < NB_LW; ib++) {
             if (O.band_output[ib]) {
                 const size_t o = (size_t)ib * (nlay + 1) * n;
-                O.olrb[(size_t)(O.col0 + col) * NB_LW + ib] = p[2 * qs + o];
-                if (A.dudTs) O.dolrb_dTs[(size_t)(O.col0 + col) * NB_LW + ib] = p[4 * qs + o];
+                O.olrb[(size_t)(O.col0 + pc) * NB_LW + ib] = p[2 * qs + o];
+                if (A.dudTs) O.dolrb_dTs[(size_t)(O.col0 + pc) * NB_LW + ib] = p[4 * qs + o];
             }
         }
     }

@@ -140,22 +140,24 @@ template <typename R> GR_DEV Kiss kiss_seed(const R *__restrict__ play, int ld, 
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_overlap(int ncol, int ld, int nlay, int doy, const R *__restrict__ zmid,
-                                                 const R *__restrict__ alat, const uint8_t *__restrict__ colcloudy,
-                                                 const LwDev<R> *__restrict__ T, R *__restrict__ alpha, R *__restrict__ rcorr,
-                                                 uint8_t *__restrict__ laycloudy)
+                                                 const R *__restrict__ alat, const int32_t *__restrict__ perm,
+                                                 const int32_t *__restrict__ nclear, const LwDev<R> *__restrict__ T,
+                                                 R *__restrict__ alpha, R *__restrict__ rcorr, uint8_t *__restrict__ laycloudy)
 {
+    // perm / nclear (k_partition) are null for the stand-alone generator: identity, every column processed
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int lay = blockIdx.y;
     if (col >= ncol) return;
-    if (colcloudy && !colcloudy[col]) return;
+    if (nclear && col < *nclear) return;
+    const int pc = perm ? perm[col] : col;
     const size_t w = (size_t)lay * ncol + col;
     if (laycloudy) laycloudy[w] = 0;     // k_mcica's (column, band) threads OR their findings into it
     if (lay == 0) { alpha[w] = 0; if (rcorr) rcorr[w] = 0; return; }
-    const R dz = fabs(zmid[(size_t)lay * ld + col] - zmid[(size_t)(lay - 1) * ld + col]);
-    const R adl = corr_length<R>(T->aam, doy, alat[col]);
+    const R dz = fabs(zmid[(size_t)lay * ld + pc] - zmid[(size_t)(lay - 1) * ld + pc]);
+    const R adl = corr_length<R>(T->aam, doy, alat[pc]);
     alpha[w] = gr_exp<R>(-dz / adl);
     if (T->xcw) {
-        const R rdl = corr_length<R>(T->ram, doy, alat[col]);
+        const R rdl = corr_length<R>(T->ram, doy, alat[pc]);
         rcorr[w] = gr_exp<R>(-dz / rdl);
     }
 }
@@ -294,7 +296,7 @@ template <typename R> struct McArgs {
     R cwp_tiny;
     const R *play, *cldf, *ciwp, *clwp, *rei, *rel;
     const R *alpha, *rcorr;            // [nlay][ncol]
-    const uint8_t *colcloudy;          // nullable
+    const int32_t *perm, *nclear;      // k_partition's compaction (null: identity, all columns)
     // MODE 0
     R *taucmc; uint8_t *laycloudy; int32_t *clearCounts; uint32_t *err;
     // MODE 1
@@ -309,13 +311,14 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int seg = blockIdx.y;
     if (col >= M.ncol) return;
-    if (M.colcloudy && !M.colcloudy[col]) return;
+    if (M.nclear && col < *M.nclear) return;      // clear columns: nothing to generate
+    const int pc = M.perm ? M.perm[col] : col;    // API arrays are indexed by the original column
     const LwDev<R> &T = *Tp;
     const int n = M.ncol, ld = M.ld, nlay = M.nlay;
     const bool inhomo = T.xcw != nullptr;
     // vertical ordering is detected from the first column of the call (cloud_subcol_gen.F90:266)
     const bool surface_at_one = M.play[0] > M.play[(size_t)(nlay - 1) * ld];
-    Kiss ks = kiss_seed<R>(M.play, ld, nlay, col, surface_at_one, M.so);
+    Kiss ks = kiss_seed<R>(M.play, ld, nlay, pc, surface_at_one, M.so);
     // n = 0 must stay the identity: a raw seed may exceed the MWC modulus (non-canonical), which mwc_jump would reduce
     if (SG.start[seg] > 0) kiss_jump(ks, SG.j[seg]);
     uint32_t err = 0;
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
         for (int il = 0; il < nlay; il++) {
             R cdf1 = kiss_next<R>(ks);
             const R cdf2 = kiss_next<R>(ks);
-            const size_t w = (size_t)il * n + col, a = (size_t)il * ld + col;
+            const size_t w = (size_t)il * n + col, a = (size_t)il * ld + pc;
             if (il > 0 && cdf2 < M.alpha[w]) cdf1 = cprev;
             cprev = cdf1;
             const R cf = M.cldf[a];
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
             for (int il = 0; il < nlay; il++) {
                 const R cdf2 = kiss_next<R>(ks);
                 R cdf3 = kiss_next<R>(ks);
-                const size_t w = (size_t)il * n + col, a = (size_t)il * ld + col;
+                const size_t w = (size_t)il * n + col, a = (size_t)il * ld + pc;
                 if (il > 0 && cdf2 < M.rcorr[w]) cdf3 = c3prev;
                 c3prev = cdf3;
                 const size_t oc = PLANES ? tb0 + (size_t)il * tbs : ((size_t)col * M.nsubcol + is) * nlay + il;
@@ -428,16 +431,16 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev
     }
     if (PLANES) {
         // integer adds: order-independent, bitwise reproducible (k_validate_pwv zeroed the cloudy columns' counts)
-        atomicAdd(&M.clearCounts[(size_t)0 * ld + col], cnt_all);
-        atomicAdd(&M.clearCounts[(size_t)1 * ld + col], cnt_hi);
-        atomicAdd(&M.clearCounts[(size_t)2 * ld + col], cnt_mid);
-        atomicAdd(&M.clearCounts[(size_t)3 * ld + col], cnt_lo);
+        atomicAdd(&M.clearCounts[(size_t)0 * ld + pc], cnt_all);
+        atomicAdd(&M.clearCounts[(size_t)1 * ld + pc], cnt_hi);
+        atomicAdd(&M.clearCounts[(size_t)2 * ld + pc], cnt_mid);
+        atomicAdd(&M.clearCounts[(size_t)3 * ld + pc], cnt_lo);
         if (err) atomicOr(M.err, err);
     }
 }
 
 // clearCounts_threeBand stand-alone (cloud_subcol_gen.F90:611-769): cldy Fortran (nlay,nsubcol,ncol)
-__global__ void __launch_bounds__(64) k_clearcounts(int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH,
+static __global__ void __launch_bounds__(64) k_clearcounts(int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH,
                                                     const int32_t *__restrict__ cldy, int32_t *__restrict__ cnt /*(4,ncol)*/)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;

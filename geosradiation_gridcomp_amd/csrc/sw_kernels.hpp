@@ -59,7 +59,8 @@ template <typename R> struct SwArgs {
     const R *tauaer, *ssaaer, *asmaer, *coszen, *asdir, *asdif, *aldir, *aldif;
     // workspace
     R *sc; uint32_t *scidx;              // setcoef record [SW_NFIELD][nlay][ncol] + packed indices
-    uint8_t *colcloudy, *blkcloudy;
+    uint8_t *colcloudy;                  // [ncol] any cld > 0, original column order
+    int32_t *perm, *nclear;              // k_partition: compacted position -> column; number of clear columns
     R *alpha, *rcorr;
     R *taucmc, *ssacmc, *asmcmc;         // McICA cloud optics, band-major planes [band][lay][g][col]
     R *cotsum;                           // [3][NG_SW][ncol]  per-sub-column low|mid|high sums of the un-scaled cloud tau
@@ -104,7 +105,6 @@ __global__ void __launch_bounds__(256) k_sw_validate(SwArgs<R> A)
     if (A.plev[(size_t)nlay * ld + col] < 0) err |= 1u << SWERR_PLEV;
     if (A.asdir[col] < 0 || A.aldir[col] < 0 || A.asdif[col] < 0 || A.aldif[col] < 0) err |= 1u << SWERR_ALB;
     A.colcloudy[col] = cloudy ? 1 : 0;
-    if (cloudy) A.blkcloudy[blockIdx.x] = 1;
     for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = cloudy ? 0 : NG_SW;   // rrtmg_sw_rad.F90:1520-1523
     if (err) atomicOr(A.err, err);
 }
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_sw_setcoef(SwArgs<R> A, const SwDev<R> 
     const int lay = blockIdx.y;
     if (col >= A.ncol) return;
     const int ld = A.ld, n = A.ncol, nlay = A.nlay;
-    const size_t i = (size_t)lay * ld + col;
+    const size_t i = (size_t)lay * ld + A.perm[col];          // API arrays: original column; workspace: compacted position
     const R amd = (R)28.9660, amw = (R)18.0160, stpfac = (R)296. / (R)1013.;
     const R pavel = A.play[i], tavel = A.tlay[i], h = A.h2o[i];
     const R coldry = (A.plev[i] - A.plev[i + ld]) * (R)1.e3 * T->avogad /
@@ -398,7 +398,7 @@ template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R &ref,
 // 7 prdnd at the layer's lower boundary.  Planes 8..15: the same for the total sky of cloudy columns.
 // ---------------------------------------------------------------------------------------------------
 template <typename R, typename B, bool CLD, bool DBG>
-GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV, int col)
+GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV, int col, int nclear)
 {
     constexpr int NG = B::NG, JB = B::JB, IBM = B::JB - 15, G0 = B::G0;
     constexpr int W = NG >= 4 ? 4 : 2;
@@ -406,17 +406,23 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
     constexpr int S = pad4(NG);
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
     const uint32_t ucol = (uint32_t)col;
-    const uint32_t cb = ucol * (uint32_t)sizeof(R);
+    const uint32_t cb = ucol * (uint32_t)sizeof(R);          // workspace rows: compacted position
+    const int pc = ldg(A.perm, ucol * 4u);                   // API arrays: original column
+    const uint32_t cba = (uint32_t)pc * (uint32_t)sizeof(R);
     const SwBandTab<R> &Bt = T.b[IBM];
-    const bool ccol = CLD && ldg(A.colcloudy, ucol) != 0;
-    R prmu0 = ldg(A.coszen, cb);
+    // CLD kernels only see cloudy columns (DBG: all columns), so this is true there; it is deliberately left a run-time
+    // value: as a compile-time constant the if-converted code needs 290 registers and halves the occupancy
+    int ncl_opaque = nclear;
+    asm volatile("" : "+s"(ncl_opaque));        // hides the fact from the optimiser (the caller already tested col >= nclear)
+    const bool ccol = CLD && col >= ncl_opaque;
+    R prmu0 = ldg(A.coszen, cba);
     prmu0 = prmu0 > (R)1.e-10 ? prmu0 : (R)1.e-10;                     // zepzen (SW/rrtmg_sw_rad.F90:1365)
 
     // surface albedo of this band (:1230-1248)
     R albp, albd;
-    if (IBM <= 8 || IBM == 14) { albp = ldg(A.aldir, cb); albd = ldg(A.aldif, cb); }
-    else if (IBM >= 10) { albp = ldg(A.asdir, cb); albd = ldg(A.asdif, cb); }
-    else { albp = (ldg(A.asdir, cb) + ldg(A.aldir, cb)) / (R)2.; albd = (ldg(A.asdif, cb) + ldg(A.aldif, cb)) / (R)2.; }
+    if (IBM <= 8 || IBM == 14) { albp = ldg(A.aldir, cba); albd = ldg(A.aldif, cba); }
+    else if (IBM >= 10) { albp = ldg(A.asdir, cba); albd = ldg(A.asdif, cba); }
+    else { albp = (ldg(A.asdir, cba) + ldg(A.aldir, cba)) / (R)2.; albd = (ldg(A.asdif, cba) + ldg(A.aldif, cba)) / (R)2.; }
 
     // ---- solar source of the band's g-points (taumolNN tail sections) -----------------------------------
     R zinc[NG];          // adjflux * ssi (without the cosine)
@@ -468,7 +474,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 if (SV.isolvar < 0) src = sf[j];
                 else if (SV.isolvar <= 2) src = SV.svar_f * fb[j] + SV.svar_s * sd[j] + SV.svar_i * ir[j];
                 else src = SV.svar_bnd[IBM] * fb[j] + SV.svar_bnd[IBM] * sd[j] + SV.svar_bnd[IBM] * ir[j];
-                if (DBG) A.dbg_ssi[(size_t)col * NG_SW + G0 + g] = src;
+                if (DBG) A.dbg_ssi[(size_t)pc * NG_SW + G0 + g] = src;
                 zinc[g] = SV.adjflux[IBM] * src;
             }
         }
@@ -493,7 +499,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
         sw_prep<R, B>(T, L, P);
         R ta = 0, om = 1, as = 0;
         if (A.iaer == 10) {
-            const uint32_t ab = ((uint32_t)lay * (uint32_t)ld + ucol) * (uint32_t)sizeof(R);
+            const uint32_t ab = ((uint32_t)lay * (uint32_t)ld + (uint32_t)pc) * (uint32_t)sizeof(R);
             const size_t bo = (size_t)(IBM - 1) * nlay * ld;
             ta = ldg(A.tauaer + bo, ab); om = ldg(A.ssaaer + bo, ab); as = ldg(A.asmaer + bo, ab);
         }
@@ -508,7 +514,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 if (g >= NG) continue;
                 const uint32_t cb4 = (cell0 + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
                 if (DBG) {
-                    const size_t o = ((size_t)col * NG_SW + (G0 + g)) * nlay + lay;      // Fortran (nlay,112,ncol)
+                    const size_t o = ((size_t)pc * NG_SW + (G0 + g)) * nlay + lay;       // Fortran (nlay,112,ncol)
                     A.dbg_taug[o] = tg[j]; A.dbg_taur[o] = tr[j];
                 }
                 // clear-sky optical properties incl. aerosol, delta-scaled with f = g^2 (:413-437)
@@ -679,24 +685,30 @@ __host__ __device__ constexpr int sw_band_ng(int jb)
 template <typename R, bool CLD, bool DBG>
 __global__ void __launch_bounds__(256) k_sw_bands(SwArgs<R> A, SwDev<R> T, SwSolar<R> SV)
 {
-    if (!DBG && (A.blkcloudy[blockIdx.x] != 0) != CLD) return;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nclear = *A.nclear;
+    // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
+    // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
+    const int bstart = (int)(blockIdx.x * blockDim.x);
+    const int bend = bstart + (int)blockDim.x < A.ncol ? bstart + (int)blockDim.x : A.ncol;
+    if (!DBG && (CLD ? bend <= nclear : bstart >= nclear)) return;
+    const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
+    if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
     switch (SW_BAND_ORDER[blockIdx.y]) {
-        case 16: sw_band_body<R, SwB16, CLD, DBG>(A, T, SV, col); break;
-        case 17: sw_band_body<R, SwB17, CLD, DBG>(A, T, SV, col); break;
-        case 18: sw_band_body<R, SwB18, CLD, DBG>(A, T, SV, col); break;
-        case 19: sw_band_body<R, SwB19, CLD, DBG>(A, T, SV, col); break;
-        case 20: sw_band_body<R, SwB20, CLD, DBG>(A, T, SV, col); break;
-        case 21: sw_band_body<R, SwB21, CLD, DBG>(A, T, SV, col); break;
-        case 22: sw_band_body<R, SwB22, CLD, DBG>(A, T, SV, col); break;
-        case 23: sw_band_body<R, SwB23, CLD, DBG>(A, T, SV, col); break;
-        case 24: sw_band_body<R, SwB24, CLD, DBG>(A, T, SV, col); break;
-        case 25: sw_band_body<R, SwB25, CLD, DBG>(A, T, SV, col); break;
-        case 26: sw_band_body<R, SwB26, CLD, DBG>(A, T, SV, col); break;
-        case 27: sw_band_body<R, SwB27, CLD, DBG>(A, T, SV, col); break;
-        case 28: sw_band_body<R, SwB28, CLD, DBG>(A, T, SV, col); break;
-        default: sw_band_body<R, SwB29, CLD, DBG>(A, T, SV, col); break;
+        case 16: sw_band_body<R, SwB16, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 17: sw_band_body<R, SwB17, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 18: sw_band_body<R, SwB18, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 19: sw_band_body<R, SwB19, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 20: sw_band_body<R, SwB20, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 21: sw_band_body<R, SwB21, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 22: sw_band_body<R, SwB22, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 23: sw_band_body<R, SwB23, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 24: sw_band_body<R, SwB24, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 25: sw_band_body<R, SwB25, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 26: sw_band_body<R, SwB26, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 27: sw_band_body<R, SwB27, CLD, DBG>(A, T, SV, col, nclear); break;
+        case 28: sw_band_body<R, SwB28, CLD, DBG>(A, T, SV, col, nclear); break;
+        default: sw_band_body<R, SwB29, CLD, DBG>(A, T, SV, col, nclear); break;
     }
 }
 
@@ -710,7 +722,8 @@ __global__ void __launch_bounds__(256) k_sw_reduce(SwArgs<R> A, SwOut<R> O)
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ncol) return;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
-    const bool ccol = A.colcloudy[col] != 0;
+    const bool ccol = col >= *A.nclear;
+    const int pc = A.perm[col];                 // outputs go to the original column
     const size_t qs = (size_t)NB_SW * (nlay + 1) * n;
     // TOA downward total-sky flux for the optional normalisation (:1769-1771)
     R top = 0;
@@ -725,7 +738,7 @@ __global__ void __launch_bounds__(256) k_sw_reduce(SwArgs<R> A, SwOut<R> O)
             if (ccol) { s[2] += A.part[2 * qs + o]; s[3] += A.part[3 * qs + o]; }
         }
         if (!ccol) { s[2] = s[0]; s[3] = s[1]; }
-        const size_t i = (size_t)lev * ld + col;
+        const size_t i = (size_t)lev * ld + pc;
         if (A.normFlx == 1) { O.swuflxc[i] = s[0] / scale; O.swdflxc[i] = s[1] / scale; O.swuflx[i] = s[2] / scale; O.swdflx[i] = s[3] / scale; }
         else { O.swuflxc[i] = s[0]; O.swdflxc[i] = s[1]; O.swuflx[i] = s[2]; O.swdflx[i] = s[3]; }
     }
@@ -739,16 +752,16 @@ __global__ void __launch_bounds__(256) k_sw_reduce(SwArgs<R> A, SwOut<R> O)
         else { zparr += (R)0.5 * dir; zparf += (R)0.5 * fd; znirr += (R)0.5 * dir; znirf += (R)0.5 * fd; }
         R fnet = fd - fu, dr = dir, df = fd - dir;
         if (A.normFlx == 1) { fnet = fnet / scale; dr = dr / scale; df = df / scale; }
-        O.fswband[(size_t)(ibm - 1) * ld + col] = fnet;
-        if (A.do_drfband) { O.drband[(size_t)(ibm - 1) * ld + col] = dr; O.dfband[(size_t)(ibm - 1) * ld + col] = df; }
+        O.fswband[(size_t)(ibm - 1) * ld + pc] = fnet;
+        if (A.do_drfband) { O.drband[(size_t)(ibm - 1) * ld + pc] = dr; O.dfband[(size_t)(ibm - 1) * ld + pc] = df; }
     }
     R o6[6] = {znirr, znirf - znirr, zparr, zparf - zparr, zuvrr, zuvrf - zuvrr};
     if (A.normFlx == 1) for (int k = 0; k < 6; k++) o6[k] = o6[k] / scale;
-    O.nirr[col] = o6[0]; O.nirf[col] = o6[1]; O.parr[col] = o6[2]; O.parf[col] = o6[3]; O.uvrr[col] = o6[4]; O.uvrf[col] = o6[5];
+    O.nirr[pc] = o6[0]; O.nirf[pc] = o6[1]; O.parr[pc] = o6[2]; O.parf[pc] = o6[3]; O.uvrr[pc] = o6[4]; O.uvrf[pc] = o6[5];
     for (int k = 0; k < 8; k++) {
         R s = 0;
         if (ccol) for (int b = 0; b < 3; b++) s += A.cot[(size_t)(k * 3 + b) * n + col];
-        O.cot[k][col] = s;
+        O.cot[k][pc] = s;
     }
 }
 
