@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/geosrad.h"
@@ -95,18 +96,6 @@ static KissJump make_kiss_jump(uint64_t n)
     J.K4 = powmod(30903u, n, 30903ull * 65536ull - 1ull);
     return J;
 }
-// segments of the sub-column range; jump distance = first sub-column * draws per sub-column
-static McSeg make_segments(const int *start, int nseg, int nlay, bool inhomo)
-{
-    McSeg S;
-    memset(&S, 0, sizeof S);
-    S.nseg = nseg;
-    for (int s = 0; s <= nseg; s++) S.start[s] = start[s];
-    const uint64_t per = (uint64_t)(inhomo ? 4 : 2) * (uint64_t)nlay;
-    for (int s = 0; s < nseg; s++) S.j[s] = make_kiss_jump((uint64_t)start[s] * per);
-    return S;
-}
-
 // staging of one coefficient blob into GPU-friendly layouts: k-table rows [index][NGP = pad4(ng)] so that a lane
 // fetches 4 consecutive g-points of its own row with one 16-byte load
 template <typename R> struct TableStage {
@@ -295,6 +284,9 @@ template <typename R> struct Ctx : geosrad_ctx {
     SwDev<R> *d_S = nullptr;
     bool have_sw = false;
     char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0;
+    // McICA segment plans (jump-ahead constants), cached per (mode, nsubcol, nlay, inhomogeneous?)
+    struct PlanEntry { McSegDev *d_seg; int nseg; KissJump jsub, jhalf; };
+    std::map<std::tuple<int, int, int, int>, PlanEntry> plans;
     // workspace
     char *d_ws = nullptr; size_t ws_bytes = 0; int ws_ncol = 0, ws_nlay = 0;
     uint32_t *d_err = nullptr;
@@ -308,6 +300,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_xcw) (void)hipFree(d_xcw);
         if (d_T) (void)hipFree(d_T);
         if (d_ws) (void)hipFree(d_ws);
+        for (auto &pe : plans) if (pe.second.d_seg) (void)hipFree(pe.second.d_seg);
         if (d_tab_sw) (void)hipFree(d_tab_sw);
         if (d_S) (void)hipFree(d_S);
         if (d_ws_sw) (void)hipFree(d_ws_sw);
@@ -517,6 +510,42 @@ template <typename R> struct Ctx : geosrad_ctx {
         return GEOSRAD_OK;
     }
 
+
+    // quads of sub-columns that never straddle a band; jump distances in units of draws
+    int mc_plan(int mode, int nsubcol, int nlay, McPlan &out, int &nseg_out)
+    {
+        const bool inhomo = h_T.xcw != nullptr;
+        const auto key = std::make_tuple(mode, nsubcol, nlay, inhomo ? 1 : 0);
+        auto it = plans.find(key);
+        if (it == plans.end()) {
+            std::vector<McSegDev> segs;
+            const uint64_t per = (uint64_t)(inhomo ? 4 : 2) * (uint64_t)nlay;
+            auto add_range = [&](int g0, int ng, int band) {
+                for (int q = 0; q < ng; q += MC_S) {
+                    McSegDev sd;
+                    memset(&sd, 0, sizeof sd);
+                    sd.start = g0 + q; sd.count = (ng - q) < MC_S ? (ng - q) : MC_S; sd.band = band;
+                    sd.j = make_kiss_jump((uint64_t)sd.start * per);
+                    segs.push_back(sd);
+                }
+            };
+            if (mode == 0) for (int b = 1; b <= NB_LW; b++) add_range(lw_band_g0(b), lw_band_ng(b), b);
+            else if (mode == 2) for (int b = 16; b <= 29; b++) add_range(sw_band_g0(b), sw_band_ng(b), b);
+            else add_range(0, nsubcol, 0);
+            PlanEntry pe;
+            pe.nseg = (int)segs.size();
+            pe.jsub = make_kiss_jump(per);
+            pe.jhalf = make_kiss_jump(2ull * (uint64_t)nlay);
+            pe.d_seg = nullptr;
+            HIPCHK(hipMalloc((void **)&pe.d_seg, segs.size() * sizeof(McSegDev)));
+            HIPCHK(hipMemcpy(pe.d_seg, segs.data(), segs.size() * sizeof(McSegDev), hipMemcpyHostToDevice));
+            it = plans.emplace(key, pe).first;
+        }
+        out.seg = it->second.d_seg; out.jsub = it->second.jsub; out.jhalf = it->second.jhalf;
+        nseg_out = it->second.nseg;
+        return GEOSRAD_OK;
+    }
+
     // ---- RRTMG_LW, device pointers ---------------------------------------------------------------------------
     int lw_dev(hipStream_t st, int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr,
                int cloudLM, int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output, void *dbg_taug,
@@ -582,10 +611,11 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
             M.taucmc = A.taucmc; M.laycloudy = A.laycloudy; M.clearCounts = A.clearCounts; M.err = d_err;
             {
-                static const int bstart[17] = {0, 10, 22, 38, 52, 68, 76, 88, 96, 108, 114, 122, 130, 134, 136, 138, 140};
-                const McSeg SG = make_segments(bstart, NB_LW, nlay, h_T.xcw != nullptr);
+                McPlan MP; int nseg = 0;
+                rc = mc_plan(0, NG_LW, nlay, MP, nseg);
+                if (rc) return rc;
                 span_begin(3, st);
-                hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), NB_LW), dim3(64), 0, st, M, SG, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+                hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
                 span_end(st);
             }
             span_begin(4, st);
@@ -910,10 +940,11 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
             M.taucmc = A.taucmc; M.ssacmc = A.ssacmc; M.asmcmc = A.asmcmc; M.cotsum = A.cotsum; M.clearCounts = A.clearCounts; M.err = d_err + 1;
             {
-                static const int bstart[15] = {0, 6, 18, 26, 34, 44, 54, 56, 66, 74, 80, 86, 94, 100, 112};
-                const McSeg SG = make_segments(bstart, NB_SW, nlay, h_T.xcw != nullptr);
+                McPlan MP; int nseg = 0;
+                rc = mc_plan(2, NG_SW, nlay, MP, nseg);
+                if (rc) return rc;
                 span_begin(3, st);
-                hipLaunchKernelGGL((k_mcica<R, 2>), dim3((unsigned)((nc + 63) / 64), NB_SW), dim3(64), 0, st, M, SG, (const LwDev<R> *)d_T,
+                hipLaunchKernelGGL((k_mcica<R, 2>), dim3((unsigned)((nc + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T,
                                    (const SwDev<R> *)d_S);
                 span_end(st);
             }
@@ -1032,10 +1063,10 @@ template <typename R> struct Ctx : geosrad_ctx {
         M.play = (const R *)(d_io + o_p); M.cldf = (const R *)(d_io + o_f); M.ciwp = (const R *)(d_io + o_i); M.clwp = (const R *)(d_io + o_l);
         M.alpha = (const R *)(d_io + o_al); M.rcorr = (const R *)(d_io + o_rc);
         M.cldy = (int32_t *)(d_io + o_cy); M.ciwp_s = (R *)(d_io + o_ci); M.clwp_s = (R *)(d_io + o_cl);
-        int nseg = nsubcol < 16 ? nsubcol : 16, sstart[17];
-        for (int s = 0; s <= nseg; s++) sstart[s] = (int)((long)s * nsubcol / nseg);
-        const McSeg SG = make_segments(sstart, nseg, nlay, h_T.xcw != nullptr);
-        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, stream, M, SG, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+        McPlan MP; int nseg = 0;
+        rc = mc_plan(1, nsubcol, nlay, MP, nseg);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, stream, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(cldy, d_io + o_cy, co * 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(ciwp_s, d_io + o_ci, co * sizeof(R), hipMemcpyDeviceToHost, stream));

@@ -64,7 +64,6 @@ template <typename R> GR_DEV R kiss_next(Kiss &k)
 //         canonical residue in [0, m) (or the fixed points 0 / m), so the jump is one modular multiply.
 // The constants are computed on the host (geosrad.hip: make_kiss_jump) and passed by value.
 struct KissJump { uint32_t A1, C1, K3, K4; uint32_t M2[32]; };
-struct McSeg { int nseg; int start[17]; KissJump j[16]; };   // segment s covers sub-columns [start[s], start[s+1])
 
 GR_DEV uint32_t mwc_jump(uint32_t s, uint32_t K, uint32_t m)
 {
@@ -278,18 +277,25 @@ GR_DEV void sw_cloud_optics(const SwDev<R> &S, int iceflag, int jb, R ciwp, R cl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_mcica: one thread per (column, segment of sub-columns); blockIdx.y = segment.  The column's KISS stream is
-// seeded as in the reference and jumped ahead to the segment's first sub-column (see KissJump), then walked
-// sequentially over (sub-column, layer) exactly like the reference's stream.
-//   MODE 0 (RRTMG_LW): segments = the 16 bands; fused generate_stochastic_clouds + clearCounts_threeBand +
-//          cldprmc: writes taucmc (band-major plane layout), ORs laycloudy[lay][col], adds clearCounts(ncol,4).
-//   MODE 1 (stand-alone generator API): up to 16 equal segments; writes cldy/ciwp_stoch/clwp_stoch Fortran
-//          (nlay,nsubcol,ncol).
-//   MODE 2 (RRTMG_SW): segments = the 14 bands (sub-column == g-point); fused generator + clearCounts + cldprmc_sw:
-//          writes taucmc / ssacmc / asmcmc planes, the PAR bands' super-layer sums of the un-scaled tau (cotsum).
-// Two passes per sub-column: pass 1 draws (cdf1,cdf2) for every layer and parks the cloud-presence
-// decision in the output cell; pass 2 draws (cdf2,cdf3) and finishes the cell.  No per-thread arrays.
+// k_mcica: one thread per (column, segment of <= 4 consecutive sub-columns of one band); blockIdx.y = segment.
+// The reference draws one KISS stream per column, sequentially over (sub-column, layer): per sub-column 2*nlay numbers
+// for the cloud-presence pass and, with inhomogeneous condensate, 2*nlay more for the condensate pass
+// (cloud_subcol_gen.F90:402-466).  Here every sub-column of the segment gets its own two stream positions by
+// jump-ahead (KissJump): the column's freshly seeded state is advanced to the segment's first sub-column, from there by
+// one sub-column per step, and by 2*nlay to the condensate pass.  The thread then walks the LAYERS once, advancing all its
+// streams together, so each layer's inputs (overlap correlations, cloud fraction, water paths, radii) are read once
+// per segment instead of once per sub-column, and each output cell is written exactly once.
+//   MODE 0 (RRTMG_LW): segments = quads of the 16 bands' g-points; fused generate_stochastic_clouds +
+//          clearCounts_threeBand + cldprmc: writes taucmc (band-major plane layout), ORs laycloudy[lay][col],
+//          adds clearCounts(ncol,4).
+//   MODE 1 (stand-alone generator API): quads of sub-columns; writes cldy/ciwp_stoch/clwp_stoch Fortran (nlay,nsubcol,ncol).
+//   MODE 2 (RRTMG_SW): quads of the 14 bands' g-points; fused generator + clearCounts + cldprmc_sw: writes
+//          taucmc / ssacmc / asmcmc planes and the PAR bands' super-layer sums of the un-scaled tau (cotsum).
 // ---------------------------------------------------------------------------------------------------
+constexpr int MC_S = 4;      // sub-columns per thread
+struct McSegDev { int start, count, band, pad; KissJump j; };      // j: jump to sub-column `start` (unused when start == 0)
+struct McPlan { const McSegDev *seg; KissJump jsub, jhalf; };      // jsub: one sub-column ahead; jhalf: 2*nlay ahead
+
 template <typename R> struct McArgs {
     int ncol, ld, nlay, nsubcol, doy, cloudLM, cloudMH, iceflg, liqflg;
     int so[4];
@@ -306,135 +312,125 @@ template <typename R> struct McArgs {
 };
 
 template <typename R, int MODE>
-__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McSeg SG, const LwDev<R> *__restrict__ Tp, const SwDev<R> *__restrict__ Sp)
+__global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev<R> *__restrict__ Tp, const SwDev<R> *__restrict__ Sp)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    const int seg = blockIdx.y;
     if (col >= M.ncol) return;
     if (M.nclear && col < *M.nclear) return;      // clear columns: nothing to generate
     const int pc = M.perm ? M.perm[col] : col;    // API arrays are indexed by the original column
     const LwDev<R> &T = *Tp;
+    const McSegDev &SG = P.seg[blockIdx.y];
+    const int s0 = SG.start, ns = SG.count, ib = SG.band;     // uniform over the block
     const int n = M.ncol, ld = M.ld, nlay = M.nlay;
     const bool inhomo = T.xcw != nullptr;
+    constexpr bool PLANES = MODE == 0 || MODE == 2;
     // vertical ordering is detected from the first column of the call (cloud_subcol_gen.F90:266)
     const bool surface_at_one = M.play[0] > M.play[(size_t)(nlay - 1) * ld];
-    Kiss ks = kiss_seed<R>(M.play, ld, nlay, pc, surface_at_one, M.so);
+
+    // stream positions of the segment's sub-columns: k1 = presence pass, k2 = condensate pass
+    Kiss k1[MC_S], k2[MC_S];
+    k1[0] = kiss_seed<R>(M.play, ld, nlay, pc, surface_at_one, M.so);
     // n = 0 must stay the identity: a raw seed may exceed the MWC modulus (non-canonical), which mwc_jump would reduce
-    if (SG.start[seg] > 0) kiss_jump(ks, SG.j[seg]);
-    uint32_t err = 0;
+    if (s0 > 0) kiss_jump(k1[0], SG.j);
+#pragma unroll
+    for (int s = 1; s < MC_S; s++) { k1[s] = k1[s - 1]; if (s < ns) kiss_jump(k1[s], P.jsub); }
+#pragma unroll
+    for (int s = 0; s < MC_S; s++) { k2[s] = k1[s]; if (inhomo && s < ns) kiss_jump(k2[s], P.jhalf); }
 
     // pressure super-layer bounds, 0-based inclusive (cloud_subcol_gen.F90:617-632)
     int lo0, lo1, mi0, mi1, hi0, hi1;
     if (M.cloudLM < M.cloudMH) { lo0 = 0; lo1 = M.cloudLM - 1; mi0 = M.cloudLM; mi1 = M.cloudMH - 1; hi0 = M.cloudMH; hi1 = nlay - 1; }
     else { hi0 = 0; hi1 = M.cloudMH - 2; mi0 = M.cloudMH - 1; mi1 = M.cloudLM - 2; lo0 = M.cloudLM - 1; lo1 = nlay - 1; }
-    int cnt_all = 0, cnt_hi = 0, cnt_mid = 0, cnt_lo = 0;
 
-    const int ib = MODE == 0 ? seg + 1 : (MODE == 2 ? seg + 16 : 0);     // MODE 0 / 2: segment == band
+    // plane layout (see band_body): band-major, then [layer][g-in-band][column]
     const int bg0 = MODE == 0 ? lw_band_g0(ib) : (MODE == 2 ? sw_band_g0(ib) : 0);
     const int bng = MODE == 0 ? lw_band_ng(ib) : (MODE == 2 ? sw_band_ng(ib) : 0);
-    constexpr bool PLANES = MODE == 0 || MODE == 2;
-    for (int is = SG.start[seg]; is < SG.start[seg + 1]; is++) {
-        // taucmc plane layout (see band_body): band-major, then [layer][g-in-band][column]
-        const size_t tb0 = PLANES ? (size_t)bg0 * nlay * n + (size_t)(is - bg0) * n + col : 0;
-        const size_t tbs = PLANES ? (size_t)bng * n : 0;     // + il * tbs
-        R cs_lo = 0, cs_mid = 0, cs_hi = 0;                  // MODE 2: super-layer sums of taormc (spcvmc :760-800)
-        bool any_all = false, any_hi = false, any_mid = false, any_lo = false;
-        // ---- pass 1: cloud presence with exponential overlap (:406-414) ----
-        R cprev = 0;
-        for (int il = 0; il < nlay; il++) {
-            R cdf1 = kiss_next<R>(ks);
-            const R cdf2 = kiss_next<R>(ks);
-            const size_t w = (size_t)il * n + col, a = (size_t)il * ld + pc;
-            if (il > 0 && cdf2 < M.alpha[w]) cdf1 = cprev;
-            cprev = cdf1;
-            const R cf = M.cldf[a];
-            const bool cloudy = cdf1 >= nf_sub((R)1., cf);
-            if (!inhomo) {
-                // homogeneous condensate: finish the cell now (:438-443)
-                R ci = 0, cl = 0; bool c = false;
+    const size_t tb0 = PLANES ? (size_t)bg0 * nlay * n + (size_t)(s0 - bg0) * n + col : 0;     // + s*n + il*tbs
+    const size_t tbs = PLANES ? (size_t)bng * n : 0;
+
+    R cprev[MC_S], c3prev[MC_S], cs_lo[MC_S], cs_mid[MC_S], cs_hi[MC_S];
+#pragma unroll
+    for (int s = 0; s < MC_S; s++) { cprev[s] = 0; c3prev[s] = 0; cs_lo[s] = 0; cs_mid[s] = 0; cs_hi[s] = 0; }
+    uint32_t any_all = 0, any_hi = 0, any_mid = 0, any_lo = 0;      // bit s: sub-column s has a cloudy cell (in the super-layer)
+    uint32_t err = 0;
+
+    for (int il = 0; il < nlay; il++) {
+        const size_t w = (size_t)il * n + col, a = (size_t)il * ld + pc;
+        const R al = il > 0 ? M.alpha[w] : (R)0;
+        const R rc = (inhomo && il > 0) ? M.rcorr[w] : (R)0;
+        const R cf = M.cldf[a], ciw = M.ciwp[a], clw = M.clwp[a];
+        const R rei = PLANES ? M.rei[a] : (R)0, rel = PLANES ? M.rel[a] : (R)0;
+        const R thr = nf_sub((R)1., cf);
+        const R sigma = cf > (R)0.99 ? (R)0.5 : (cf > (R)0.9 ? (R)0.71 : (R)1.0);
+        const bool in_hi = il >= hi0 && il <= hi1, in_mid = il >= mi0 && il <= mi1, in_lo = il >= lo0 && il <= lo1;
+#pragma unroll
+        for (int s = 0; s < MC_S; s++) {
+            if (s >= ns) continue;
+            // cloud presence with exponential overlap (:406-414)
+            R cdf1 = kiss_next<R>(k1[s]);
+            const R cdf2 = kiss_next<R>(k1[s]);
+            if (il > 0 && cdf2 < al) cdf1 = cprev[s];
+            cprev[s] = cdf1;
+            const bool cloudy = cdf1 >= thr;
+            R ci = 0, cl = 0;
+            if (inhomo) {
+                // condensate with exponential overlap + inhomogeneity (:416-466); the stream is consumed for every layer
+                const R c2 = kiss_next<R>(k2[s]);
+                R cdf3 = kiss_next<R>(k2[s]);
+                if (il > 0 && c2 < rc) cdf3 = c3prev[s];
+                c3prev[s] = cdf3;
                 if (cloudy) {
-                    ci = M.ciwp[a]; cl = M.clwp[a];
-                    const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
-                    if (cin) ci = 0;
-                    if (cln) cl = 0;
-                    c = !(cin && cln);
-                }
-                if (c) { any_all = true; if (il >= hi0 && il <= hi1) any_hi = true; if (il >= mi0 && il <= mi1) any_mid = true; if (il >= lo0 && il <= lo1) any_lo = true; }
-                if (MODE == 0) {
-                    R tau = 0;
-                    if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
-                    M.taucmc[tb0 + (size_t)il * tbs] = tau;
-                    if (tau > 0) M.laycloudy[w] = 1;
-                } else if (MODE == 2) {
-                    R taor = 0, tauc = 0, ssac = 1, asmc = 0;
-                    if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], taor, tauc, ssac, asmc);
-                    const size_t oc = tb0 + (size_t)il * tbs;
-                    M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
-                    if (il < M.cloudLM) cs_lo += taor; else if (il < M.cloudMH) cs_mid += taor; else cs_hi += taor;
-                } else {
-                    const size_t o = ((size_t)col * M.nsubcol + is) * nlay + il;
-                    M.cldy[o] = c ? 1 : 0; M.ciwp_s[o] = ci; M.clwp_s[o] = cl;
-                }
-            } else {
-                if (PLANES) M.taucmc[tb0 + (size_t)il * tbs] = cloudy ? (R)1 : (R)0;
-                else M.cldy[((size_t)col * M.nsubcol + is) * nlay + il] = cloudy ? 1 : 0;
-            }
-        }
-        // ---- pass 2: condensate with exponential overlap + inhomogeneity (:416-466) ----
-        if (inhomo) {
-            R c3prev = 0;
-            for (int il = 0; il < nlay; il++) {
-                const R cdf2 = kiss_next<R>(ks);
-                R cdf3 = kiss_next<R>(ks);
-                const size_t w = (size_t)il * n + col, a = (size_t)il * ld + pc;
-                if (il > 0 && cdf2 < M.rcorr[w]) cdf3 = c3prev;
-                c3prev = cdf3;
-                const size_t oc = PLANES ? tb0 + (size_t)il * tbs : ((size_t)col * M.nsubcol + is) * nlay + il;
-                bool cloudy;
-                if constexpr (PLANES) cloudy = M.taucmc[oc] != (R)0; else cloudy = M.cldy[oc] != 0;
-                R ci = 0, cl = 0; bool c = false;
-                if (cloudy) {
-                    const R cf = M.cldf[a];
-                    const R sigma = cf > (R)0.99 ? (R)0.5 : (cf > (R)0.9 ? (R)0.71 : (R)1.0);
                     const R zcw = zcw_lookup<R>(T.xcw, cdf3, sigma);
-                    ci = nf_mul(M.ciwp[a], zcw); cl = nf_mul(M.clwp[a], zcw);
-                    const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
-                    if (cin) ci = 0;
-                    if (cln) cl = 0;
-                    c = !(cin && cln);
+                    ci = nf_mul(ciw, zcw); cl = nf_mul(clw, zcw);
                 }
-                if (c) { any_all = true; if (il >= hi0 && il <= hi1) any_hi = true; if (il >= mi0 && il <= mi1) any_mid = true; if (il >= lo0 && il <= lo1) any_lo = true; }
-                if (MODE == 0) {
-                    R tau = 0;
-                    if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], err);
-                    M.taucmc[oc] = tau;
-                    if (tau > 0) M.laycloudy[w] = 1;
-                } else if (MODE == 2) {
-                    R taor = 0, tauc = 0, ssac = 1, asmc = 0;
-                    if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, M.rei[a], M.rel[a], taor, tauc, ssac, asmc);
-                    M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
-                    if (il < M.cloudLM) cs_lo += taor; else if (il < M.cloudMH) cs_mid += taor; else cs_hi += taor;
-                } else {
-                    M.cldy[oc] = c ? 1 : 0; M.ciwp_s[oc] = ci; M.clwp_s[oc] = cl;
-                }
+            } else if (cloudy) { ci = ciw; cl = clw; }      // homogeneous condensate (:438-443)
+            bool c = false;
+            if (cloudy) {
+                const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
+                if (cin) ci = 0;
+                if (cln) cl = 0;
+                c = !(cin && cln);
+            }
+            if (c) {
+                any_all |= 1u << s;
+                if (in_hi) any_hi |= 1u << s;
+                if (in_mid) any_mid |= 1u << s;
+                if (in_lo) any_lo |= 1u << s;
+            }
+            if (MODE == 0) {
+                R tau = 0;
+                if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, rei, rel, err);
+                M.taucmc[tb0 + (size_t)s * n + (size_t)il * tbs] = tau;
+                if (tau > 0) M.laycloudy[w] = 1;
+            } else if (MODE == 2) {
+                R taor = 0, tauc = 0, ssac = 1, asmc = 0;
+                if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, rei, rel, taor, tauc, ssac, asmc);
+                const size_t oc = tb0 + (size_t)s * n + (size_t)il * tbs;
+                M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
+                // super-layer sums of the un-scaled tau for the PAR diagnostics (SW/rrtmg_sw_spcvmc.F90:760-800)
+                if (il < M.cloudLM) cs_lo[s] += taor; else if (il < M.cloudMH) cs_mid[s] += taor; else cs_hi[s] += taor;
+            } else {
+                const size_t o = ((size_t)col * M.nsubcol + (s0 + s)) * nlay + il;
+                M.cldy[o] = c ? 1 : 0; M.ciwp_s[o] = ci; M.clwp_s[o] = cl;
             }
         }
-        if (MODE == 2 && ib >= 24 && ib <= 26) {
-            M.cotsum[((size_t)0 * 112 + is) * n + col] = cs_lo;
-            M.cotsum[((size_t)1 * 112 + is) * n + col] = cs_mid;
-            M.cotsum[((size_t)2 * 112 + is) * n + col] = cs_hi;
+    }
+    if (MODE == 2 && ib >= 24 && ib <= 26) {
+#pragma unroll
+        for (int s = 0; s < MC_S; s++) {
+            if (s >= ns) continue;
+            M.cotsum[((size_t)0 * 112 + s0 + s) * n + col] = cs_lo[s];
+            M.cotsum[((size_t)1 * 112 + s0 + s) * n + col] = cs_mid[s];
+            M.cotsum[((size_t)2 * 112 + s0 + s) * n + col] = cs_hi[s];
         }
-        if (!any_all) cnt_all++;
-        if (!any_hi) cnt_hi++;
-        if (!any_mid) cnt_mid++;
-        if (!any_lo) cnt_lo++;
     }
     if (PLANES) {
-        // integer adds: order-independent, bitwise reproducible (k_validate_pwv zeroed the cloudy columns' counts)
-        atomicAdd(&M.clearCounts[(size_t)0 * ld + pc], cnt_all);
-        atomicAdd(&M.clearCounts[(size_t)1 * ld + pc], cnt_hi);
-        atomicAdd(&M.clearCounts[(size_t)2 * ld + pc], cnt_mid);
-        atomicAdd(&M.clearCounts[(size_t)3 * ld + pc], cnt_lo);
+        // integer adds: order-independent, bitwise reproducible (the validate kernel zeroed the cloudy columns' counts)
+        const uint32_t act = (1u << ns) - 1u;
+        atomicAdd(&M.clearCounts[(size_t)0 * ld + pc], __popc(~any_all & act));
+        atomicAdd(&M.clearCounts[(size_t)1 * ld + pc], __popc(~any_hi & act));
+        atomicAdd(&M.clearCounts[(size_t)2 * ld + pc], __popc(~any_mid & act));
+        atomicAdd(&M.clearCounts[(size_t)3 * ld + pc], __popc(~any_lo & act));
         if (err) atomicOr(M.err, err);
     }
 }

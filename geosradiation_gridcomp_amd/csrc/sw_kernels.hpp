@@ -491,8 +491,10 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
     R tdbt[NG], ztdn[NG], prdnd[NG], tdbtT[NG], ztdnT[NG], prdndT[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) { tdbt[g] = 1; ztdn[g] = 1; prdnd[g] = 0; tdbtT[g] = 1; ztdnT[g] = 1; prdndT[g] = 0; }
+    uint32_t cmask = 0;      // bit g: the layer processed last (finally: the surface layer) is cloudy in sub-column g
     for (int jk = 0; jk < nlay; jk++) {
         const int lay = nlay - 1 - jk;
+        cmask = 0;
         SwLayer<R> L;
         sw_load_layer<R>(A, lay, col, L);
         SwPrep<R> P;
@@ -545,7 +547,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 if (CLD && ccol) {
                     // total sky: cloudy cells get the (already delta-scaled) cloud optics added (:512-536, 541, 547-559)
                     const R tc = ldg(tcb, cb4);
-                    if (tc > 0) {
+                    const bool cellcld = tc > 0;
+                    if (cellcld) {
                         const R oc = ldg(ocb, cb4), gc = ldg(gcb, cb4);
                         R g2 = ztauo * zomco * zgco + tc * oc * gc;
                         R o2 = ztauo * zomco + tc * oc;
@@ -553,6 +556,10 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                         g2 = g2 / o2; o2 = o2 / t2;
                         sw_reftra<R>(t2, o2, g2, prmu0, ref, refd, tra, trad);
                         dbt = gr_exp<R>(-t2 / prmu0);
+                        cmask |= 1u << g;
+                        // total-sky layer properties are parked for cloudy cells only (elsewhere they equal the clear-sky ones)
+                        stg(CELL(8), cb4, ref); stg(CELL(9), cb4, refd); stg(CELL(10), cb4, tra); stg(CELL(11), cb4, trad);
+                        stg(CELL(12), cb4, dbt);
                     }
                     R zt, pr;
                     if (jk == 0) { zt = tra; pr = refd; }
@@ -562,8 +569,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                         pr = refd + trad * trad * prdndT[g] * zreflect;
                     }
                     tdbtT[g] = dbt * tdbtT[g]; ztdnT[g] = zt; prdndT[g] = pr;
-                    stg(CELL(8), cb4, ref); stg(CELL(9), cb4, refd); stg(CELL(10), cb4, tra); stg(CELL(11), cb4, trad);
-                    stg(CELL(12), cb4, dbt); stg(CELL(13), cb4, tdbtT[g]); stg(CELL(14), cb4, ztdnT[g]); stg(CELL(15), cb4, prdndT[g]);
+                    // the sign bit of the parked T_dir^cum (>= 0) carries "this layer is cloudy" to sweep B
+                    stg(CELL(13), cb4, cellcld ? -tdbtT[g] : tdbtT[g]); stg(CELL(14), cb4, ztdnT[g]); stg(CELL(15), cb4, prdndT[g]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -609,13 +616,14 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
         const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
         const uint32_t cellu = ((uint32_t)(lay + 1) * (uint32_t)NG) * (uint32_t)n + ucol;    // layer above: holds this level's tdbt/ztdn/prdnd
         R cu = 0, cd = 0, fu = 0, fd = 0;
+        uint32_t cnext = 0;
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const uint32_t c4 = (cell0 + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
             const uint32_t u4 = (cellu + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
             const R zi = zinc[g] * prmu0;
+            R ref = ldg(CELL(0), c4), refd = ldg(CELL(1), c4), tra = ldg(CELL(2), c4), trad = ldg(CELL(3), c4), dbt = ldg(CELL(4), c4);
             {
-                const R ref = ldg(CELL(0), c4), refd = ldg(CELL(1), c4), tra = ldg(CELL(2), c4), trad = ldg(CELL(3), c4), dbt = ldg(CELL(4), c4);
                 const R zrj = (R)1. / ((R)1. - prupd[g] * refd);
                 const R pu = ref + (trad * ((tra - dbt) * prupd[g] + dbt * prup[g])) * zrj;
                 const R pd = refd + trad * trad * prupd[g] * zrj;
@@ -627,13 +635,18 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 cd = cd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
             }
             if (CLD && ccol) {
-                const R ref = ldg(CELL(8), c4), refd = ldg(CELL(9), c4), tra = ldg(CELL(10), c4), trad = ldg(CELL(11), c4), dbt = ldg(CELL(12), c4);
+                if (cmask & (1u << g)) {
+                    ref = ldg(CELL(8), c4); refd = ldg(CELL(9), c4); tra = ldg(CELL(10), c4); trad = ldg(CELL(11), c4); dbt = ldg(CELL(12), c4);
+                }
                 const R zrj = (R)1. / ((R)1. - prupdT[g] * refd);
                 const R pu = ref + (trad * ((tra - dbt) * prupdT[g] + dbt * prupT[g])) * zrj;
                 const R pd = refd + trad * trad * prupdT[g] * zrj;
                 prupT[g] = pu; prupdT[g] = pd;
                 R tb = 1, zt = 1, pr = 0;
-                if (jk > 0) { tb = ldg(CELL(13), u4); zt = ldg(CELL(14), u4); pr = ldg(CELL(15), u4); }
+                if (jk > 0) {
+                    tb = ldg(CELL(13), u4); zt = ldg(CELL(14), u4); pr = ldg(CELL(15), u4);
+                    if (__builtin_signbit(tb)) { cnext |= 1u << g; tb = -tb; }
+                }
                 const R zr = (R)1. / ((R)1. - pr * pd);
                 fu = fu + zi * ((tb * pu + (zt - tb) * pd) * zr);
                 fd = fd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
@@ -641,6 +654,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
         }
         PART(0, lay + 1, cu); PART(1, lay + 1, cd);
         if (CLD && ccol) { PART(2, lay + 1, fu); PART(3, lay + 1, fd); }
+        cmask = cnext;
     }
 #undef PART
 #undef CELL
