@@ -342,51 +342,89 @@ GR_DEV void sw_eval(const SwDev<R> &T, const SwLayer<R> &L, const SwPrep<R> &P, 
         for (int j = 0; j < W; j++) ray[j] = L.colmol * t[j];
     }
 }
-// layer reflectance / transmittance, PIFM two-stream (SW/rrtmg_sw_spcvmc.F90:1236-1362)
-template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R &ref, R &refd, R &tra, R &trad)
+// Fast-path arithmetic of the fp32 instantiation: 1-ulp hardware reciprocal / sqrt / exp2 instead of the correctly rounded
+// (10-instruction) IEEE sequences.  The per-cell two-stream needs ~16 divisions, which made half of the instruction count;
+// the differences (<= 2 ulp per operation) are of the size of fp32 rounding itself and far inside the parity tolerance of
+// the fp32 path (tests/test_gpu_sw.py).  The fp64 instantiation keeps exact IEEE operations (parity <= 1e-6 W m-2).
+template <typename R> GR_DEV R f_rcp(R x);
+template <> GR_DEV float f_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <> GR_DEV double f_rcp<double>(double x) { return 1.0 / x; }
+template <typename R> GR_DEV R f_div(R a, R b);
+template <> GR_DEV float f_div<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+template <> GR_DEV double f_div<double>(double a, double b) { return a / b; }
+template <typename R> GR_DEV R f_sqrt(R x);
+template <> GR_DEV float f_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <> GR_DEV double f_sqrt<double>(double x) { return sqrt(x); }
+template <typename R> GR_DEV R f_exp(R x);
+template <> GR_DEV float f_exp<float>(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+template <> GR_DEV double f_exp<double>(double x) { return exp(x); }
+
+// `zwo >= zwcrit` of reftra_sw (SW/rrtmg_sw_spcvmc.F90:1207,1260-1262).  The reference evaluates the un-scaled single
+// scattering albedo zwo = w / (1 - (1-w) (g/(1-g))^2) in real(8) even in the default-real build, rounds it to default real
+// and compares.  fp64: exactly that.  fp32: the same predicate cross-multiplied (no fp64 division), comparing against the
+// rounding boundary of the float constant.
+template <typename R> GR_DEV bool sw_conservative(R zw, R zg);
+template <> GR_DEV bool sw_conservative<double>(double zw, double zg)
 {
-    const R eps = (R)1.e-08, zwcrit = (R)0.9999995, od_lo = (R)0.06;
+    const double q = zg / (1.0 - zg);
+    const double zwo = zw / (1.0 - (1.0 - zw) * (q * q));
+    return zwo >= 0.9999995;
+}
+template <> GR_DEV bool sw_conservative<float>(float zw, float zg)
+{
+    // (float)x >= c  <=>  x >= midpoint(prev(c), c) =: m   (c = 0.9999995f = 1 - 8 * 2^-24; ulp below 1 is 2^-24)
+    const double m = (double)0.9999995f - 0.5 * 5.9604644775390625e-08;
+    const double w = zw, g = zg, omg = 1.0 - g;
+    const double a = omg * omg, d = a - (1.0 - w) * (g * g);       // zwo = w a / d
+    if (d > 0.0) return w * a >= m * d;
+    return d == 0.0 ? w > 0.0 : false;                            // +inf >= c ; negative zwo never is
+}
+
+// layer reflectance / transmittance, PIFM two-stream (SW/rrtmg_sw_spcvmc.F90:1236-1362)
+template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R rmuz, R &ref, R &refd, R &tra, R &trad)
+{
+    // rmuz = 1 / prmuz (hoisted by the caller)
+    const R eps = (R)1.e-08, od_lo = (R)0.06;
     const R zg3 = (R)3. * zg;
     const R zgamma1 = ((R)8. - zw * ((R)5. + zg3)) * (R)0.25;
     const R zgamma2 = (R)3. * (zw * ((R)1. - zg)) * (R)0.25;
     const R zgamma3 = ((R)2. - zg3 * prmuz) * (R)0.25;
     const R zgamma4 = (R)1. - zgamma3;
-    // fp64 island of the reference (:1207,1260): un-scaled single scattering albedo
-    const double zw8 = (double)zw, zg8 = (double)zg;
-    const double q = zg8 / (1.0 - zg8);
-    const R zwo = (R)(zw8 / (1.0 - (1.0 - zw8) * (q * q)));
-    if (zwo >= zwcrit) {
+    if (sw_conservative<R>(zw, zg)) {
         const R za = zgamma1 * prmuz, za1 = za - zgamma3, zgt = zgamma1 * zto1;
-        R ze1 = zto1 / prmuz; ze1 = ze1 > (R)500. ? (R)500. : ze1;
-        const R ze2 = gr_exp<R>(-ze1);
-        ref = (zgt - za1 * ((R)1. - ze2)) / ((R)1. + zgt);
+        R ze1 = zto1 * rmuz; ze1 = ze1 > (R)500. ? (R)500. : ze1;
+        const R ze2 = f_exp<R>(-ze1);
+        const R r1 = f_rcp<R>((R)1. + zgt);
+        ref = (zgt - za1 * ((R)1. - ze2)) * r1;
         tra = (R)1. - ref;
-        refd = zgt / ((R)1. + zgt);
+        refd = zgt * r1;
         trad = (R)1. - refd;
         if (ze2 == (R)1.) { ref = 0; tra = 1; refd = 0; trad = 1; }
     } else {
         const R za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3, za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
-        const R zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+        const R zrk = f_sqrt<R>(zgamma1 * zgamma1 - zgamma2 * zgamma2);
         const R zrp = zrk * prmuz, zrp1 = (R)1. + zrp, zrm1 = (R)1. - zrp, zrk2 = (R)2. * zrk;
         const R zrpp = (R)1. - zrp * zrp, zrkg = zrk + zgamma1;
         const R zr1 = zrm1 * (za2 + zrk * zgamma3), zr2 = zrp1 * (za2 - zrk * zgamma3), zr3 = zrk2 * (zgamma3 - za2 * prmuz);
         const R zr4 = zrpp * zrkg, zr5 = zrpp * (zrk - zgamma1);
         const R zt1 = zrp1 * (za1 + zrk * zgamma4), zt2 = zrm1 * (za1 - zrk * zgamma4), zt3 = zrk2 * (zgamma4 + za1 * prmuz);
-        const R zbeta = (zgamma1 - zrk) / zrkg;
+        const R rzrkg = f_rcp<R>(zrkg);
+        const R zbeta = (zgamma1 - zrk) * rzrkg;
         R ze1 = zrk * zto1; ze1 = ze1 > (R)5. ? (R)5. : ze1;
-        R ze2 = zto1 / prmuz; ze2 = ze2 > (R)5. ? (R)5. : ze2;
-        const R zem1 = ze1 <= od_lo ? (R)1. - ze1 + (R)0.5 * ze1 * ze1 : gr_exp<R>(-ze1);
-        const R zep1 = (R)1. / zem1;
-        const R zem2 = ze2 <= od_lo ? (R)1. - ze2 + (R)0.5 * ze2 * ze2 : gr_exp<R>(-ze2);
-        const R zep2 = (R)1. / zem2;
-        const R zdenr = zr4 * zep1 + zr5 * zem1, zdent = zr4 * zep1 + zr5 * zem1;
+        R ze2 = zto1 * rmuz; ze2 = ze2 > (R)5. ? (R)5. : ze2;
+        const R zem1 = ze1 <= od_lo ? (R)1. - ze1 + (R)0.5 * ze1 * ze1 : f_exp<R>(-ze1);
+        const R zep1 = f_rcp<R>(zem1);
+        const R zem2 = ze2 <= od_lo ? (R)1. - ze2 + (R)0.5 * ze2 * ze2 : f_exp<R>(-ze2);
+        const R zep2 = f_rcp<R>(zem2);
+        const R zdenr = zr4 * zep1 + zr5 * zem1;           // zdent == zdenr (zt4 = zr4, zt5 = zr5)
         if (zdenr >= -eps && zdenr <= eps) { ref = eps; tra = zem2; }
         else {
-            ref = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) / zdenr;
-            tra = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) / zdent;
+            const R rden = f_rcp<R>(zdenr);
+            ref = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) * rden;
+            tra = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) * rden;
         }
         const R zemm = zem1 * zem1;
-        const R zdend = (R)1. / (((R)1. - zbeta * zemm) * zrkg);
+        const R zdend = f_rcp<R>((R)1. - zbeta * zemm) * rzrkg;
         refd = zgamma2 * ((R)1. - zemm) * zdend;
         trad = zrk2 * zem1 * zdend;
     }
@@ -417,6 +455,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
     const bool ccol = CLD && col >= ncl_opaque;
     R prmu0 = ldg(A.coszen, cba);
     prmu0 = prmu0 > (R)1.e-10 ? prmu0 : (R)1.e-10;                     // zepzen (SW/rrtmg_sw_rad.F90:1365)
+    const R rmu0 = (R)1. / prmu0;
 
     // surface albedo of this band (:1230-1248)
     R albp, albd;
@@ -482,8 +521,12 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
 
     // uniform bases of the parked-cell planes of this band
     const size_t bandoff = (size_t)G0 * nlay * n;
-    const size_t plane = (size_t)NG_SW * nlay * n;
-    R *const cellb = A.cell + bandoff;
+    // parked cell planes are tiled by 256-column block: [block][layer][g][256], so that a block's scratch is one contiguous
+    // 0.9 MB run per plane instead of 1 KB pieces 400 KB apart (TLB reach, DRAM page locality)
+    const uint32_t npad = ((uint32_t)n + 255u) & ~255u;
+    const size_t plane = (size_t)NG_SW * nlay * npad;
+    R *const cellb = A.cell + (size_t)G0 * nlay * npad;
+    const uint32_t tbase = (ucol >> 8) * (uint32_t)nlay * (uint32_t)NG * 256u + (ucol & 255u);
     const R *const tcb = A.taucmc + bandoff, *const ocb = A.ssacmc + bandoff, *const gcb = A.asmcmc + bandoff;
 #define CELL(q) (cellb + (size_t)(q) * plane)
 
@@ -515,6 +558,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 const int g = q * W + j;
                 if (g >= NG) continue;
                 const uint32_t cb4 = (cell0 + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
+                const uint32_t ct4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
                 if (DBG) {
                     const size_t o = ((size_t)pc * NG_SW + (G0 + g)) * nlay + lay;       // Fortran (nlay,112,ncol)
                     A.dbg_taug[o] = tg[j]; A.dbg_taur[o] = tr[j];
@@ -522,28 +566,28 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 // clear-sky optical properties incl. aerosol, delta-scaled with f = g^2 (:413-437)
                 R ztauo = tr[j] + tg[j] + ta;
                 R zomco = tr[j] + ta * om;
-                R zgco = (as * om * ta) / zomco;
-                zomco = zomco / ztauo;
+                R zgco = f_div<R>(as * om * ta, zomco);
+                zomco = f_div<R>(zomco, ztauo);
                 const R zf = zgco * zgco, zwf = zomco * zf;
                 ztauo = ((R)1. - zwf) * ztauo;
-                zomco = (zomco - zwf) / ((R)1. - zwf);
-                zgco = (zgco - zf) / ((R)1. - zf);
+                zomco = f_div<R>(zomco - zwf, (R)1. - zwf);
+                zgco = f_div<R>(zgco - zf, (R)1. - zf);
                 R ref, refd, tra, trad;
-                sw_reftra<R>(ztauo, zomco, zgco, prmu0, ref, refd, tra, trad);
-                R dbt = gr_exp<R>(-ztauo / prmu0);
+                sw_reftra<R>(ztauo, zomco, zgco, prmu0, rmu0, ref, refd, tra, trad);
+                R dbt = f_exp<R>(-ztauo * rmu0);
                 // downward adding recurrences (:1530-1572): values at the lower boundary of this layer
                 {
                     R zt, pr;
                     if (jk == 0) { zt = tra; pr = refd; }
                     else {
-                        const R zreflect = (R)1. / ((R)1. - refd * prdnd[g]);
+                        const R zreflect = f_rcp<R>((R)1. - refd * prdnd[g]);
                         zt = tdbt[g] * tra + (trad * ((ztdn[g] - tdbt[g]) + tdbt[g] * ref * prdnd[g])) * zreflect;
                         pr = refd + trad * trad * prdnd[g] * zreflect;
                     }
                     tdbt[g] = dbt * tdbt[g]; ztdn[g] = zt; prdnd[g] = pr;
                 }
-                stg(CELL(0), cb4, ref); stg(CELL(1), cb4, refd); stg(CELL(2), cb4, tra); stg(CELL(3), cb4, trad);
-                stg(CELL(4), cb4, dbt); stg(CELL(5), cb4, tdbt[g]); stg(CELL(6), cb4, ztdn[g]); stg(CELL(7), cb4, prdnd[g]);
+                stg(CELL(0), ct4, ref); stg(CELL(1), ct4, refd); stg(CELL(2), ct4, tra); stg(CELL(3), ct4, trad);
+                stg(CELL(4), ct4, dbt); stg(CELL(5), ct4, tdbt[g]); stg(CELL(6), ct4, ztdn[g]); stg(CELL(7), ct4, prdnd[g]);
                 if (CLD && ccol) {
                     // total sky: cloudy cells get the (already delta-scaled) cloud optics added (:512-536, 541, 547-559)
                     const R tc = ldg(tcb, cb4);
@@ -553,24 +597,24 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                         R g2 = ztauo * zomco * zgco + tc * oc * gc;
                         R o2 = ztauo * zomco + tc * oc;
                         const R t2 = ztauo + tc;
-                        g2 = g2 / o2; o2 = o2 / t2;
-                        sw_reftra<R>(t2, o2, g2, prmu0, ref, refd, tra, trad);
-                        dbt = gr_exp<R>(-t2 / prmu0);
+                        g2 = f_div<R>(g2, o2); o2 = f_div<R>(o2, t2);
+                        sw_reftra<R>(t2, o2, g2, prmu0, rmu0, ref, refd, tra, trad);
+                        dbt = f_exp<R>(-t2 * rmu0);
                         cmask |= 1u << g;
                         // total-sky layer properties are parked for cloudy cells only (elsewhere they equal the clear-sky ones)
-                        stg(CELL(8), cb4, ref); stg(CELL(9), cb4, refd); stg(CELL(10), cb4, tra); stg(CELL(11), cb4, trad);
-                        stg(CELL(12), cb4, dbt);
+                        stg(CELL(8), ct4, ref); stg(CELL(9), ct4, refd); stg(CELL(10), ct4, tra); stg(CELL(11), ct4, trad);
+                        stg(CELL(12), ct4, dbt);
                     }
                     R zt, pr;
                     if (jk == 0) { zt = tra; pr = refd; }
                     else {
-                        const R zreflect = (R)1. / ((R)1. - refd * prdndT[g]);
+                        const R zreflect = f_rcp<R>((R)1. - refd * prdndT[g]);
                         zt = tdbtT[g] * tra + (trad * ((ztdnT[g] - tdbtT[g]) + tdbtT[g] * ref * prdndT[g])) * zreflect;
                         pr = refd + trad * trad * prdndT[g] * zreflect;
                     }
                     tdbtT[g] = dbt * tdbtT[g]; ztdnT[g] = zt; prdndT[g] = pr;
                     // the sign bit of the parked T_dir^cum (>= 0) carries "this layer is cloudy" to sweep B
-                    stg(CELL(13), cb4, cellcld ? -tdbtT[g] : tdbtT[g]); stg(CELL(14), cb4, ztdnT[g]); stg(CELL(15), cb4, prdndT[g]);
+                    stg(CELL(13), ct4, cellcld ? -tdbtT[g] : tdbtT[g]); stg(CELL(14), ct4, ztdnT[g]); stg(CELL(15), ct4, prdndT[g]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -591,14 +635,14 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
             prup[g] = albp; prupd[g] = albd; prupT[g] = albp; prupdT[g] = albd;
             const R zi = zinc[g] * prmu0;
             {
-                const R zr = (R)1. / ((R)1. - prdnd[g] * prupd[g]);
+                const R zr = f_rcp<R>((R)1. - prdnd[g] * prupd[g]);
                 const R u = (tdbt[g] * prup[g] + (ztdn[g] - tdbt[g]) * prupd[g]) * zr;
                 const R d = tdbt[g] + (ztdn[g] - tdbt[g] + tdbt[g] * prup[g] * prdnd[g]) * zr;
                 cu = cu + zi * u; cd = cd + zi * d;
                 if (!(CLD && ccol)) { sdir = sdir + zi * tdbt[g]; sfd = sfd + zi * d; sfu = sfu + zi * u; }
             }
             if (CLD && ccol) {
-                const R zr = (R)1. / ((R)1. - prdndT[g] * prupdT[g]);
+                const R zr = f_rcp<R>((R)1. - prdndT[g] * prupdT[g]);
                 const R u = (tdbtT[g] * prupT[g] + (ztdnT[g] - tdbtT[g]) * prupdT[g]) * zr;
                 const R d = tdbtT[g] + (ztdnT[g] - tdbtT[g] + tdbtT[g] * prupT[g] * prdndT[g]) * zr;
                 fu = fu + zi * u; fd = fd + zi * d;
@@ -619,18 +663,18 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
         uint32_t cnext = 0;
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const uint32_t c4 = (cell0 + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
-            const uint32_t u4 = (cellu + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
+            const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
+            const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
             const R zi = zinc[g] * prmu0;
             R ref = ldg(CELL(0), c4), refd = ldg(CELL(1), c4), tra = ldg(CELL(2), c4), trad = ldg(CELL(3), c4), dbt = ldg(CELL(4), c4);
             {
-                const R zrj = (R)1. / ((R)1. - prupd[g] * refd);
+                const R zrj = f_rcp<R>((R)1. - prupd[g] * refd);
                 const R pu = ref + (trad * ((tra - dbt) * prupd[g] + dbt * prup[g])) * zrj;
                 const R pd = refd + trad * trad * prupd[g] * zrj;
                 prup[g] = pu; prupd[g] = pd;
                 R tb = 1, zt = 1, pr = 0;
                 if (jk > 0) { tb = ldg(CELL(5), u4); zt = ldg(CELL(6), u4); pr = ldg(CELL(7), u4); }
-                const R zr = (R)1. / ((R)1. - pr * pd);
+                const R zr = f_rcp<R>((R)1. - pr * pd);
                 cu = cu + zi * ((tb * pu + (zt - tb) * pd) * zr);
                 cd = cd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
             }
@@ -638,7 +682,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 if (cmask & (1u << g)) {
                     ref = ldg(CELL(8), c4); refd = ldg(CELL(9), c4); tra = ldg(CELL(10), c4); trad = ldg(CELL(11), c4); dbt = ldg(CELL(12), c4);
                 }
-                const R zrj = (R)1. / ((R)1. - prupdT[g] * refd);
+                const R zrj = f_rcp<R>((R)1. - prupdT[g] * refd);
                 const R pu = ref + (trad * ((tra - dbt) * prupdT[g] + dbt * prupT[g])) * zrj;
                 const R pd = refd + trad * trad * prupdT[g] * zrj;
                 prupT[g] = pu; prupdT[g] = pd;
@@ -647,7 +691,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                     tb = ldg(CELL(13), u4); zt = ldg(CELL(14), u4); pr = ldg(CELL(15), u4);
                     if (__builtin_signbit(tb)) { cnext |= 1u << g; tb = -tb; }
                 }
-                const R zr = (R)1. / ((R)1. - pr * pd);
+                const R zr = f_rcp<R>((R)1. - pr * pd);
                 fu = fu + zi * ((tb * pu + (zt - tb) * pd) * zr);
                 fd = fd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
             }
