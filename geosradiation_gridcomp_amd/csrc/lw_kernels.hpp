@@ -1008,8 +1008,16 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
     // uniform bases
     const size_t bandoff = (size_t)G0 * nlay * n;                         // this band's sub-array of the cell planes
     const R *const taucmc_b = A.taucmc + bandoff;
-    R2 *const s1_b = A.s1 + bandoff;
-    R2 *const s2_b = A.s2 + bandoff;
+    // the parked (a, B-up) pairs are tiled by 256-column block, [block][layer][g][256]: a block's scratch is one contiguous run
+    const uint32_t npad = ((uint32_t)n + 255u) & ~255u;
+    R2 *const s1_b = A.s1 + (size_t)G0 * nlay * npad;
+    R2 *const s2_b = A.s2 + (size_t)G0 * nlay * npad;
+    const uint32_t tbase = (ucol >> 8) * (uint32_t)nlay * (uint32_t)NG * 256u + (ucol & 255u);
+#ifdef GEOSRAD_LW_NOTILE
+#define SCELL(lay, g) (((uint32_t)(lay) * (uint32_t)NG + (uint32_t)(g)) * (uint32_t)npad + ucol)
+#else
+#define SCELL(lay, g) (tbase + ((uint32_t)(lay) * (uint32_t)NG + (uint32_t)(g)) * 256u)
+#endif
     const size_t qs = (size_t)NB_LW * (nlay + 1) * n;                     // one flux kind of `part`
     R *const part = A.part + (size_t)(IB - 1) * (nlay + 1) * n;           // [(kind*qs) + lev*n + col]
 #define PART(kind, lev, val) stg(part + (size_t)(kind) * qs + (size_t)(lev) * n, cb, (R)(val))
@@ -1029,6 +1037,12 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
     int ltop = -1;   // highest optically cloudy layer: where the clear/total streams part (:297-307)
     R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
 
+    // (a, B-up) pairs of the g-group processed last, waiting to be written (see phase 2 below)
+    constexpr bool DEFER = !CLD;       // the cloudy instantiation has no registers to spare for it
+    R2 pend1[W], pend2[W];
+    uint32_t poff[W];
+    int npend = 0;
+    uint32_t pmask2 = 0;
     // ---- downward sweep, top layer -> surface ------------------------------------------------------
     R plk_up = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)nlay * ld, cba));   // level above the current layer
     for (int lay = nlay - 1; lay >= 0; lay--) {
@@ -1048,14 +1062,18 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
         }
         const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;   // g = 0 cell of this layer; + g*n
         R dsum = 0, dcsum = 0;
+        if constexpr (!CLD) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             R tau[W], pf[W];
             BAND::template eval<R, W>(T, L, P, q * W, tau, pf);
+            // phase 1: Pade index of the gas optical depth + LUT gathers of the whole group
+            int itg[W];
+            R2 eg[W];
 #pragma unroll
             for (int j = 0; j < W; j++) {
                 const int g = q * W + j;
-                if (g >= NG) continue;   // padding of the last group
+                if (g >= NG) { itg[j] = 0; eg[j].x = 0; eg[j].y = 0; continue; }   // padding of the last group
                 if (DBG) {
                     const size_t o = ((size_t)pc * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
                     A.dbg_taug[o] = tau[j] + ta;
@@ -1064,12 +1082,35 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                 R odepth = secdiff * (tau[j] + ta);
                 if (odepth < 0) odepth = 0;
                 const R tblind = odepth / (bpade + odepth);
-                const int itgas = (int)(tblint * tblind + (R)0.5);
-                const R2 e = ldg(T.lut, (uint32_t)itgas * (uint32_t)sizeof(R2));
+                itg[j] = (int)(tblint * tblind + (R)0.5);
+                eg[j] = ldg(T.lut, (uint32_t)itg[j] * (uint32_t)sizeof(R2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: only now write the PREVIOUS group's (a, B-up) pairs.  Loads and stores share one in-order counter
+            // (vmcnt) on gfx9: a load issued after a store cannot be consumed before that store is acknowledged, so the
+            // stores go behind this group's loads and get a whole group of arithmetic to drain.
+            if (npend) {
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    if (j < npend) {
+                        stg(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
+                        if (CLD && (pmask2 >> j) & 1u) stg(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
+                    }
+            }
+            npend = 0; pmask2 = 0;
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: radiance recurrences of the group
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                if (g >= NG) continue;
+                const int itgas = itg[j];
+                const R2 e = eg[j];
                 const R agas = (R)1. - e.x, tfacgas = e.y;
                 const R bbdgas = pf[j] * (blay + tfacgas * dplankdn);
                 const R bbugas = pf[j] * (blay + tfacgas * dplankup);
                 const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
+                const uint32_t scell = SCELL(lay, g);
                 R atot = agas, bbutot = bbugas;
                 const R radprev = rad[g];
                 bool cldcell = false;
@@ -1089,14 +1130,14 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                     }
                 }
                 if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
-                R2 sv; sv.x = atot; sv.y = bbutot;
-                stg(s1_b, cell * (uint32_t)sizeof(R2), sv);
+                if (DEFER) { pend1[j].x = atot; pend1[j].y = bbutot; poff[j] = scell; npend = j + 1; }
+                else { R2 sv; sv.x = atot; sv.y = bbutot; stg(s1_b, scell * (uint32_t)sizeof(R2), sv); }
                 dsum = dsum + sumfac * rad[g];
                 if (CLD && ccol) {
                     if (diverge) {
                         radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
-                        R2 sg; sg.x = agas; sg.y = bbugas;
-                        stg(s2_b, cell * (uint32_t)sizeof(R2), sg);
+                        if (DEFER) { pend2[j].x = agas; pend2[j].y = bbugas; pmask2 |= 1u << j; }
+                        else { R2 sg; sg.x = agas; sg.y = bbugas; stg(s2_b, scell * (uint32_t)sizeof(R2), sg); }
                     } else {
                         radc[g] = rad[g];
                     }
@@ -1119,9 +1160,89 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
             }
             __builtin_amdgcn_sched_barrier(0);   // keep one g-group's table rows in flight at a time
         }
+        } else {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            R tau[W], pf[W];
+            BAND::template eval<R, W>(T, L, P, q * W, tau, pf);
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                if (g >= NG) continue;   // padding of the last group
+                if (DBG) {
+                    const size_t o = ((size_t)pc * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
+                    A.dbg_taug[o] = tau[j] + ta;
+                    A.dbg_pfracs[o] = pf[j];
+                }
+                R odepth = secdiff * (tau[j] + ta);
+                if (odepth < 0) odepth = 0;
+                const R tblind = odepth / (bpade + odepth);
+                const int itgas = (int)(tblint * tblind + (R)0.5);
+                const R2 e = ldg(T.lut, (uint32_t)itgas * (uint32_t)sizeof(R2));
+                const R agas = (R)1. - e.x, tfacgas = e.y;
+                const R bbdgas = pf[j] * (blay + tfacgas * dplankdn);
+                const R bbugas = pf[j] * (blay + tfacgas * dplankup);
+                const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
+                const uint32_t scell = SCELL(lay, g);
+                R atot = agas, bbutot = bbugas;
+                const R radprev = rad[g];
+                bool cldcell = false;
+                if (CLD && laycld) {
+                    const R tc = ldg(taucmc_b, cell * (uint32_t)sizeof(R));
+                    if (tc > 0) {
+                        cldcell = true;
+                        // cloud added to the DISCRETISED gas tau (:264-268)
+                        const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
+                        const R tb2 = odtot / (bpade + odtot);
+                        const int ittot = (int)(tblint * tb2 + (R)0.5);
+                        const R2 e2 = ldg(T.lut, (uint32_t)ittot * (uint32_t)sizeof(R2));
+                        atot = (R)1. - e2.x;
+                        const R bbdtot = pf[j] * (blay + e2.y * dplankdn);
+                        bbutot = pf[j] * (blay + e2.y * dplankup);
+                        rad[g] = radprev + (bbdtot - radprev) * atot;
+                    }
+                }
+                if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
+                R2 sv; sv.x = atot; sv.y = bbutot;
+                stg(s1_b, scell * (uint32_t)sizeof(R2), sv);
+                dsum = dsum + sumfac * rad[g];
+                if (CLD && ccol) {
+                    if (diverge) {
+                        radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
+                        R2 sg; sg.x = agas; sg.y = bbugas;
+                        stg(s2_b, scell * (uint32_t)sizeof(R2), sg);
+                    } else {
+                        radc[g] = rad[g];
+                    }
+                    dcsum = dcsum + sumfac * radc[g];
+                }
+                if (lay == 0) {
+                    // surface: emission + reflection turn the downward radiance into the upward one (:319-333)
+                    const R rad0 = pf[j] * plankbnd;
+                    rad[g] = rad0 + reflect * rad[g];
+                    dlu[g] = pf[j] * dplankbnd;
+                    usum = usum + sumfac * rad[g];
+                    dusum = dusum + sumfac * dlu[g];
+                    if (CLD) {
+                        radc[g] = rad0 + reflect * radc[g];
+                        dclu[g] = dlu[g];
+                        ucsum = ucsum + sumfac * radc[g];
+                        ducsum = ducsum + sumfac * dclu[g];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep one g-group's table rows in flight at a time
+        }
+        }
         PART(0, lay, dsum);
         if (CLD && ccol) PART(1, lay, dcsum);
     }
+#pragma unroll
+    for (int j = 0; j < W; j++)
+        if (j < npend) {
+            stg(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
+            if (CLD && (pmask2 >> j) & 1u) stg(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
+        }
     // TOA downward flux is zero (level nlay); written so the reduce kernel can sum unconditionally
     PART(0, nlay, 0);
     if (CLD && ccol) PART(1, nlay, 0);
@@ -1135,8 +1256,8 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
         const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
-            const R2 sv = ldg(s1_b, cell * (uint32_t)sizeof(R2));
+            const uint32_t scell = SCELL(lay, g);
+            const R2 sv = ldg(s1_b, scell * (uint32_t)sizeof(R2));
             rad[g] = rad[g] + (sv.y - rad[g]) * sv.x;
             dlu[g] = dlu[g] - dlu[g] * sv.x;
             usum = usum + sumfac * rad[g];
@@ -1144,7 +1265,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
             if (CLD && ccol) {
                 if (diverge) {
                     // above ltop the layer is clear for every g-point: gas == total
-                    const R2 sg = (lay <= ltop) ? ldg(s2_b, cell * (uint32_t)sizeof(R2)) : sv;
+                    const R2 sg = (lay <= ltop) ? ldg(s2_b, scell * (uint32_t)sizeof(R2)) : sv;
                     radc[g] = radc[g] + (sg.y - radc[g]) * sg.x;
                     dclu[g] = dclu[g] - dclu[g] * sg.x;
                 } else {
