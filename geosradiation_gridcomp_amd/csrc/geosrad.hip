@@ -928,6 +928,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             const dim3 blk(256);
             const unsigned gx = (unsigned)((nc + 255) / 256);
             span_begin(6, st); hipLaunchKernelGGL(k_sw_validate<R>, dim3(gx), blk, 0, st, A);
+            if (iaer == 10) hipLaunchKernelGGL(k_sw_validate_aer<R>, dim3(gx, nlay), blk, 0, st, A);
             hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, st, nc, (const uint8_t *)w.colcloudy, w.perm, w.nclear); span_end(st);
             span_begin(7, st); hipLaunchKernelGGL(k_sw_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, (const SwDev<R> *)d_S); span_end(st);
             span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,

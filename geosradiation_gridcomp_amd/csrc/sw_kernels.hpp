@@ -96,17 +96,27 @@ __global__ void __launch_bounds__(256) k_sw_validate(SwArgs<R> A)
             if (chk[k][i] < 0) err |= 1u << k;
         if (A.plev[i] < 0) err |= 1u << SWERR_PLEV;
         if (A.cld[i] > 0) cloudy = true;
-        if (A.iaer == 10)
-            for (int ib = 0; ib < NB_SW; ib++) {
-                const size_t j = ((size_t)ib * nlay + lay) * ld + col;
-                if (A.tauaer[j] < 0 || A.ssaaer[j] < 0) err |= 1u << SWERR_AER;
-            }
     }
     if (A.plev[(size_t)nlay * ld + col] < 0) err |= 1u << SWERR_PLEV;
     if (A.asdir[col] < 0 || A.aldir[col] < 0 || A.asdif[col] < 0 || A.aldif[col] < 0) err |= 1u << SWERR_ALB;
     A.colcloudy[col] = cloudy ? 1 : 0;
     for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = cloudy ? 0 : NG_SW;   // rrtmg_sw_rad.F90:1520-1523
     if (err) atomicOr(A.err, err);
+}
+
+// aerosol assertions (SW/rrtmg_sw_rad.F90:380-383), one thread per (layer, column) so that the 2 x 14 band planes are read coalesced
+template <typename R>
+__global__ void __launch_bounds__(256) k_sw_validate_aer(SwArgs<R> A)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lay = blockIdx.y;
+    if (col >= A.ncol) return;
+    bool bad = false;
+    for (int ib = 0; ib < NB_SW; ib++) {
+        const size_t j = ((size_t)ib * A.nlay + lay) * A.ld + col;
+        bad |= A.tauaer[j] < 0 || A.ssaaer[j] < 0;
+    }
+    if (bad) atomicOr(A.err, 1u << SWERR_AER);
 }
 
 // SW/rrtmg_sw_rad.F90:1370-1387 (column amounts) + SW/rrtmg_sw_setcoef.F90:89-241
