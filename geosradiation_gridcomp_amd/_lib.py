@@ -17,7 +17,7 @@ EXPORTS = [
     "geosrad_workspace_bytes", "geosrad_set_tables_lw", "geosrad_load_tables_lw", "geosrad_set_inhomogeneity",
     "geosrad_load_inhomogeneity", "geosrad_set_corr_lengths", "geosrad_rrtmg_lw", "geosrad_rrtmg_lw_dev",
     "geosrad_check", "geosrad_profile", "geosrad_profile_read", "geosrad_kernel_name", "geosrad_rrtmg_lw_taumol", "geosrad_mcica", "geosrad_clearcounts",
-    "geosrad_set_tables_sw", "geosrad_load_tables_sw", "geosrad_rrtmg_sw", "geosrad_rrtmg_sw_dev", "geosrad_rrtmg_sw_taumol",
+    "geosrad_set_tables_sw", "geosrad_load_tables_sw", "geosrad_rrtmg_sw", "geosrad_rrtmg_sw_dev", "geosrad_rrtmg_sw_taumol", "geosrad_mcica_dev",
 ]
 
 _lib = None

@@ -274,6 +274,16 @@ class Context:
         self._chk(rc)
         return cldy, ci_s, cl_s
 
+    def generate_stochastic_clouds_dev(self, stream, ncol, nsubcol, nlay, ptr, doy, cwp_tiny, seed_order=(1, 2, 3, 4)):
+        """device-pointer variant: `ptr` maps zm, alat, play, cldf, ciwp, clwp (inputs, solver-API layout) and
+        cldy_stoch (int32), ciwp_stoch, clwp_stoch (outputs, Fortran (nlay,nsubcol,ncol)) to device addresses."""
+        v = lambda k: ctypes.c_void_p(ptr[k])
+        so = (ctypes.c_int32 * 4)(*[int(s) for s in seed_order])
+        rc = self.L.geosrad_mcica_dev(self.h, ctypes.c_void_p(stream), ctypes.c_int(ncol), ctypes.c_int(nsubcol), ctypes.c_int(nlay),
+                                      v("zm"), v("alat"), ctypes.c_int(int(doy)), v("play"), v("cldf"), v("ciwp"), v("clwp"),
+                                      ctypes.c_double(cwp_tiny), so, v("cldy_stoch"), v("ciwp_stoch"), v("clwp_stoch"))
+        self._chk(rc)
+
     def clearCounts_threeBand(self, ncol, nsubcol, nlay, cloudLM, cloudMH, cldy_stoch):
         cldy = np.ascontiguousarray(cldy_stoch, dtype=np.int32)
         cnt = np.zeros((ncol, 4), dtype=np.int32)

@@ -240,6 +240,9 @@ struct geosrad_ctx {
     virtual int mcica_host(int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
                            const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so,
                            int32_t *cldy, void *ciwp_s, void *clwp_s) = 0;
+    virtual int mcica_dev(hipStream_t st, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
+                          const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so,
+                          int32_t *cldy, void *ciwp_s, void *clwp_s) = 0;
     virtual int check(hipStream_t st) = 0;
     virtual int set_tables_sw(const void *blob, size_t n) = 0;
     virtual int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg,
@@ -306,6 +309,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_ws_sw) (void)hipFree(d_ws_sw);
         if (d_err) (void)hipFree(d_err);
         if (d_io) (void)hipFree(d_io);
+        if (d_mc) (void)hipFree(d_mc);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -1028,9 +1032,11 @@ template <typename R> struct Ctx : geosrad_ctx {
     }
 
     // ---- stand-alone McICA generator, host pointers ------------------------------------------------------------------
-    int mcica_host(int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play, const void *cldfrac,
-                   const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so, int32_t *cldy, void *ciwp_s,
-                   void *clwp_s) override
+    // ---- stand-alone McICA generator ---------------------------------------------------------------------------------
+    char *d_mc = nullptr; size_t mc_bytes = 0;      // alpha / rcorr scratch of the stand-alone generator
+    int mcica_dev(hipStream_t st, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
+                  const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so, int32_t *cldy,
+                  void *ciwp_s, void *clwp_s) override
     {
         HIPCHK(hipSetDevice(device));
         if (ncol <= 0 || nlay < 4 || nsubcol <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay/nsubcol");
@@ -1043,33 +1049,53 @@ template <typename R> struct Ctx : geosrad_ctx {
                 sov[k] = so[k];
             }
         }
+        const size_t cl = (size_t)ncol * nlay;
+        const size_t need = 2 * al(cl * sizeof(R));
+        if (need > mc_bytes) {
+            if (d_mc) { HIPCHK(hipFree(d_mc)); d_mc = nullptr; mc_bytes = 0; }
+            if (hipMalloc((void **)&d_mc, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the McICA scratch failed");
+            mc_bytes = need;
+        }
+        R *d_alpha = (R *)d_mc, *d_rcorr = (R *)(d_mc + al(cl * sizeof(R)));
+        const unsigned gx = (unsigned)((ncol + 255) / 256);
+        hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), dim3(256), 0, st, ncol, ncol, nlay, doy, (const R *)zmid, (const R *)alat,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, (const LwDev<R> *)d_T, d_alpha, d_rcorr, (uint8_t *)nullptr);
+        McArgs<R> M{};
+        M.ncol = ncol; M.ld = ncol; M.nlay = nlay; M.nsubcol = nsubcol; M.doy = doy; M.cloudLM = 1; M.cloudMH = 2;
+        for (int k = 0; k < 4; k++) M.so[k] = sov[k];
+        M.cwp_tiny = (R)cwp_tiny;
+        M.play = (const R *)play; M.cldf = (const R *)cldfrac; M.ciwp = (const R *)ciwp; M.clwp = (const R *)clwp;
+        M.alpha = d_alpha; M.rcorr = d_rcorr;
+        M.cldy = cldy; M.ciwp_s = (R *)ciwp_s; M.clwp_s = (R *)clwp_s;
+        McPlan MP; int nseg = 0;
+        int rc = mc_plan(1, nsubcol, nlay, MP, nseg);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int mcica_host(int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play, const void *cldfrac,
+                   const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so, int32_t *cldy, void *ciwp_s,
+                   void *clwp_s) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || nlay < 4 || nsubcol <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay/nsubcol");
         const size_t cl = (size_t)ncol * nlay, co = cl * nsubcol;
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
         const size_t o_z = take(cl * sizeof(R)), o_p = take(cl * sizeof(R)), o_f = take(cl * sizeof(R)), o_i = take(cl * sizeof(R)),
-                     o_l = take(cl * sizeof(R)), o_a = take((size_t)ncol * sizeof(R)), o_al = take(cl * sizeof(R)),
-                     o_rc = take(cl * sizeof(R)), o_cy = take(co * 4), o_ci = take(co * sizeof(R)), o_cl = take(co * sizeof(R));
+                     o_l = take(cl * sizeof(R)), o_a = take((size_t)ncol * sizeof(R)), o_cy = take(co * 4), o_ci = take(co * sizeof(R)),
+                     o_cl = take(co * sizeof(R));
         int rc = ensure_io(off);
         if (rc) return rc;
         const void *src[6] = {zmid, play, cldfrac, ciwp, clwp, alat};
         const size_t dst[6] = {o_z, o_p, o_f, o_i, o_l, o_a};
         for (int k = 0; k < 6; k++)
             HIPCHK(hipMemcpyAsync(d_io + dst[k], src[k], (k == 5 ? (size_t)ncol : cl) * sizeof(R), hipMemcpyHostToDevice, stream));
-        const unsigned gx = (unsigned)((ncol + 255) / 256);
-        hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), dim3(256), 0, stream, ncol, ncol, nlay, doy, (const R *)(d_io + o_z),
-                           (const R *)(d_io + o_a), (const int32_t *)nullptr, (const int32_t *)nullptr, (const LwDev<R> *)d_T, (R *)(d_io + o_al), (R *)(d_io + o_rc), (uint8_t *)nullptr);
-        McArgs<R> M{};
-        M.ncol = ncol; M.ld = ncol; M.nlay = nlay; M.nsubcol = nsubcol; M.doy = doy; M.cloudLM = 1; M.cloudMH = 2;
-        for (int k = 0; k < 4; k++) M.so[k] = sov[k];
-        M.cwp_tiny = (R)cwp_tiny;
-        M.play = (const R *)(d_io + o_p); M.cldf = (const R *)(d_io + o_f); M.ciwp = (const R *)(d_io + o_i); M.clwp = (const R *)(d_io + o_l);
-        M.alpha = (const R *)(d_io + o_al); M.rcorr = (const R *)(d_io + o_rc);
-        M.cldy = (int32_t *)(d_io + o_cy); M.ciwp_s = (R *)(d_io + o_ci); M.clwp_s = (R *)(d_io + o_cl);
-        McPlan MP; int nseg = 0;
-        rc = mc_plan(1, nsubcol, nlay, MP, nseg);
+        rc = mcica_dev(stream, ncol, nsubcol, nlay, d_io + o_z, d_io + o_a, doy, d_io + o_p, d_io + o_f, d_io + o_i, d_io + o_l, cwp_tiny, so,
+                       (int32_t *)(d_io + o_cy), d_io + o_ci, d_io + o_cl);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, stream, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
-        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(cldy, d_io + o_cy, co * 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(ciwp_s, d_io + o_ci, co * sizeof(R), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(clwp_s, d_io + o_cl, co * sizeof(R), hipMemcpyDeviceToHost, stream));
@@ -1312,6 +1338,15 @@ int geosrad_mcica(geosrad_ctx *c, int ncol, int nsubcol, int nlay, const void *z
     if (!c || !zmid || !alat || !play || !cldfrac || !ciwp || !clwp || !cldy_stoch || !ciwp_stoch || !clwp_stoch) return GEOSRAD_EINVAL;
     return c->mcica_host(ncol, nsubcol, nlay, zmid, alat, doy, play, cldfrac, ciwp, clwp, cwp_tiny, seed_order, cldy_stoch, ciwp_stoch,
                          clwp_stoch);
+}
+
+int geosrad_mcica_dev(geosrad_ctx *c, void *stream, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy,
+                      const void *play, const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny,
+                      const int32_t seed_order[4], int32_t *cldy_stoch, void *ciwp_stoch, void *clwp_stoch)
+{
+    if (!c || !zmid || !alat || !play || !cldfrac || !ciwp || !clwp || !cldy_stoch || !ciwp_stoch || !clwp_stoch) return GEOSRAD_EINVAL;
+    return c->mcica_dev((hipStream_t)stream, ncol, nsubcol, nlay, zmid, alat, doy, play, cldfrac, ciwp, clwp, cwp_tiny, seed_order,
+                        cldy_stoch, ciwp_stoch, clwp_stoch);
 }
 
 int geosrad_clearcounts(geosrad_ctx *c, int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH, const int32_t *cldy, int32_t *cnt)

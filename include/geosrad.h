@@ -194,6 +194,11 @@ int geosrad_mcica(geosrad_ctx *ctx, int ncol, int nsubcol, int nlay,
                   const void *zmid, const void *alat, int doy, const void *play, const void *cldfrac,
                   const void *ciwp, const void *clwp, double cwp_tiny, const int32_t seed_order[4],
                   int32_t *cldy_stoch, void *ciwp_stoch, void *clwp_stoch);
+/* same, DEVICE pointers, asynchronous on `stream` (seed_order stays a host pointer) */
+int geosrad_mcica_dev(geosrad_ctx *ctx, void *stream, int ncol, int nsubcol, int nlay,
+                      const void *zmid, const void *alat, int doy, const void *play, const void *cldfrac,
+                      const void *ciwp, const void *clwp, double cwp_tiny, const int32_t seed_order[4],
+                      int32_t *cldy_stoch, void *ciwp_stoch, void *clwp_stoch);
 /* clearCounts_threeBand (cloud_subcol_gen.F90:611): cldy (nlay,nsubcol,ncol) int32 -> clearCnts (4,ncol) */
 int geosrad_clearcounts(geosrad_ctx *ctx, int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH,
                         const int32_t *cldy_stoch, int32_t *clearCnts);

@@ -174,3 +174,53 @@ def test_full_size_properties(gpu_ctx):
     r = clib.rrtmg_lw(sub_columns(shard, 32), "r4")
     for k in ("uflx", "dflx"):
         assert np.abs(p[k][:, :32] - r[k]).max() <= TOL_FLUX[4]
+
+
+def test_device_pointer_entry_points_match_host_entry_points(gpu_ctx):
+    """the `_dev` variants (HBM-resident arrays + caller's stream) give the same bits as the host-pointer ones"""
+    import torch
+    from geosradiation_gridcomp_amd import synth
+    ctx = gpu_ctx[4]
+    ncol, nlay, nsub = 96, 72, 200
+    inp = synth.make_columns(ncol, nlay, start=4321, cloudy_frac=0.7, aerosol=True)
+    dev = torch.device("cuda", 0)
+    ctx.set_inhomogeneity(1)
+    # stand-alone McICA generator with BASELINE's 200 sub-columns
+    cl, ci, cw = ctx.generate_stochastic_clouds(ncol, nsub, nlay, inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"],
+                                                inp["ciwp"], inp["clwp"], 1e-20)
+    d = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in ("zm", "alat", "play", "cldf", "ciwp", "clwp")}
+    d["cldy_stoch"] = torch.zeros((ncol, nsub, nlay), dtype=torch.int32, device=dev)
+    d["ciwp_stoch"] = torch.zeros((ncol, nsub, nlay), dtype=torch.float32, device=dev)
+    d["clwp_stoch"] = torch.zeros((ncol, nsub, nlay), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.generate_stochastic_clouds_dev(st, ncol, nsub, nlay, {k: v.data_ptr() for k, v in d.items()}, int(inp["dyofyr"]), 1e-20)
+    ctx.check(st)
+    np.testing.assert_array_equal(d["cldy_stoch"].cpu().numpy(), cl)
+    np.testing.assert_array_equal(d["ciwp_stoch"].cpu().numpy(), ci)
+    np.testing.assert_array_equal(d["clwp_stoch"].cpu().numpy(), cw)
+    assert cl.any() and not cl.all()
+    # RRTMG_LW / RRTMG_SW
+    from bench import LW_IN2D, SW_IN, SW_AER, SW_OUT1
+    names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat", "tauaer"] + LW_IN2D + SW_IN + SW_AER
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in names}
+    for k in FLUX + ("swuflx", "swdflx", "swuflxc", "swdflxc"):
+        t[k] = torch.zeros((nlay + 1, ncol), device=dev)
+    for k in SW_OUT1:
+        t[k] = torch.zeros(ncol, device=dev)
+    t["fswband"] = torch.zeros((14, ncol), device=dev)
+    t["clearCounts"] = torch.zeros((4, ncol), dtype=torch.int32, device=dev)
+    t["clearCounts_sw"] = torch.zeros((4, ncol), dtype=torch.int32, device=dev)
+    ptr = {k: v.data_ptr() for k, v in t.items()}
+    doy, lm, mh = int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"])
+    ctx.rrtmg_lw_dev(st, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
+    ctx.rrtmg_sw_dev(st, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 10, lm, mh, normFlx=1)
+    ctx.check(st)
+    h_lw = ctx.rrtmg_lw_columns(inp)
+    h_sw = ctx.rrtmg_sw_columns(inp, iaer=10, normFlx=1)
+    ctx.set_inhomogeneity(0)
+    for k in FLUX:
+        np.testing.assert_array_equal(t[k].cpu().numpy(), h_lw[k], err_msg=k)
+    for k in ("swuflx", "swdflx", "swuflxc", "swdflxc", "nirr", "parf", "fswband", "cotdtp"):
+        np.testing.assert_array_equal(t[k].cpu().numpy(), h_sw[k], err_msg=k)
+    np.testing.assert_array_equal(t["clearCounts"].cpu().numpy(), h_lw["clearCounts"])
+    np.testing.assert_array_equal(t["clearCounts_sw"].cpu().numpy(), h_sw["clearCounts"])
