@@ -160,3 +160,54 @@ def make_columns(ncol, nlay=72, seed=SEED, start=0, cloudy_frac=0.0, aerosol=Fal
     out["cloudMH"] = np.int32(max(int(out["cloudLM"]) + 1, int(np.sum(pref[1:] >= 400.0))))
     out["dyofyr"] = np.int32(180)
     return out
+
+
+def chou_lw_inputs(inp, aerosol=False):
+    """Inputs of the Chou-Suarez `irrad` for the columns of `make_columns` (the unit conversions and the vertical flip that
+    GEOS_IrradGridComp does before the call, GEOS_IrradGridComp.F90:1870-2101): layers from the TOP down, pressure in Pa,
+    specific humidity, O3 mass mixing ratio, hydrometeor mixing ratios of the 4 species (ice, liquid, rain, snow).
+    Arrays are numpy C-order with the reversed Fortran shape, e.g. ple (np+1, m), cwc (4, np, m), eg (10, ns, m)."""
+    f32 = np.float32
+    nlay, m = inp["play"].shape
+    flip = lambda a: np.ascontiguousarray(a[::-1])
+    ple = (flip(inp["plev"]).astype(np.float64) * 100.0)                       # Pa, top -> surface
+    dp = np.diff(ple, axis=0)
+    w = flip(inp["h2ovmr"]).astype(np.float64) * (18.016 / 28.966)             # mass mixing ratio
+    grav = 9.80665
+    out = dict(
+        ple=ple.astype(f32), ta=flip(inp["tlay"]), wa=(w / (1.0 + w)).astype(f32),
+        oa=(flip(inp["o3vmr"]).astype(np.float64) * (47.998 / 28.966)).astype(f32), tb=inp["tlev"][0].astype(f32),
+        co2=float(inp["co2vmr"][0, 0]), n2o=flip(inp["n2ovmr"]), ch4=flip(inp["ch4vmr"]), cfc11=flip(inp["cfc11vmr"]),
+        cfc12=flip(inp["cfc12vmr"]), cfc22=flip(inp["cfc22vmr"]), fcld=flip(inp["cldf"]),
+    )
+    # in-cloud water paths (g m-2) -> grid-mean mixing ratios (kg/kg): wp = cwc * dp / g * 1e3 (getirtau.code)
+    cf = flip(inp["cldf"]).astype(np.float64)
+    ice = flip(inp["ciwp"]).astype(np.float64) * cf * grav / (dp * 1.0e3)
+    liq = flip(inp["clwp"]).astype(np.float64) * cf * grav / (dp * 1.0e3)
+    zero = np.zeros_like(ice)
+    out["cwc"] = np.stack([ice, liq, 0.05 * liq, 0.05 * ice]).astype(f32)
+    out["reff"] = np.stack([flip(inp["rei"]), flip(inp["rel"]), np.full_like(zero, 100.0), np.full_like(zero, 140.0)]).astype(f32)
+    # level indices separating high/middle (400 hPa) and middle/low (700 hPa) clouds, top-down numbering
+    pref = ple.mean(axis=1) * 0.01
+    out["ict"] = int(max(2, np.sum(pref < 400.0)))
+    out["icb"] = int(max(out["ict"] + 1, np.sum(pref < 700.0)))
+    out["ns"] = 1
+    out["fs"] = np.ones((1, m), dtype=f32)
+    out["tg"] = inp["tsfc"].reshape(1, m).astype(f32)
+    out["tv"] = out["tg"].copy()
+    out["eg"] = np.broadcast_to(inp["emis"][:10].reshape(10, 1, m), (10, 1, m)).astype(f32).copy()
+    out["ev"] = np.zeros((10, 1, m), dtype=f32)
+    out["rv"] = np.zeros((10, 1, m), dtype=f32)
+    out["nb"] = 10
+    if aerosol and "tauaer_sw" in inp:
+        tau = inp["tauaer_sw"][:10, ::-1].astype(np.float64)
+        ssa = inp["ssaaer_sw"][:10, ::-1].astype(np.float64)
+        g = inp["asmaer_sw"][:10, ::-1].astype(np.float64)
+        out["na"] = 3
+        out["taua"] = np.ascontiguousarray(tau).astype(f32)
+        out["ssaa"] = np.ascontiguousarray(tau * ssa).astype(f32)          # the reference takes tau, tau*ssa, tau*ssa*g
+        out["asya"] = np.ascontiguousarray(tau * ssa * g).astype(f32)
+    else:
+        out["na"] = 0
+        out["taua"] = np.zeros((10, nlay, m), dtype=f32); out["ssaa"] = np.zeros_like(out["taua"]); out["asya"] = np.zeros_like(out["taua"])
+    return out

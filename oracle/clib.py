@@ -72,6 +72,13 @@ def _load_tables(sfx):
         flat = np.ascontiguousarray(np.asfortranarray(a).ravel(order="F"))
         _keep[(sfx, "sw_" + name)] = flat
         setter(name.encode(), _p(flat))
+    _, t = read_blob(os.path.join(DATA, f"chou_lw_{kind}.grtb"))
+    setter = getattr(_lib, f"oracle_chou_set_table_{sfx}")
+    setter.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    for name, a in t.items():
+        flat = np.ascontiguousarray(np.asfortranarray(a).ravel(order="F"))
+        _keep[(sfx, "chou_" + name)] = flat
+        setter(name.encode(), _p(flat))
 
 
 def set_inhomogeneity(ih, prec="f32"):
@@ -244,4 +251,31 @@ def rrtmg_sw(inp, prec="f32", scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqfl
         _p(out["swuflxc"]), _p(out["swdflxc"]), _p(out["nirr"]), _p(out["nirf"]), _p(out["parr"]), _p(out["parf"]), _p(out["uvrr"]),
         _p(out["uvrf"]), _p(out["fswband"]), _p(out["cot"]), ci(1 if do_drfband else 0), _p(out["drband"]), _p(out["dfband"]), bs, ind)
     out["rc"] = rc
+    return out
+
+
+def irrad(ch, prec="f32", trace=True):
+    """Chou-Suarez LW (irrad.F90:27).  `ch` from synth.chou_lw_inputs.  Returns the 8 flux arrays + dfdts (np+1, m), sfcem (m),
+    taudiag (10, np, m); upward fluxes are negative as in the reference."""
+    L = lib()
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    n1, m = ch["ple"].shape
+    npl = n1 - 1
+    c = lambda k: _c(ch[k], dt)
+    a = {k: c(k) for k in ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg",
+                           "tv", "ev", "rv")}
+    aer = {k: _c(ch[k], dt).copy() for k in ("taua", "ssaa", "asya")}        # INOUT in the reference
+    out = {k: np.zeros((n1, m), dtype=dt) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts")}
+    out["sfcem"] = np.zeros(m, dtype=dt)
+    out["taudiag"] = np.zeros((10, npl, m), dtype=dt)
+    R = ctypes.c_float if sfx == "f32" else ctypes.c_double
+    ci = ctypes.c_int
+    rc = getattr(L, f"oracle_irrad_{sfx}")(
+        ci(m), ci(npl), _p(a["ple"]), _p(a["ta"]), _p(a["wa"]), _p(a["oa"]), _p(a["tb"]), R(ch["co2"]), ci(1 if trace else 0),
+        _p(a["n2o"]), _p(a["ch4"]), _p(a["cfc11"]), _p(a["cfc12"]), _p(a["cfc22"]), _p(a["cwc"]), _p(a["fcld"]), ci(int(ch["ict"])),
+        ci(int(ch["icb"])), _p(a["reff"]), ci(int(ch["ns"])), _p(a["fs"]), _p(a["tg"]), _p(a["eg"]), _p(a["tv"]), _p(a["ev"]), _p(a["rv"]),
+        ci(int(ch["na"])), ci(int(ch["nb"])), _p(aer["taua"]), _p(aer["ssaa"]), _p(aer["asya"]),
+        *[_p(out[k]) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts", "sfcem", "taudiag")])
+    out["rc"] = rc
+    out.update({k + "_out": v for k, v in aer.items()})
     return out

@@ -1,5 +1,5 @@
 /* oracle/lw_oracle.c -- TEST INFRASTRUCTURE ONLY.  Builds the plain-C restatements (RRTMG_LW + McICA:
- * lw_oracle_impl.h; RRTMG_SW: sw_oracle_impl.h) in both precisions (see those files for the reference citations).  gcc -O2 -ffp-contract=off -shared -fPIC. */
+ * lw_oracle_impl.h; RRTMG_SW: sw_oracle_impl.h; Chou-Suarez irrad: chou_oracle_impl.h) in both precisions (see those files for the reference citations).  gcc -O2 -ffp-contract=off -shared -fPIC. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -13,8 +13,11 @@
 #define FMOD fmodf
 #define FABS fabsf
 #define SQRT sqrtf
+#define LOG10 log10f
 #include "lw_oracle_impl.h"
 #include "sw_oracle_impl.h"
+#include "chou_oracle_impl.h"
+#undef LOG10
 #undef REAL
 #undef SFX
 #undef EXP
@@ -34,5 +37,8 @@
 #define FMOD fmod
 #define FABS fabs
 #define SQRT sqrt
+#define LOG10 log10
 #include "lw_oracle_impl.h"
 #include "sw_oracle_impl.h"
+#include "chou_oracle_impl.h"
+#undef LOG10

@@ -686,3 +686,26 @@ subroutine ref_sw_cldprmc(ncol, nlay, iceflag, liqflag, cldy, ciwpmc, clwpmc, re
    call cldprmc_sw(ncol, ncol, nlay, iceflag, liqflag, l, ciwpmc, clwpmc, rei, rel, taormc, taucmc, ssacmc, asmcmc)
    deallocate(l)
 end subroutine ref_sw_cldprmc
+
+! Chou-Suarez LW coefficient tables (irrad_constants, rad_constants): data modules only -- irrad.F90 itself is not
+! buildable here (module gettau -> MAPL_ConstantsMod).
+subroutine ref_chou_lw_dump_tables(cpath, n) bind(C, name='ref_chou_lw_dump_tables')
+   use iso_c_binding
+   use ref_glue_io
+   use irrad_constants
+   use rad_constants, only: aib_ir, awb_ir, aiw_ir, aww_ir, aig_ir, awg_ir
+   implicit none
+   character(kind=c_char), intent(in) :: cpath(*)
+   integer(c_int), value :: n
+   call open_blob(cpath, n)
+   call put('xkw', xkw); call put('xke', xke); call put('mw', mw); call put('aw', aw); call put('bw', bw); call put('pm', pm)
+   call put('fkw', fkw); call put('gkw', gkw); call put('cb', cb); call put('dcb', dcb)
+   call put('w11', w11); call put('w12', w12); call put('w13', w13); call put('p11', p11); call put('p12', p12); call put('p13', p13)
+   call put('dwe', dwe); call put('dpe', dpe)
+   call put('c1', c1); call put('c2', c2); call put('c3', c3); call put('oo1', oo1); call put('oo2', oo2); call put('oo3', oo3)
+   call put('h11', h11); call put('h12', h12); call put('h13', h13); call put('h21', h21); call put('h22', h22); call put('h23', h23)
+   call put('h81', h81); call put('h82', h82); call put('h83', h83)
+   call put('aib_ir', aib_ir); call put('awb_ir', awb_ir); call put('aiw_ir', aiw_ir); call put('aww_ir', aww_ir)
+   call put('aig_ir', aig_ir); call put('awg_ir', awg_ir)
+   call close_blob
+end subroutine ref_chou_lw_dump_tables

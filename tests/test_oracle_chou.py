@@ -1,0 +1,76 @@
+"""CPU: the plain-C restatement of the Chou-Suarez LW scheme `irrad` (oracle/chou_oracle_impl.h).
+
+PARITY UNPINNED: irrad.F90 cannot be built here (module gettau needs MAPL_ConstantsMod) and the reference has no fixtures
+for it; only its coefficient tables are reference data.  These tests therefore hold the restatement to (a) the algorithm's own
+invariants and (b) consistency with the RRTMG_LW oracle, which IS pinned bit-exactly to the reference, on the same profiles
+(the survey measured irrad OLR 270.67 vs RRTMG_LW 266.93 W m-2 on its test profile: the schemes agree to a few W m-2)."""
+import numpy as np
+from geosradiation_gridcomp_amd import synth
+from oracle import clib
+
+FL = ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad")
+
+
+def test_irrad_clear_sky_consistent_with_pinned_rrtmg_lw():
+    inp = synth.make_columns(24, 72, start=100, cloudy_frac=0.0, aerosol=False)
+    o = clib.irrad(synth.chou_lw_inputs(inp), "f64")
+    r = clib.rrtmg_lw(inp, "f64")
+    assert o["rc"] == 0
+    olr_c, olr_r = -o["flxu"][0], r["uflx"][-1]
+    np.testing.assert_allclose(olr_c, olr_r, rtol=0.03)                       # different spectroscopy: a few W m-2
+    np.testing.assert_allclose(-o["flxu"][-1], r["uflx"][0], rtol=2e-3)       # surface emission + reflection
+    np.testing.assert_allclose(o["flxd"][-1], r["dflx"][0], rtol=0.04)
+    np.testing.assert_allclose(-o["dfdts"][-1], r["duflx_dTs"][0], rtol=5e-3)  # d(sigma T^4 eps)/dT at the surface
+    np.testing.assert_allclose(-o["dfdts"][0], r["duflx_dTs"][-1], rtol=0.10)  # ... transmitted to the top
+    # no clouds, no aerosol: the four flavours coincide
+    for k in ("flcu", "flau", "flxau"):
+        np.testing.assert_array_equal(o[k], o["flxu"])
+    for k in ("flcd", "flad", "flxad"):
+        np.testing.assert_array_equal(o[k], o["flxd"])
+    # sign convention (upward negative), tiny downward flux at the model top, monotone downward flux
+    assert (o["flxu"] < 0).all() and (o["flxd"] >= 0).all() and (o["flxd"][0] < 1.0).all()
+    assert (np.diff(o["flxd"], axis=0) > -1e-9).all()
+    assert (o["sfcem"] < 0).all() and (np.abs(o["sfcem"]) <= np.abs(o["flxu"][-1]) + 1e-9).all()
+    assert (o["taudiag"] == 0).all()
+
+
+def test_irrad_clouds_and_aerosols():
+    inp = synth.make_columns(32, 72, start=300, cloudy_frac=0.7, aerosol=True)
+    ch = synth.chou_lw_inputs(inp, aerosol=True)
+    o = clib.irrad(ch, "f64")
+    assert o["rc"] == 0
+    cloudy = (inp["cldf"] > 0).any(axis=0)
+    assert cloudy.any() and (~cloudy).any()
+    # clouds trap longwave: all-sky OLR <= clear-sky OLR, all-sky surface downward flux >= clear-sky
+    assert (-o["flxu"][0] <= -o["flcu"][0] + 1e-9).all()
+    assert (o["flxd"][-1] >= o["flcd"][-1] - 1e-9).all()
+    assert ((-o["flcu"][0] - -o["flxu"][0])[cloudy] > 0.01).any()
+    np.testing.assert_array_equal(o["flxu"][:, ~cloudy], o["flcu"][:, ~cloudy])
+    # aerosol-free flavours differ from the aerosol ones, and absorbing aerosol increases the surface downward flux
+    assert np.abs(o["flau"] - o["flcu"]).max() > 1e-3
+    assert (o["flcd"][-1] >= o["flad"][-1] - 1e-9).all()
+    # the reference rescales taua / ssaa / asya in place (irrad.F90:655-678): tau -> tau (1 - ssa f), ssaa -> ssa, asya -> g
+    big = ch["taua"] > 0.001
+    assert big.any()
+    assert (o["taua_out"][big] <= ch["taua"][big] * (1 + 1e-6)).all() and (o["taua_out"][~big] == ch["taua"][~big]).all()
+    np.testing.assert_allclose(o["ssaa_out"][big & (ch["ssaa"] > 0.001)], (ch["ssaa"] / np.maximum(ch["taua"], 1e-30))[big & (ch["ssaa"] > 0.001)], rtol=1e-6)
+    # cloud optical thickness diagnostic only where there is condensate
+    assert (o["taudiag"][:, :, ~cloudy] == 0).all() and (o["taudiag"][:, :, cloudy] > 0).any()
+    # r4 and r8 instantiations agree to fp32 round-off of an O(np^2) sum
+    o4 = clib.irrad(ch, "f32")
+    for k in FL:
+        assert np.abs(o4[k].astype(np.float64) - o[k]).max() < 5e-2, k
+
+
+def test_irrad_trace_gases_and_band10():
+    inp = synth.make_columns(8, 72, start=900, cloudy_frac=0.0)
+    ch = synth.chou_lw_inputs(inp)
+    a = clib.irrad(ch, "f64", trace=True)
+    b = clib.irrad(ch, "f64", trace=False)
+    # n2o, ch4, cfcs and the minor co2 bands absorb: including them lowers the OLR by O(1-10) W m-2
+    d = -b["flxu"][0] - -a["flxu"][0]
+    assert (d > 0.5).all() and (d < 15).all()
+    # a warmer surface raises OLR by ~ dfdts * dT (linear response)
+    ch2 = dict(ch); ch2["tg"] = ch["tg"] + 1.0; ch2["tv"] = ch2["tg"]
+    c = clib.irrad(ch2, "f64")
+    np.testing.assert_allclose(c["flxu"][0] - a["flxu"][0], a["dfdts"][0], rtol=0.02)
