@@ -7,6 +7,7 @@ calls into the reference:
     rrtmg_lw(ncol, nlay, psize, dudTs, ...) rrtmg_lw_rad.F90:15-23
     rrtmg_sw_ini()                          SW rrtmg_sw_init.F90:23
     rrtmg_sw(rpart, ncol, nlay, scon, ...)  SW rrtmg_sw_rad.F90:68-124
+    irrad(m, np, ple, ta, wa, oa, tb, ...)  GEOSirrad_GridComp/irrad.F90:27-35 (Chou-Suarez LW)
     generate_stochastic_clouds(...)         cloud_subcol_gen.F90:132-137
     clearCounts_threeBand(...)              cloud_subcol_gen.F90:611-614
     set_inhomogeneity / unset_inhomogeneity cloud_condensate_inhomogeneity.F90:45,75
@@ -58,6 +59,7 @@ class Context:
         if tables:
             self.rrtmg_lw_ini()
             self.rrtmg_sw_ini()
+            self.irrad_ini()
 
     def close(self):
         if self.h:
@@ -86,6 +88,11 @@ class Context:
     def rrtmg_sw_ini(self, path=None):
         path = path or os.path.join(_lib.DATA, f"rrtmg_sw_{self._kind()}.grtb")
         self._chk(self.L.geosrad_load_tables_sw(self.h, os.fsencode(path)))
+
+    def irrad_ini(self, path=None):
+        """uploads irrad_constants / rad_constants (the reference keeps them as module data: no init routine there)"""
+        path = path or os.path.join(_lib.DATA, f"chou_lw_{self._kind()}.grtb")
+        self._chk(self.L.geosrad_load_tables_chou_lw(self.h, os.fsencode(path)))
 
     def set_inhomogeneity(self, ih, path=None):
         if ih and path is None:
@@ -229,6 +236,48 @@ class Context:
             *[v(k) for k in _SW_COT], ci(1 if do_drfband else 0), v("drband"), v("dfband"), _p(bs), _p(ind))
         self._chk(rc)
 
+    # ---- Chou-Suarez LW, host arrays ---------------------------------------------------------------------
+    def irrad(self, m, np_, ple, ta, wa, oa, tb, co2, trace, n2o, ch4, cfc11, cfc12, cfc22, cwc, fcld, ict, icb, reff,
+              ns, fs, tg, eg, tv, ev, rv, na, nb, taua, ssaa, asya):
+        """irrad (irrad.F90:27).  Returns dict(flxu, flcu, flau, flxau, flxd, flcd, flad, flxad, dfdts (np+1, m); sfcem (m);
+        taudiag (10, np, m); taua, ssaa, asya = the in-out aerosol arrays after the call)."""
+        dt = self.dtype
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        ple, ta, wa, oa, tb, n2o, ch4, cfc11, cfc12, cfc22, cwc, fcld, reff, fs, tg, eg, tv, ev, rv = map(
+            c, (ple, ta, wa, oa, tb, n2o, ch4, cfc11, cfc12, cfc22, cwc, fcld, reff, fs, tg, eg, tv, ev, rv))
+        aer = [None if a is None else np.array(a, dtype=dt, order="C", copy=True) for a in (taua, ssaa, asya)]
+        assert ple.shape == (np_ + 1, m) and ta.shape == (np_, m)
+        out = {k: np.zeros((np_ + 1, m), dtype=dt) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts")}
+        out["sfcem"] = np.zeros(m, dtype=dt)
+        out["taudiag"] = np.zeros((10, np_, m), dtype=dt)
+        ci = ctypes.c_int
+        rc = self.L.geosrad_irrad(
+            self.h, ci(m), ci(np_), _p(ple), _p(ta), _p(wa), _p(oa), _p(tb), ctypes.c_double(co2), ci(1 if trace else 0), _p(n2o), _p(ch4),
+            _p(cfc11), _p(cfc12), _p(cfc22), _p(cwc), _p(fcld), ci(int(ict)), ci(int(icb)), _p(reff), ci(int(ns)), _p(fs), _p(tg), _p(eg),
+            _p(tv), _p(ev), _p(rv), ci(int(na)), ci(int(nb)), _p(aer[0]), _p(aer[1]), _p(aer[2]),
+            *[_p(out[k]) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts", "sfcem", "taudiag")])
+        self._chk(rc)
+        out.update(taua=aer[0], ssaa=aer[1], asya=aer[2])
+        return out
+
+    def irrad_columns(self, ch, trace=True):
+        """Convenience: `ch` as produced by synth.chou_lw_inputs."""
+        n1, m = ch["ple"].shape
+        return self.irrad(m, n1 - 1, ch["ple"], ch["ta"], ch["wa"], ch["oa"], ch["tb"], ch["co2"], trace, ch["n2o"], ch["ch4"], ch["cfc11"],
+                          ch["cfc12"], ch["cfc22"], ch["cwc"], ch["fcld"], ch["ict"], ch["icb"], ch["reff"], ch["ns"], ch["fs"], ch["tg"],
+                          ch["eg"], ch["tv"], ch["ev"], ch["rv"], ch["na"], ch["nb"], ch["taua"], ch["ssaa"], ch["asya"])
+
+    def irrad_dev(self, stream, m, np_, ptr, co2, trace, ict, icb, ns, na, nb):
+        """`ptr`: dict name -> device address for every array argument of irrad (inputs, in-out aerosols, outputs)."""
+        v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
+        ci = ctypes.c_int
+        rc = self.L.geosrad_irrad_dev(
+            self.h, ctypes.c_void_p(stream), ci(m), ci(np_), v("ple"), v("ta"), v("wa"), v("oa"), v("tb"), ctypes.c_double(co2),
+            ci(1 if trace else 0), v("n2o"), v("ch4"), v("cfc11"), v("cfc12"), v("cfc22"), v("cwc"), v("fcld"), ci(int(ict)), ci(int(icb)),
+            v("reff"), ci(int(ns)), v("fs"), v("tg"), v("eg"), v("tv"), v("ev"), v("rv"), ci(int(na)), ci(int(nb)), v("taua"), v("ssaa"),
+            v("asya"), *[v(k) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts", "sfcem", "taudiag")])
+        self._chk(rc)
+
     # ---- RRTMG_LW, device pointers (bench / drivers that keep data in HBM) -------------------------------------
     def rrtmg_lw_dev(self, stream, ncol, nlay, dudTs, ptr, iceflg, liqflg, dyofyr, cloudLM, cloudMH, band_output=None):
         """`ptr`: dict name -> device address (int) for every argument array of rrtmg_lw (inputs and outputs)."""
@@ -248,7 +297,7 @@ class Context:
     def profile_read(self):
         """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
         out = {}
-        for k in range(10):
+        for k in range(12):
             ms = ctypes.c_double(); n = ctypes.c_long()
             self._chk(self.L.geosrad_profile_read(self.h, ctypes.c_int(k), ctypes.byref(ms), ctypes.byref(n)))
             out[self.L.geosrad_kernel_name(ctypes.c_int(k)).decode()] = (ms.value, n.value)

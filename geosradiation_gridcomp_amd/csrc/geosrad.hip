@@ -15,6 +15,7 @@
 #include "lw_kernels.hpp"
 #include "sw_kernels.hpp"
 #include "mcica_kernels.hpp"
+#include "chou_kernels.hpp"
 
 using namespace geosrad;
 
@@ -198,8 +199,8 @@ struct geosrad_ctx {
     struct Span { int kid; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> evpool;
-    double prof_ms[12] = {0};
-    long prof_n[12] = {0};
+    double prof_ms[16] = {0};
+    long prof_n[16] = {0};
     hipEvent_t getev()
     {
         hipEvent_t e = nullptr;
@@ -245,6 +246,11 @@ struct geosrad_ctx {
                           int32_t *cldy, void *ciwp_s, void *clwp_s) = 0;
     virtual int check(hipStream_t st) = 0;
     virtual int set_tables_sw(const void *blob, size_t n) = 0;
+    virtual int set_tables_chou_lw(const void *blob, size_t n) = 0;
+    virtual int irrad_dev(hipStream_t st, int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na,
+                          int nb, void *const *aer, void *const *out) = 0;
+    virtual int irrad_host(int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb,
+                           void *const *aer, void *const *out) = 0;
     virtual int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg,
                        int liqflg, int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
                        int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
@@ -258,6 +264,11 @@ enum SwIn { S_PLAY, S_PLEV, S_TLAY, S_H2O, S_O3, S_CO2, S_CH4, S_O2, S_CLD, S_CI
             S_SSAAER, S_ASMAER, S_COSZEN, S_ASDIR, S_ASDIF, S_ALDIR, S_ALDIF, S_NIN };
 enum SwOutIx { SO_UFLX, SO_DFLX, SO_UFLXC, SO_DFLXC, SO_NIRR, SO_NIRF, SO_PARR, SO_PARF, SO_UVRR, SO_UVRF, SO_FSWBAND, SO_COT0,
                SO_DRBAND = SO_COT0 + 8, SO_DFBAND, SO_NOUT };
+
+// irrad: order of the `in` (19) / `aer` (3, in-out) / `out` (11) pointer arrays
+enum ChIn { C_PLE, C_TA, C_WA, C_OA, C_TB, C_N2O, C_CH4, C_CFC11, C_CFC12, C_CFC22, C_CWC, C_FCLD, C_REFF, C_FS, C_TG, C_EG, C_TV, C_EV,
+            C_RV, C_NIN };
+enum ChOutIx { CO_FLXU, CO_FLCU, CO_FLAU, CO_FLXAU, CO_FLXD, CO_FLCD, CO_FLAD, CO_FLXAD, CO_DFDTS, CO_SFCEM, CO_TAUDIAG, CO_NOUT };
 
 // order of the `in` pointer array of lw_dev / lw_host
 enum LwIn { I_PLAY, I_PLEV, I_TLAY, I_TLEV, I_TSFC, I_EMIS, I_H2O, I_O3, I_CO2, I_CH4, I_N2O, I_O2, I_CFC11, I_CFC12, I_CFC22,
@@ -287,6 +298,12 @@ template <typename R> struct Ctx : geosrad_ctx {
     SwDev<R> *d_S = nullptr;
     bool have_sw = false;
     char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0;
+    // Chou-Suarez LW tables + workspace
+    char *d_tab_ch = nullptr; size_t tab_ch_bytes = 0;
+    ChouDev<R> h_C{};
+    ChouDev<R> *d_C = nullptr;
+    bool have_chou = false;
+    char *d_ws_ch = nullptr; size_t ws_ch_bytes = 0;
     // McICA segment plans (jump-ahead constants), cached per (mode, nsubcol, nlay, inhomogeneous?)
     struct PlanEntry { McSegDev *d_seg; int nseg; KissJump jsub, jhalf; };
     std::map<std::tuple<int, int, int, int>, PlanEntry> plans;
@@ -305,6 +322,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_ws) (void)hipFree(d_ws);
         for (auto &pe : plans) if (pe.second.d_seg) (void)hipFree(pe.second.d_seg);
         if (d_tab_sw) (void)hipFree(d_tab_sw);
+        if (d_tab_ch) (void)hipFree(d_tab_ch);
+        if (d_C) (void)hipFree(d_C);
+        if (d_ws_ch) (void)hipFree(d_ws_ch);
         if (d_S) (void)hipFree(d_S);
         if (d_ws_sw) (void)hipFree(d_ws_sw);
         if (d_err) (void)hipFree(d_err);
@@ -321,6 +341,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         HIPCHK(hipMemset(d_err, 0, 256));
         HIPCHK(hipMalloc((void **)&d_T, sizeof(LwDev<R>)));
         HIPCHK(hipMalloc((void **)&d_S, sizeof(SwDev<R>)));
+        HIPCHK(hipMalloc((void **)&d_C, sizeof(ChouDev<R>)));
         // Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
         const double adl[4] = {1.4315, 2.1219, 7., -25.584}, rdl[4] = {0.72192, 0.78996, 8.5, 40.404};
         for (int i = 0; i < 4; i++) { h_T.aam[i] = (R)(sizeof(R) == 4 ? (float)adl[i] : adl[i]); h_T.ram[i] = (R)(sizeof(R) == 4 ? (float)rdl[i] : rdl[i]); }
@@ -474,7 +495,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return sync_T();
     }
 
-    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + io_bytes + tab_bytes + tab_sw_bytes; }
+    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
     struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
@@ -1032,6 +1053,142 @@ template <typename R> struct Ctx : geosrad_ctx {
     }
 
     // ---- stand-alone McICA generator, host pointers ------------------------------------------------------------------
+
+    // =====================================================================================================
+    // Chou-Suarez longwave (irrad)
+    // =====================================================================================================
+    int set_tables_chou_lw(const void *blob, size_t nbytes) override
+    {
+        HIPCHK(hipSetDevice(device));
+        Blob B;
+        if (!B.parse(blob, nbytes)) return fail(GEOSRAD_ETABLE, B.err);
+        if (B.realbytes != (int)sizeof(R)) return fail(GEOSRAD_ETABLE, "table blob real size does not match the context's real_kind");
+        TableStage<R> S(B);
+        ChouDev<R> &T = h_C;
+        memset(&T, 0, sizeof(T));
+        auto cp = [&](R *dst, const char *nm, size_t n) { const R *s = S.get(nm, n); if (s) memcpy(dst, s, n * sizeof(R)); };
+        cp(T.xkw, "xkw", 9); cp(T.xke, "xke", 9); cp(T.aw, "aw", 9); cp(T.bw, "bw", 9); cp(T.pm, "pm", 9);
+        cp(T.fkw, "fkw", 54); cp(T.gkw, "gkw", 18); cp(T.cb, "cb", 60); cp(T.dcb, "dcb", 50);
+        cp(T.aib, "aib_ir", 30); cp(T.awb, "awb_ir", 40); cp(T.aiw, "aiw_ir", 40); cp(T.aww, "aww_ir", 40); cp(T.aig, "aig_ir", 40);
+        cp(T.awg, "awg_ir", 40);
+        { int32_t mw[9]; if (S.ints("mw", 9, mw)) for (int k = 0; k < 9; k++) T.mw[k] = mw[k]; }
+        T.w11 = S.scalar("w11"); T.w12 = S.scalar("w12"); T.w13 = S.scalar("w13"); T.p11 = S.scalar("p11"); T.p12 = S.scalar("p12");
+        T.p13 = S.scalar("p13"); T.dwe = S.scalar("dwe"); T.dpe = S.scalar("dpe");
+        S.raw(&T.c1, "c1", 26 * 30); S.raw(&T.c2, "c2", 26 * 30); S.raw(&T.c3, "c3", 26 * 30);
+        S.raw(&T.oo1, "oo1", 26 * 21); S.raw(&T.oo2, "oo2", 26 * 21); S.raw(&T.oo3, "oo3", 26 * 21);
+        S.raw(&T.h11, "h11", 26 * 31); S.raw(&T.h12, "h12", 26 * 31); S.raw(&T.h13, "h13", 26 * 31);
+        S.raw(&T.h21, "h21", 26 * 31); S.raw(&T.h22, "h22", 26 * 31); S.raw(&T.h23, "h23", 26 * 31);
+        S.raw(&T.h81, "h81", 26 * 31); S.raw(&T.h82, "h82", 26 * 31); S.raw(&T.h83, "h83", 26 * 31);
+        if (!S.missing.empty()) return fail(GEOSRAD_ETABLE, "missing/ill-shaped table entries: " + S.missing);
+        if (d_tab_ch) { HIPCHK(hipFree(d_tab_ch)); d_tab_ch = nullptr; }
+        tab_ch_bytes = S.stage.size();
+        HIPCHK(hipMalloc((void **)&d_tab_ch, tab_ch_bytes));
+        HIPCHK(hipMemcpy(d_tab_ch, S.stage.data(), tab_ch_bytes, hipMemcpyHostToDevice));
+        for (auto &f : S.fix) *f.first = (const R *)(d_tab_ch + f.second);
+        HIPCHK(hipMemcpy(d_C, &h_C, sizeof(ChouDev<R>), hipMemcpyHostToDevice));
+        have_chou = true;
+        return GEOSRAD_OK;
+    }
+
+    int irrad_dev(hipStream_t st, int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb,
+                  void *const *aer, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (!have_chou) return fail(GEOSRAD_EINVAL, "Chou-Suarez LW tables not set: call geosrad_load_tables_chou_lw first");
+        if (m <= 0 || np < 4 || np > 400) return fail(GEOSRAD_EINVAL, "bad m/np");
+        if (ns < 1 || ns > 15) return fail(GEOSRAD_EINVAL, "ns must be in 1..15");
+        if (!(ict >= 1 && ict < icb && icb <= np)) return fail(GEOSRAD_EINPUT, "ict / icb must satisfy 1 <= ict < icb <= np");
+        if (nb < 10) return fail(GEOSRAD_EINVAL, "nb (bands of the aerosol arrays) must be 10");
+        for (int k = 0; k < C_NIN; k++) if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array");
+        for (int k = 0; k < CO_NOUT; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+        if (na > 0 && (!aer[0] || !aer[1] || !aer[2])) return fail(GEOSRAD_EINVAL, "na > 0 but taua/ssaa/asya null");
+        const int K1 = np + 1, K2 = np + 2;
+        const int nc_max = m < chunk ? m : chunk;
+        const size_t need = al((size_t)nc_max * CF_NFIELD * K1 * sizeof(R)) + al((size_t)nc_max * CH_NB * CH_NKIND * K2 * sizeof(R));
+        if (need > ws_ch_bytes) {
+            if (d_ws_ch) { HIPCHK(hipFree(d_ws_ch)); d_ws_ch = nullptr; ws_ch_bytes = 0; }
+            if (hipMalloc((void **)&d_ws_ch, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the irrad workspace failed");
+            ws_ch_bytes = need;
+        }
+        const int nband = trace ? 10 : 9;      // irrad.F90:478 (band 10 only with trace gases)
+        const size_t lds = (size_t)(25 * K1 + 23 * K2) * sizeof(R) + (size_t)K1 * sizeof(int);
+        if (lds > 64 * 1024) {
+            if (hipFuncSetAttribute((const void *)k_chou_bands<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(GEOSRAD_EINVAL, "np too large for the LDS-resident band state");
+        }
+        for (int c0 = 0; c0 < m; c0 += nc_max) {
+            const int nc = (m - c0) < nc_max ? (m - c0) : nc_max;
+            ChouArgs<R> A{};
+            A.m = nc; A.ld = m; A.np = np; A.trace = trace; A.ict = ict; A.icb = icb; A.ns = ns; A.na = na; A.nb = nb; A.co2 = (R)co2;
+            auto P = [&](int k) { return (const R *)in[k] + c0; };
+            A.ple = P(C_PLE); A.ta = P(C_TA); A.wa = P(C_WA); A.oa = P(C_OA); A.tb = P(C_TB); A.n2o = P(C_N2O); A.ch4 = P(C_CH4);
+            A.cfc11 = P(C_CFC11); A.cfc12 = P(C_CFC12); A.cfc22 = P(C_CFC22); A.cwc = P(C_CWC); A.fcld = P(C_FCLD); A.reff = P(C_REFF);
+            A.fs = P(C_FS); A.tg = P(C_TG); A.eg = P(C_EG); A.tv = P(C_TV); A.ev = P(C_EV); A.rv = P(C_RV);
+            A.taua = aer[0] ? (R *)aer[0] + c0 : nullptr; A.ssaa = aer[1] ? (R *)aer[1] + c0 : nullptr; A.asya = aer[2] ? (R *)aer[2] + c0 : nullptr;
+            A.taudiag = (R *)out[CO_TAUDIAG] + c0;
+            A.rec = (R *)d_ws_ch; A.part = (R *)(d_ws_ch + al((size_t)nc_max * CF_NFIELD * K1 * sizeof(R)));
+            A.err = d_err + 2;
+            span_begin(10, st);
+            hipLaunchKernelGGL(k_chou_prep<R>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, A);
+            span_end(st);
+            span_begin(11, st);
+            hipLaunchKernelGGL(k_chou_bands<R>, dim3((unsigned)nc, nband), dim3(64), lds, st, A, (const ChouDev<R> *)d_C);
+            span_end(st);
+            ChouOut<R> O{};
+            auto Q = [&](int k) { return (R *)out[k] + c0; };
+            O.flxu = Q(CO_FLXU); O.flcu = Q(CO_FLCU); O.flau = Q(CO_FLAU); O.flxau = Q(CO_FLXAU); O.flxd = Q(CO_FLXD); O.flcd = Q(CO_FLCD);
+            O.flad = Q(CO_FLAD); O.flxad = Q(CO_FLXAD); O.dfdts = Q(CO_DFDTS); O.sfcem = Q(CO_SFCEM);
+            hipLaunchKernelGGL(k_chou_reduce<R>, dim3((unsigned)nc), dim3(64), 0, st, A, O, nband);
+            if (!trace)      // band 10 of taudiag stays zero (the reference zeroes the array and never reaches band 10)
+                for (int k = 0; k < np; k++)
+                    HIPCHK(hipMemsetAsync((R *)out[CO_TAUDIAG] + ((size_t)9 * np + k) * m + c0, 0, (size_t)nc * sizeof(R), st));
+        }
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int irrad_host(int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb, void *const *aer,
+                   void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (m <= 0 || np <= 0 || ns < 1 || nb < 1) return fail(GEOSRAD_EINVAL, "bad m/np/ns/nb");
+        const size_t cl = (size_t)m * np, cv = (size_t)m * (np + 1);
+        size_t insz[C_NIN];
+        for (int k = 0; k < C_NIN; k++) insz[k] = cl;
+        insz[C_PLE] = cv; insz[C_TB] = m; insz[C_CWC] = insz[C_REFF] = cl * 4; insz[C_FS] = insz[C_TG] = insz[C_TV] = (size_t)m * ns;
+        insz[C_EG] = insz[C_EV] = insz[C_RV] = (size_t)m * ns * 10;
+        size_t outsz[CO_NOUT];
+        for (int k = 0; k < CO_NOUT; k++) outsz[k] = cv;
+        outsz[CO_SFCEM] = m; outsz[CO_TAUDIAG] = cl * 10;
+        const size_t aersz = cl * nb;
+        size_t off = 0;
+        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
+        size_t ino[C_NIN], outo[CO_NOUT], aero[3];
+        for (int k = 0; k < C_NIN; k++) { if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array"); ino[k] = take(insz[k]); }
+        for (int k = 0; k < CO_NOUT; k++) { if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array"); outo[k] = take(outsz[k]); }
+        for (int k = 0; k < 3; k++) aero[k] = take(aersz);
+        int rc = ensure_io(off);
+        if (rc) return rc;
+        const void *din[C_NIN]; void *dout[CO_NOUT]; void *daer[3];
+        for (int k = 0; k < C_NIN; k++) {
+            din[k] = d_io + ino[k];
+            HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
+        }
+        for (int k = 0; k < CO_NOUT; k++) dout[k] = d_io + outo[k];
+        for (int k = 0; k < 3; k++) {
+            daer[k] = (na > 0 && aer[k]) ? d_io + aero[k] : nullptr;
+            if (daer[k]) HIPCHK(hipMemcpyAsync(daer[k], aer[k], aersz * sizeof(R), hipMemcpyHostToDevice, stream));
+        }
+        rc = irrad_dev(stream, m, np, din, co2, trace, ict, icb, ns, na, nb, daer, dout);
+        if (rc) return rc;
+        rc = check(stream);
+        if (rc) return rc;
+        for (int k = 0; k < CO_NOUT; k++) HIPCHK(hipMemcpyAsync(out[k], dout[k], outsz[k] * sizeof(R), hipMemcpyDeviceToHost, stream));
+        for (int k = 0; k < 3; k++) if (daer[k]) HIPCHK(hipMemcpyAsync(aer[k], daer[k], aersz * sizeof(R), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return GEOSRAD_OK;
+    }
+
     // ---- stand-alone McICA generator ---------------------------------------------------------------------------------
     char *d_mc = nullptr; size_t mc_bytes = 0;      // alpha / rcorr scratch of the stand-alone generator
     int mcica_dev(hipStream_t st, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
@@ -1250,6 +1407,44 @@ int geosrad_rrtmg_sw_taumol(geosrad_ctx *c, int ncol, int nlay, double scon, int
     return c->sw_host(ncol, nlay, scon, 1.0, isolvar, in, 3, 1, 1, 0, 1, 2, 0, cc.data(), out, 0, bndscl, indsolvar, dbg);
 }
 
+int geosrad_set_tables_chou_lw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_chou_lw(blob, n) : GEOSRAD_EINVAL; }
+int geosrad_load_tables_chou_lw(geosrad_ctx *c, const char *path)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    std::vector<char> buf;
+    int rc = read_file(c, path, buf);
+    return rc ? rc : c->set_tables_chou_lw(buf.data(), buf.size());
+}
+
+#define CH_PACK()                                                                                                                   \
+    const void *in[C_NIN] = {ple, ta, wa, oa, tb, n2o, ch4, cfc11, cfc12, cfc22, cwc, fcld, reff, fs, tg, eg, tv, ev, rv};             \
+    void *aer[3] = {taua, ssaa, asya};                                                                                              \
+    void *out[CO_NOUT] = {flxu, flcu, flau, flxau, flxd, flcd, flad, flxad, dfdts, sfcem, taudiag}
+
+int geosrad_irrad(geosrad_ctx *c, int m, int np, const void *ple, const void *ta, const void *wa, const void *oa, const void *tb, double co2,
+                  int trace, const void *n2o, const void *ch4, const void *cfc11, const void *cfc12, const void *cfc22, const void *cwc,
+                  const void *fcld, int ict, int icb, const void *reff, int ns, const void *fs, const void *tg, const void *eg,
+                  const void *tv, const void *ev, const void *rv, int na, int nb, void *taua, void *ssaa, void *asya, void *flxu,
+                  void *flcu, void *flau, void *flxau, void *flxd, void *flcd, void *flad, void *flxad, void *dfdts, void *sfcem,
+                  void *taudiag)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    CH_PACK();
+    return c->irrad_host(m, np, in, co2, trace, ict, icb, ns, na, nb, aer, out);
+}
+
+int geosrad_irrad_dev(geosrad_ctx *c, void *stream, int m, int np, const void *ple, const void *ta, const void *wa, const void *oa,
+                      const void *tb, double co2, int trace, const void *n2o, const void *ch4, const void *cfc11, const void *cfc12,
+                      const void *cfc22, const void *cwc, const void *fcld, int ict, int icb, const void *reff, int ns, const void *fs,
+                      const void *tg, const void *eg, const void *tv, const void *ev, const void *rv, int na, int nb, void *taua,
+                      void *ssaa, void *asya, void *flxu, void *flcu, void *flau, void *flxau, void *flxd, void *flcd, void *flad,
+                      void *flxad, void *dfdts, void *sfcem, void *taudiag)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    CH_PACK();
+    return c->irrad_dev((hipStream_t)stream, m, np, in, co2, trace, ict, icb, ns, na, nb, aer, out);
+}
+
 #define LW_PACK_IN()                                                                                                     \
     const void *in[I_NIN] = {play, plev, tlay, tlev, tsfc, emis, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, \
                              cfc12vmr, cfc22vmr, ccl4vmr, cldf, ciwp, clwp, rei, rel, tauaer, zm, alat}
@@ -1290,12 +1485,12 @@ int geosrad_profile(geosrad_ctx *c, int enable)
     if (!c) return GEOSRAD_EINVAL;
     c->prof_collect();
     c->profiling = enable != 0;
-    for (int k = 0; k < 12; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    for (int k = 0; k < 16; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return GEOSRAD_OK;
 }
 int geosrad_profile_read(geosrad_ctx *c, int kernel_id, double *total_ms, long *launches)
 {
-    if (!c || kernel_id < 0 || kernel_id >= 12) return GEOSRAD_EINVAL;
+    if (!c || kernel_id < 0 || kernel_id >= 16) return GEOSRAD_EINVAL;
     (void)hipSetDevice(c->device);
     c->prof_collect();
     if (total_ms) *total_ms = c->prof_ms[kernel_id];
@@ -1304,9 +1499,9 @@ int geosrad_profile_read(geosrad_ctx *c, int kernel_id, double *total_ms, long *
 }
 const char *geosrad_kernel_name(int kernel_id)
 {
-    static const char *nm[10] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce",
-                                 "k_sw_validate", "k_sw_setcoef", "k_sw_bands", "k_sw_reduce"};
-    return kernel_id >= 0 && kernel_id < 10 ? nm[kernel_id] : "";
+    static const char *nm[12] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce",
+                                 "k_sw_validate", "k_sw_setcoef", "k_sw_bands", "k_sw_reduce", "k_chou_prep", "k_chou_bands"};
+    return kernel_id >= 0 && kernel_id < 12 ? nm[kernel_id] : "";
 }
 
 int geosrad_check(geosrad_ctx *c, void *stream) { return c ? c->check((hipStream_t)stream) : GEOSRAD_EINVAL; }

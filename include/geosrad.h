@@ -9,6 +9,8 @@
  *   geosrad_rrtmg_sw[_dev]        <- rrtmg_sw_rad::rrtmg_sw
  *                                    GEOSsolar_GridComp/RRTMG/rrtmg_sw/gcm_model/src/rrtmg_sw_rad.F90:68-124
  *   geosrad_set_tables_sw         <- rrtmg_sw_init::rrtmg_sw_ini           .../src/rrtmg_sw_init.F90:23
+ *   geosrad_irrad[_dev]           <- irradmod::irrad                       GEOSirrad_GridComp/irrad.F90:27-35
+ *   geosrad_set_tables_chou_lw    <- irrad_constants / rad_constants (data modules)  GEOSirrad_GridComp/irradconstants.F90
  *   geosrad_mcica[_dev]           <- cloud_subcol_gen::generate_stochastic_clouds
  *                                    GEOS_RadiationShared/cloud_subcol_gen.F90:132-137
  *   geosrad_clearcounts           <- cloud_subcol_gen::clearCounts_threeBand   .../cloud_subcol_gen.F90:611-614
@@ -72,6 +74,9 @@ int geosrad_load_tables_lw(geosrad_ctx *ctx, const char *path);
 /* what rrtmg_sw_ini leaves in rrsw_kgNN/rrsw_ref/rrsw_cld/rrsw_wvn/NRLSSI2 (SW/rrtmg_sw_init.F90:23-190) */
 int geosrad_set_tables_sw(geosrad_ctx *ctx, const void *blob, size_t nbytes);
 int geosrad_load_tables_sw(geosrad_ctx *ctx, const char *path);
+/* the coefficient tables of the Chou-Suarez LW scheme: irrad_constants + the IR part of rad_constants */
+int geosrad_set_tables_chou_lw(geosrad_ctx *ctx, const void *blob, size_t nbytes);
+int geosrad_load_tables_chou_lw(geosrad_ctx *ctx, const char *path);
 /* ih = 0 homogeneous (blob ignored), 1 beta, 2 gamma; blob = xcw(1000,140) table of that kind */
 int geosrad_set_inhomogeneity(geosrad_ctx *ctx, int ih, const void *xcw_blob, size_t nbytes);
 int geosrad_load_inhomogeneity(geosrad_ctx *ctx, int ih, const char *path);
@@ -120,7 +125,7 @@ int geosrad_check(geosrad_ctx *ctx, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, around every kernel the *_dev entry points
  * enqueue (kernel ids 0..5 = k_validate_pwv, k_setcoef, k_overlap, k_mcica, k_lw_bands, k_lw_reduce; 6..9 =
- * k_sw_validate, k_sw_setcoef, k_sw_bands, k_sw_reduce; k_overlap / k_mcica are shared by LW and SW).
+ * k_sw_validate, k_sw_setcoef, k_sw_bands, k_sw_reduce; 10..11 = k_chou_prep, k_chou_bands; k_overlap / k_mcica are shared).
  * geosrad_profile(ctx, 1) resets and enables, geosrad_profile_read() waits for the recorded events and
  * returns the accumulated milliseconds and launch count of one kernel. */
 int geosrad_profile(geosrad_ctx *ctx, int enable);
@@ -185,6 +190,29 @@ int geosrad_rrtmg_sw_taumol(geosrad_ctx *ctx, int ncol, int nlay, double scon, i
                             const void *play, const void *plev, const void *tlay,
                             const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
                             const void *bndscl, const void *indsolvar, void *taug, void *taur, void *ssi);
+
+/* ---- Chou-Suarez longwave ------------------------------------------------------------------------------
+ * irrad (GEOSirrad_GridComp/irrad.F90:27-35), same argument order (the logical `trace` as int).  Layers from the TOP down
+ * (k = 1 top layer), ple in Pa; Fortran layouts: ple (m,np+1); ta, wa, oa, n2o, ch4, cfc11, cfc12, cfc22, fcld (m,np); tb (m);
+ * cwc, reff (m,np,4); fs, tg, tv (m,ns); eg, ev, rv (m,ns,10); taua, ssaa, asya (m,np,nb) are IN-OUT and rescaled in place
+ * exactly like the reference does (irrad.F90:655-678; may be NULL when na == 0); outputs flxu ... flxad, dfdts (m,np+1),
+ * sfcem (m), taudiag (m,np,10).  Upward fluxes are negative.  Non-OVERCAST behaviour (maximum-random overlap).
+ * trace == 0: band 10 is skipped for every column (the reference `return`s out of its column loop there, irrad.F90:478;
+ * GEOS always passes trace = .true.). */
+int geosrad_irrad(geosrad_ctx *ctx, int m, int np, const void *ple, const void *ta, const void *wa, const void *oa, const void *tb,
+                  double co2, int trace, const void *n2o, const void *ch4, const void *cfc11, const void *cfc12, const void *cfc22,
+                  const void *cwc, const void *fcld, int ict, int icb, const void *reff,
+                  int ns, const void *fs, const void *tg, const void *eg, const void *tv, const void *ev, const void *rv,
+                  int na, int nb, void *taua, void *ssaa, void *asya,
+                  void *flxu, void *flcu, void *flau, void *flxau, void *flxd, void *flcd, void *flad, void *flxad,
+                  void *dfdts, void *sfcem, void *taudiag);
+int geosrad_irrad_dev(geosrad_ctx *ctx, void *stream, int m, int np, const void *ple, const void *ta, const void *wa, const void *oa,
+                      const void *tb, double co2, int trace, const void *n2o, const void *ch4, const void *cfc11, const void *cfc12,
+                      const void *cfc22, const void *cwc, const void *fcld, int ict, int icb, const void *reff,
+                      int ns, const void *fs, const void *tg, const void *eg, const void *tv, const void *ev, const void *rv,
+                      int na, int nb, void *taua, void *ssaa, void *asya,
+                      void *flxu, void *flcu, void *flau, void *flxau, void *flxd, void *flcd, void *flad, void *flxad,
+                      void *dfdts, void *sfcem, void *taudiag);
 
 /* ---- McICA ------------------------------------------------------------------------------------------
  * generate_stochastic_clouds (cloud_subcol_gen.F90:132): profile inputs Fortran (nlay,dncol) there; here
