@@ -211,3 +211,29 @@ def chou_lw_inputs(inp, aerosol=False):
         out["na"] = 0
         out["taua"] = np.zeros((10, nlay, m), dtype=f32); out["ssaa"] = np.zeros_like(out["taua"]); out["asya"] = np.zeros_like(out["taua"])
     return out
+
+
+def chou_sw_inputs(inp, aerosol=False):
+    """Inputs of the Chou-Suarez `sorad` for the columns of `make_columns` (same conventions as chou_lw_inputs; pl in hPa;
+    hk_uv / hk_ir = the band weights the GridComp passes, here the defaults of sorad_constants)."""
+    import os
+    from . import _lib
+    from .tableblob import read_blob
+    f32 = np.float32
+    ch = chou_lw_inputs(inp)
+    nlay, m = inp["play"].shape
+    _, t = read_blob(os.path.join(_lib.DATA, "chou_sw_r8.grtb"))
+    out = dict(cosz=np.maximum(inp["coszen"], 1e-4).astype(f32), pl=(ch["ple"].astype(np.float64) * 0.01).astype(f32), ta=ch["ta"], wa=ch["wa"],
+               oa=ch["oa"], co2=ch["co2"], cwc=ch["cwc"], fcld=ch["fcld"], ict=ch["ict"], icb=ch["icb"], reff=ch["reff"],
+               hk_uv=np.asarray(t["hk_uv_old"], dtype=np.float64), hk_ir=np.ascontiguousarray(np.asarray(t["hk_ir_old"], dtype=np.float64).T),
+               rsuvbm=inp["asdir"], rsuvdf=inp["asdif"], rsirbm=inp["aldir"], rsirdf=inp["aldif"], nb=8)
+    if aerosol and "tauaer_sw" in inp:
+        tau = inp["tauaer_sw"][:8, ::-1].astype(np.float64)
+        ssa = inp["ssaaer_sw"][:8, ::-1].astype(np.float64)
+        g = inp["asmaer_sw"][:8, ::-1].astype(np.float64)
+        out["taua"] = np.ascontiguousarray(tau).astype(f32)
+        out["ssaa"] = np.ascontiguousarray(tau * ssa).astype(f32)
+        out["asya"] = np.ascontiguousarray(tau * ssa * g).astype(f32)
+    else:
+        out["taua"] = np.zeros((8, nlay, m), dtype=f32); out["ssaa"] = np.zeros_like(out["taua"]); out["asya"] = np.zeros_like(out["taua"])
+    return out

@@ -72,6 +72,13 @@ def _load_tables(sfx):
         flat = np.ascontiguousarray(np.asfortranarray(a).ravel(order="F"))
         _keep[(sfx, "sw_" + name)] = flat
         setter(name.encode(), _p(flat))
+    _, t = read_blob(os.path.join(DATA, f"chou_sw_{kind}.grtb"))
+    setter = getattr(_lib, f"oracle_chou_sw_set_table_{sfx}")
+    setter.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    for name, a in t.items():
+        flat = np.ascontiguousarray(np.asfortranarray(a).ravel(order="F"))
+        _keep[(sfx, "chsw_" + name)] = flat
+        setter(name.encode(), _p(flat))
     _, t = read_blob(os.path.join(DATA, f"chou_lw_{kind}.grtb"))
     setter = getattr(_lib, f"oracle_chou_set_table_{sfx}")
     setter.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
@@ -278,4 +285,28 @@ def irrad(ch, prec="f32", trace=True):
         *[_p(out[k]) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts", "sfcem", "taudiag")])
     out["rc"] = rc
     out.update({k + "_out": v for k, v in aer.items()})
+    return out
+
+
+def sorad(cs, prec="f32", do_drfband=True):
+    """Chou-Suarez SW (sorad.F90:43).  `cs` from synth.chou_sw_inputs.  Fluxes are fractions of the TOA insolation."""
+    L = lib()
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    n1, m = cs["pl"].shape
+    npl = n1 - 1
+    a = {k: _c(cs[k], dt) for k in ("cosz", "pl", "ta", "wa", "oa", "cwc", "fcld", "reff", "hk_uv", "hk_ir", "taua", "ssaa", "asya", "rsuvbm",
+                                    "rsuvdf", "rsirbm", "rsirdf")}
+    out = {k: np.zeros((n1, m), dtype=dt) for k in ("flx", "flc", "flxu", "flcu")}
+    for k in ("fdiruv", "fdifuv", "fdirpar", "fdifpar", "fdirir", "fdifir"):
+        out[k] = np.zeros(m, dtype=dt)
+    out["flx_sfc_band"] = np.zeros((8, m), dtype=dt); out["drband"] = np.zeros((8, m), dtype=dt); out["dfband"] = np.zeros((8, m), dtype=dt)
+    R = ctypes.c_float if sfx == "f32" else ctypes.c_double
+    ci = ctypes.c_int
+    rc = getattr(L, f"oracle_sorad_{sfx}")(
+        ci(m), ci(npl), ci(8), _p(a["cosz"]), _p(a["pl"]), _p(a["ta"]), _p(a["wa"]), _p(a["oa"]), R(cs["co2"]), _p(a["cwc"]), _p(a["fcld"]),
+        ci(int(cs["ict"])), ci(int(cs["icb"])), _p(a["reff"]), _p(a["hk_uv"]), _p(a["hk_ir"]), _p(a["taua"]), _p(a["ssaa"]), _p(a["asya"]),
+        _p(a["rsuvbm"]), _p(a["rsuvdf"]), _p(a["rsirbm"]), _p(a["rsirdf"]), _p(out["flx"]), _p(out["flc"]), _p(out["fdiruv"]),
+        _p(out["fdifuv"]), _p(out["fdirpar"]), _p(out["fdifpar"]), _p(out["fdirir"]), _p(out["fdifir"]), _p(out["flxu"]), _p(out["flcu"]),
+        _p(out["flx_sfc_band"]), ci(1 if do_drfband else 0), _p(out["drband"]), _p(out["dfband"]))
+    out["rc"] = rc
     return out

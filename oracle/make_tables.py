@@ -20,6 +20,7 @@ def main():
         reflib.dump_lw_tables(os.path.join(DATA, f"rrtmg_lw_{kind}.grtb"), kind)
         reflib.dump_sw_tables(os.path.join(DATA, f"rrtmg_sw_{kind}.grtb"), kind)
         reflib.dump_chou_lw_tables(os.path.join(DATA, f"chou_lw_{kind}.grtb"), kind)
+        reflib.dump_chou_sw_tables(os.path.join(DATA, f"chou_sw_{kind}.grtb"), kind)
     # condensate-inhomogeneity tables: beta (ih=1) and gamma (ih=2).  r4 is recovered bit-exactly through the
     # public zcw_lookup(); the r8 table is the decimal literal of each entry parsed as double, obtained by
     # snapping the (<=2e-14 rel.) r8 recovery to the shortest decimal of the exact r4 value.

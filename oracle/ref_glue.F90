@@ -709,3 +709,24 @@ subroutine ref_chou_lw_dump_tables(cpath, n) bind(C, name='ref_chou_lw_dump_tabl
    call put('aig_ir', aig_ir); call put('awg_ir', awg_ir)
    call close_blob
 end subroutine ref_chou_lw_dump_tables
+
+! Chou-Suarez SW coefficient tables (sorad_constants, UV/NIR part of rad_constants): data modules only -- sorad.F90 itself is
+! not buildable here (MAPL_ConstantsMod).
+subroutine ref_chou_sw_dump_tables(cpath, n) bind(C, name='ref_chou_sw_dump_tables')
+   use iso_c_binding
+   use ref_glue_io
+   use sorad_constants
+   use rad_constants, only: aig_uv, awg_uv, arg_uv, aib_uv, awb_uv, arb_uv, aib_nir, awb_nir, arb_nir, aia_nir, awa_nir, ara_nir, &
+      aig_nir, awg_nir, arg_nir, caib, caif
+   implicit none
+   character(kind=c_char), intent(in) :: cpath(*)
+   integer(c_int), value :: n
+   call open_blob(cpath, n)
+   call put('zk_uv', zk_uv); call put('wk_uv', wk_uv); call put('ry_uv', ry_uv); call put('xk_ir', xk_ir); call put('ry_ir', ry_ir)
+   call put('coa', coa); call put('cah', cah); call put('hk_uv_old', hk_uv_old); call put('hk_ir_old', hk_ir_old)
+   call put('aig_uv', aig_uv); call put('awg_uv', awg_uv); call put('arg_uv', arg_uv); call put('aib_uv', aib_uv)
+   call put('awb_uv', awb_uv); call put('arb_uv', arb_uv); call put('aib_nir', aib_nir); call put('awb_nir', awb_nir)
+   call put('arb_nir', arb_nir); call put('aia_nir', aia_nir); call put('awa_nir', awa_nir); call put('ara_nir', ara_nir)
+   call put('aig_nir', aig_nir); call put('awg_nir', awg_nir); call put('arg_nir', arg_nir); call put('caib', caib); call put('caif', caif)
+   call close_blob
+end subroutine ref_chou_sw_dump_tables

@@ -179,6 +179,12 @@ def dump_chou_lw_tables(path, kind="r4"):
     lib(kind).ref_chou_lw_dump_tables(p, ctypes.c_int(len(p)))
 
 
+def dump_chou_sw_tables(path, kind="r4"):
+    """sorad_constants + rad_constants (UV / NIR part): data modules of the Chou-Suarez SW scheme"""
+    p = os.fsencode(path)
+    lib(kind).ref_chou_sw_dump_tables(p, ctypes.c_int(len(p)))
+
+
 def sw_setcoef_taumol(inp, isolvar=0, svar=(1.0, 1.0, 1.0), svar_bnd=None, kind="r4"):
     """setcoef_sw + taumol_sw.  Returns taug,taur numpy (ncol,112,nlay); ssi,sfluxzen (ncol,112); colmol (ncol,nlay)."""
     L = lib(kind)

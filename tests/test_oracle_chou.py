@@ -74,3 +74,51 @@ def test_irrad_trace_gases_and_band10():
     ch2 = dict(ch); ch2["tg"] = ch["tg"] + 1.0; ch2["tv"] = ch2["tg"]
     c = clib.irrad(ch2, "f64")
     np.testing.assert_allclose(c["flxu"][0] - a["flxu"][0], a["dfdts"][0], rtol=0.02)
+
+
+# ---- sorad (oracle/chou_sw_oracle_impl.h, parity unpinned for the same reason) ---------------------------------------------
+def test_sorad_clear_sky_consistent_with_rrtmg_sw():
+    inp = synth.make_columns(24, 72, start=100, cloudy_frac=0.0, aerosol=False)
+    o = clib.sorad(synth.chou_sw_inputs(inp), "f64")
+    r = clib.rrtmg_sw(inp, prec="f64", normFlx=1)                        # fractions of the TOA insolation, like sorad
+    assert o["rc"] == 0
+    net_r = r["swdflx"] - r["swuflx"]
+    np.testing.assert_allclose(o["flx"][0], net_r[-1], atol=0.02)          # TOA net (planetary co-albedo)
+    np.testing.assert_allclose(o["flx"][-1], net_r[0], atol=0.02)          # surface net
+    np.testing.assert_allclose(o["flxu"][0], r["swuflx"][-1], atol=0.02)
+    # energy bookkeeping: TOA net + TOA up = insolation minus the O2/CO2 reduction df(1) >= 0 (tiny at the top)
+    tot = o["flx"][0] + o["flxu"][0]
+    assert (tot <= 1.0 + 1e-12).all() and (tot > 0.995).all()
+    # no clouds: all-sky == clear-sky; net flux decreases downwards (absorption), upward flux positive
+    np.testing.assert_array_equal(o["flx"], o["flc"]); np.testing.assert_array_equal(o["flxu"], o["flcu"])
+    assert (np.diff(o["flx"], axis=0) <= 1e-12).all() and (o["flxu"] >= 0).all()
+    # surface partition: direct + diffuse over the three regions = total downward; band net fluxes sum to the surface net flux
+    dn_sfc = o["flx"][-1] + o["flxu"][-1]
+    part = o["fdiruv"] + o["fdifuv"] + o["fdirpar"] + o["fdifpar"] + o["fdirir"] + o["fdifir"]
+    np.testing.assert_allclose(part, dn_sfc, rtol=0.05)                    # equal before the O2/CO2 rescaling (sorad.F90:1554-1584)
+    np.testing.assert_allclose(o["flx_sfc_band"].sum(axis=0), o["flx"][-1], rtol=1e-6)
+    np.testing.assert_allclose((o["drband"] + o["dfband"]).sum(axis=0), part, rtol=1e-12)
+
+
+def test_sorad_clouds_aerosols_and_precision():
+    inp = synth.make_columns(32, 72, start=300, cloudy_frac=0.7, aerosol=True)
+    cs = synth.chou_sw_inputs(inp, aerosol=True)
+    o = clib.sorad(cs, "f64")
+    cloudy = (inp["cldf"] > 0).any(axis=0)
+    assert o["rc"] == 0 and cloudy.any() and (~cloudy).any()
+    np.testing.assert_array_equal(o["flx"][:, ~cloudy], o["flc"][:, ~cloudy])
+    # clouds brighten the planet: all-sky TOA upward >= clear-sky, surface net <= clear-sky (on average clearly so)
+    assert (o["flxu"][0] - o["flcu"][0])[cloudy].mean() > 0.01
+    assert (o["flc"][-1] - o["flx"][-1])[cloudy].mean() > 0.01
+    for k in ("flx", "flc", "flxu", "flcu"):
+        assert np.isfinite(o[k]).all() and (o[k] > -1e-9).all() and (o[k] < 1 + 1e-9).all()
+    # r4 vs r8 instantiation (deledd is fp64 in both, sorad.F90:1614-1625)
+    o4 = clib.sorad(cs, "f32")
+    for k in ("flx", "flc", "flxu", "flcu"):
+        assert np.abs(o4[k].astype(np.float64) - o[k]).max() < 2e-4, k
+    # a black surface under a non-scattering... every column: darker surface -> less upward flux at TOA
+    cs2 = dict(cs)
+    for k in ("rsuvbm", "rsuvdf", "rsirbm", "rsirdf"):
+        cs2[k] = np.zeros_like(cs[k])
+    b = clib.sorad(cs2, "f64")
+    assert (b["flxu"][-1] == 0).all() and (b["flxu"][0] <= o["flxu"][0] + 1e-12).all()
