@@ -8,6 +8,7 @@ calls into the reference:
     rrtmg_sw_ini()                          SW rrtmg_sw_init.F90:23
     rrtmg_sw(rpart, ncol, nlay, scon, ...)  SW rrtmg_sw_rad.F90:68-124
     irrad(m, np, ple, ta, wa, oa, tb, ...)  GEOSirrad_GridComp/irrad.F90:27-35 (Chou-Suarez LW)
+    sorad(m, np, nb, cosz, pl, ta, ...)     GEOSsolar_GridComp/sorad.F90:43-51 (Chou-Suarez SW)
     generate_stochastic_clouds(...)         cloud_subcol_gen.F90:132-137
     clearCounts_threeBand(...)              cloud_subcol_gen.F90:611-614
     set_inhomogeneity / unset_inhomogeneity cloud_condensate_inhomogeneity.F90:45,75
@@ -60,6 +61,7 @@ class Context:
             self.rrtmg_lw_ini()
             self.rrtmg_sw_ini()
             self.irrad_ini()
+            self.sorad_ini()
 
     def close(self):
         if self.h:
@@ -93,6 +95,10 @@ class Context:
         """uploads irrad_constants / rad_constants (the reference keeps them as module data: no init routine there)"""
         path = path or os.path.join(_lib.DATA, f"chou_lw_{self._kind()}.grtb")
         self._chk(self.L.geosrad_load_tables_chou_lw(self.h, os.fsencode(path)))
+
+    def sorad_ini(self, path=None):
+        path = path or os.path.join(_lib.DATA, f"chou_sw_{self._kind()}.grtb")
+        self._chk(self.L.geosrad_load_tables_chou_sw(self.h, os.fsencode(path)))
 
     def set_inhomogeneity(self, ih, path=None):
         if ih and path is None:
@@ -278,6 +284,51 @@ class Context:
             v("asya"), *[v(k) for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts", "sfcem", "taudiag")])
         self._chk(rc)
 
+    # ---- Chou-Suarez SW, host arrays ---------------------------------------------------------------------
+    def sorad(self, m, np_, nb, cosz, pl, ta, wa, oa, co2, cwc, fcld, ict, icb, reff, hk_uv, hk_ir, taua, ssaa, asya,
+              rsuvbm, rsuvdf, rsirbm, rsirdf, do_drfband=False):
+        """sorad (sorad.F90:43).  Returns dict(flx, flc, flxu, flcu (np+1, m); fdiruv ... fdifir (m); flx_sfc_band[, drband, dfband] (8, m))."""
+        dt = self.dtype
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        cosz, pl, ta, wa, oa, cwc, fcld, reff, hk_uv, hk_ir, taua, ssaa, asya, rsuvbm, rsuvdf, rsirbm, rsirdf = map(
+            c, (cosz, pl, ta, wa, oa, cwc, fcld, reff, hk_uv, hk_ir, taua, ssaa, asya, rsuvbm, rsuvdf, rsirbm, rsirdf))
+        assert pl.shape == (np_ + 1, m) and hk_uv.shape == (5,) and hk_ir.shape == (10, 3)
+        out = {k: np.zeros((np_ + 1, m), dtype=dt) for k in ("flx", "flc", "flxu", "flcu")}
+        for k in ("fdiruv", "fdifuv", "fdirpar", "fdifpar", "fdirir", "fdifir"):
+            out[k] = np.zeros(m, dtype=dt)
+        out["flx_sfc_band"] = np.zeros((8, m), dtype=dt)
+        if do_drfband:
+            out["drband"] = np.zeros((8, m), dtype=dt); out["dfband"] = np.zeros((8, m), dtype=dt)
+        ci = ctypes.c_int
+        rc = self.L.geosrad_sorad(
+            self.h, ci(m), ci(np_), ci(nb), _p(cosz), _p(pl), _p(ta), _p(wa), _p(oa), ctypes.c_double(co2), _p(cwc), _p(fcld), ci(int(ict)),
+            ci(int(icb)), _p(reff), _p(hk_uv), _p(hk_ir), _p(taua), _p(ssaa), _p(asya), _p(rsuvbm), _p(rsuvdf), _p(rsirbm), _p(rsirdf),
+            _p(out["flx"]), _p(out["flc"]), _p(out["fdiruv"]), _p(out["fdifuv"]), _p(out["fdirpar"]), _p(out["fdifpar"]), _p(out["fdirir"]),
+            _p(out["fdifir"]), _p(out["flxu"]), _p(out["flcu"]), _p(out["flx_sfc_band"]), ci(1 if do_drfband else 0), _p(out.get("drband")),
+            _p(out.get("dfband")))
+        self._chk(rc)
+        return out
+
+    def sorad_columns(self, cs, do_drfband=False):
+        """Convenience: `cs` as produced by synth.chou_sw_inputs."""
+        n1, m = cs["pl"].shape
+        return self.sorad(m, n1 - 1, cs["nb"], cs["cosz"], cs["pl"], cs["ta"], cs["wa"], cs["oa"], cs["co2"], cs["cwc"], cs["fcld"], cs["ict"],
+                          cs["icb"], cs["reff"], cs["hk_uv"], cs["hk_ir"], cs["taua"], cs["ssaa"], cs["asya"], cs["rsuvbm"], cs["rsuvdf"],
+                          cs["rsirbm"], cs["rsirdf"], do_drfband=do_drfband)
+
+    def sorad_dev(self, stream, m, np_, nb, ptr, co2, ict, icb, hk_uv, hk_ir, do_drfband=False):
+        """`ptr`: dict name -> device address for every array argument of sorad; hk_uv / hk_ir are host arrays."""
+        dt = self.dtype
+        v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
+        hu = np.ascontiguousarray(hk_uv, dtype=dt); hi = np.ascontiguousarray(hk_ir, dtype=dt)
+        ci = ctypes.c_int
+        rc = self.L.geosrad_sorad_dev(
+            self.h, ctypes.c_void_p(stream), ci(m), ci(np_), ci(nb), v("cosz"), v("pl"), v("ta"), v("wa"), v("oa"), ctypes.c_double(co2),
+            v("cwc"), v("fcld"), ci(int(ict)), ci(int(icb)), v("reff"), _p(hu), _p(hi), v("taua"), v("ssaa"), v("asya"), v("rsuvbm"),
+            v("rsuvdf"), v("rsirbm"), v("rsirdf"), v("flx"), v("flc"), v("fdiruv"), v("fdifuv"), v("fdirpar"), v("fdifpar"), v("fdirir"),
+            v("fdifir"), v("flxu"), v("flcu"), v("flx_sfc_band"), ci(1 if do_drfband else 0), v("drband"), v("dfband"))
+        self._chk(rc)
+
     # ---- RRTMG_LW, device pointers (bench / drivers that keep data in HBM) -------------------------------------
     def rrtmg_lw_dev(self, stream, ncol, nlay, dudTs, ptr, iceflg, liqflg, dyofyr, cloudLM, cloudMH, band_output=None):
         """`ptr`: dict name -> device address (int) for every argument array of rrtmg_lw (inputs and outputs)."""
@@ -297,7 +348,7 @@ class Context:
     def profile_read(self):
         """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
         out = {}
-        for k in range(12):
+        for k in range(14):
             ms = ctypes.c_double(); n = ctypes.c_long()
             self._chk(self.L.geosrad_profile_read(self.h, ctypes.c_int(k), ctypes.byref(ms), ctypes.byref(n)))
             out[self.L.geosrad_kernel_name(ctypes.c_int(k)).decode()] = (ms.value, n.value)

@@ -16,6 +16,7 @@
 #include "sw_kernels.hpp"
 #include "mcica_kernels.hpp"
 #include "chou_kernels.hpp"
+#include "sorad_kernels.hpp"
 
 using namespace geosrad;
 
@@ -247,6 +248,11 @@ struct geosrad_ctx {
     virtual int check(hipStream_t st) = 0;
     virtual int set_tables_sw(const void *blob, size_t n) = 0;
     virtual int set_tables_chou_lw(const void *blob, size_t n) = 0;
+    virtual int set_tables_chou_sw(const void *blob, size_t n) = 0;
+    virtual int sorad_dev(hipStream_t st, int m, int np, int nb, const void *const *in, double co2, int ict, int icb, const void *hk_uv,
+                          const void *hk_ir, void *const *out, int do_drfband) = 0;
+    virtual int sorad_host(int m, int np, int nb, const void *const *in, double co2, int ict, int icb, const void *hk_uv, const void *hk_ir,
+                           void *const *out, int do_drfband) = 0;
     virtual int irrad_dev(hipStream_t st, int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na,
                           int nb, void *const *aer, void *const *out) = 0;
     virtual int irrad_host(int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb,
@@ -264,6 +270,12 @@ enum SwIn { S_PLAY, S_PLEV, S_TLAY, S_H2O, S_O3, S_CO2, S_CH4, S_O2, S_CLD, S_CI
             S_SSAAER, S_ASMAER, S_COSZEN, S_ASDIR, S_ASDIF, S_ALDIR, S_ALDIF, S_NIN };
 enum SwOutIx { SO_UFLX, SO_DFLX, SO_UFLXC, SO_DFLXC, SO_NIRR, SO_NIRF, SO_PARR, SO_PARF, SO_UVRR, SO_UVRF, SO_FSWBAND, SO_COT0,
                SO_DRBAND = SO_COT0 + 8, SO_DFBAND, SO_NOUT };
+
+// sorad: order of the `in` (15) / `out` (13) pointer arrays
+enum SoIn { SI_COSZ, SI_PL, SI_TA, SI_WA, SI_OA, SI_CWC, SI_FCLD, SI_REFF, SI_TAUA, SI_SSAA, SI_ASYA, SI_RSUVBM, SI_RSUVDF, SI_RSIRBM,
+            SI_RSIRDF, SI_NIN };
+enum SoOutIx { SOO_FLX, SOO_FLC, SOO_FDIRUV, SOO_FDIFUV, SOO_FDIRPAR, SOO_FDIFPAR, SOO_FDIRIR, SOO_FDIFIR, SOO_FLXU, SOO_FLCU,
+               SOO_SFCBAND, SOO_DRBAND, SOO_DFBAND, SOO_NOUT };
 
 // irrad: order of the `in` (19) / `aer` (3, in-out) / `out` (11) pointer arrays
 enum ChIn { C_PLE, C_TA, C_WA, C_OA, C_TB, C_N2O, C_CH4, C_CFC11, C_CFC12, C_CFC22, C_CWC, C_FCLD, C_REFF, C_FS, C_TG, C_EG, C_TV, C_EV,
@@ -298,6 +310,12 @@ template <typename R> struct Ctx : geosrad_ctx {
     SwDev<R> *d_S = nullptr;
     bool have_sw = false;
     char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0;
+    // Chou-Suarez SW tables + workspace
+    char *d_tab_so = nullptr; size_t tab_so_bytes = 0;
+    SoradDev<R> h_O{};
+    SoradDev<R> *d_O = nullptr;
+    bool have_sorad = false;
+    char *d_ws_so = nullptr; size_t ws_so_bytes = 0;
     // Chou-Suarez LW tables + workspace
     char *d_tab_ch = nullptr; size_t tab_ch_bytes = 0;
     ChouDev<R> h_C{};
@@ -323,6 +341,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (auto &pe : plans) if (pe.second.d_seg) (void)hipFree(pe.second.d_seg);
         if (d_tab_sw) (void)hipFree(d_tab_sw);
         if (d_tab_ch) (void)hipFree(d_tab_ch);
+        if (d_tab_so) (void)hipFree(d_tab_so);
+        if (d_O) (void)hipFree(d_O);
+        if (d_ws_so) (void)hipFree(d_ws_so);
         if (d_C) (void)hipFree(d_C);
         if (d_ws_ch) (void)hipFree(d_ws_ch);
         if (d_S) (void)hipFree(d_S);
@@ -342,6 +363,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         HIPCHK(hipMalloc((void **)&d_T, sizeof(LwDev<R>)));
         HIPCHK(hipMalloc((void **)&d_S, sizeof(SwDev<R>)));
         HIPCHK(hipMalloc((void **)&d_C, sizeof(ChouDev<R>)));
+        HIPCHK(hipMalloc((void **)&d_O, sizeof(SoradDev<R>)));
         // Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
         const double adl[4] = {1.4315, 2.1219, 7., -25.584}, rdl[4] = {0.72192, 0.78996, 8.5, 40.404};
         for (int i = 0; i < 4; i++) { h_T.aam[i] = (R)(sizeof(R) == 4 ? (float)adl[i] : adl[i]); h_T.ram[i] = (R)(sizeof(R) == 4 ? (float)rdl[i] : rdl[i]); }
@@ -495,7 +517,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return sync_T();
     }
 
-    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
+    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
     struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
@@ -1189,6 +1211,133 @@ template <typename R> struct Ctx : geosrad_ctx {
         return GEOSRAD_OK;
     }
 
+
+    // =====================================================================================================
+    // Chou-Suarez shortwave (sorad)
+    // =====================================================================================================
+    int set_tables_chou_sw(const void *blob, size_t nbytes) override
+    {
+        HIPCHK(hipSetDevice(device));
+        Blob B;
+        if (!B.parse(blob, nbytes)) return fail(GEOSRAD_ETABLE, B.err);
+        if (B.realbytes != (int)sizeof(R)) return fail(GEOSRAD_ETABLE, "table blob real size does not match the context's real_kind");
+        TableStage<R> S(B);
+        SoradDev<R> &T = h_O;
+        memset(&T, 0, sizeof(T));
+        auto cp = [&](R *dst, const char *nm, size_t n) { const R *s = S.get(nm, n); if (s) memcpy(dst, s, n * sizeof(R)); };
+        cp(T.zk_uv, "zk_uv", 5); cp(T.wk_uv, "wk_uv", 5); cp(T.ry_uv, "ry_uv", 5); cp(T.xk_ir, "xk_ir", 10); cp(T.ry_ir, "ry_ir", 3);
+        cp(T.aig_uv, "aig_uv", 3); cp(T.awg_uv, "awg_uv", 3); cp(T.arg_uv, "arg_uv", 3); cp(T.awb_uv, "awb_uv", 2); cp(T.arb_uv, "arb_uv", 2);
+        cp(T.awb_nir, "awb_nir", 6); cp(T.arb_nir, "arb_nir", 6); cp(T.aia_nir, "aia_nir", 9); cp(T.awa_nir, "awa_nir", 9);
+        cp(T.ara_nir, "ara_nir", 9); cp(T.aig_nir, "aig_nir", 9); cp(T.awg_nir, "awg_nir", 9); cp(T.arg_nir, "arg_nir", 9);
+        T.aib_uv = S.scalar("aib_uv"); T.aib_nir = S.scalar("aib_nir");
+        S.raw(&T.coa, "coa", 62 * 101); S.raw(&T.cah, "cah", 43 * 37); S.raw(&T.caib, "caib", 11 * 9 * 11); S.raw(&T.caif, "caif", 9 * 11);
+        if (!S.missing.empty()) return fail(GEOSRAD_ETABLE, "missing/ill-shaped table entries: " + S.missing);
+        if (d_tab_so) { HIPCHK(hipFree(d_tab_so)); d_tab_so = nullptr; }
+        tab_so_bytes = S.stage.size();
+        HIPCHK(hipMalloc((void **)&d_tab_so, tab_so_bytes));
+        HIPCHK(hipMemcpy(d_tab_so, S.stage.data(), tab_so_bytes, hipMemcpyHostToDevice));
+        for (auto &f : S.fix) *f.first = (const R *)(d_tab_so + f.second);
+        HIPCHK(hipMemcpy(d_O, &h_O, sizeof(SoradDev<R>), hipMemcpyHostToDevice));
+        have_sorad = true;
+        return GEOSRAD_OK;
+    }
+
+    int sorad_dev(hipStream_t st, int m, int np, int nb, const void *const *in, double co2, int ict, int icb, const void *hk_uv,
+                  const void *hk_ir, void *const *out, int do_drfband) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (!have_sorad) return fail(GEOSRAD_EINVAL, "Chou-Suarez SW tables not set: call geosrad_load_tables_chou_sw first");
+        if (m <= 0 || np < 4 || np > 400) return fail(GEOSRAD_EINVAL, "bad m/np");
+        if (nb < 8) return fail(GEOSRAD_EINVAL, "nb (bands of the aerosol arrays) must be 8");
+        if (!(ict >= 1 && ict < icb && icb <= np)) return fail(GEOSRAD_EINPUT, "ict / icb must satisfy 1 <= ict < icb < np + 1");
+        if (!hk_uv || !hk_ir) return fail(GEOSRAD_EINVAL, "hk_uv / hk_ir null");
+        for (int k = 0; k < SI_NIN; k++) if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array");
+        for (int k = 0; k < SOO_DRBAND; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+        if (do_drfband && (!out[SOO_DRBAND] || !out[SOO_DFBAND])) return fail(GEOSRAD_EINVAL, "do_drfband set but drband/dfband null");
+        const int K2 = np + 2;
+        const int nc_max = m < chunk ? m : chunk;
+        const size_t per = (size_t)nc_max * sizeof(R);
+        const size_t o_lay = 0, o_swh = o_lay + al(4 * K2 * per), o_colv = o_swh + al(K2 * per), o_cld = o_colv + al(8 * per),
+                     o_scr = o_cld + al((size_t)SO_NGRP * 4 * K2 * per), o_psum = o_scr + al((size_t)SO_NPASS * 34 * K2 * per),
+                     need = o_psum + al((size_t)SO_NPASS * 2 * per);
+        if (need > ws_so_bytes) {
+            if (d_ws_so) { HIPCHK(hipFree(d_ws_so)); d_ws_so = nullptr; ws_so_bytes = 0; }
+            if (hipMalloc((void **)&d_ws_so, need) != hipSuccess)
+                return fail(GEOSRAD_ENOMEM, "hipMalloc of the sorad workspace failed (" + std::to_string(need >> 20) + " MiB); lower it with geosrad_set_chunk()");
+            ws_so_bytes = need;
+        }
+        for (int c0 = 0; c0 < m; c0 += nc_max) {
+            const int nc = (m - c0) < nc_max ? (m - c0) : nc_max;
+            SoradArgs<R> A{};
+            A.m = nc; A.ld = m; A.np = np; A.ict = ict; A.icb = icb; A.do_drfband = do_drfband; A.co2 = (R)co2;
+            for (int p = 0; p < 5; p++) A.hk[p] = ((const R *)hk_uv)[p];
+            for (int ib = 0; ib < 3; ib++) for (int ik = 0; ik < 10; ik++) A.hk[5 + ib * 10 + ik] = ((const R *)hk_ir)[ik * 3 + ib];   // hk_ir(3,10)
+            auto P = [&](int k) { return (const R *)in[k] + c0; };
+            A.cosz = P(SI_COSZ); A.pl = P(SI_PL); A.ta = P(SI_TA); A.wa = P(SI_WA); A.oa = P(SI_OA); A.cwc = P(SI_CWC); A.fcld = P(SI_FCLD);
+            A.reff = P(SI_REFF); A.taua = P(SI_TAUA); A.ssaa = P(SI_SSAA); A.asya = P(SI_ASYA); A.rsuvbm = P(SI_RSUVBM);
+            A.rsuvdf = P(SI_RSUVDF); A.rsirbm = P(SI_RSIRBM); A.rsirdf = P(SI_RSIRDF);
+            A.lay = (R *)(d_ws_so + o_lay); A.swh = (R *)(d_ws_so + o_swh); A.colv = (R *)(d_ws_so + o_colv); A.cld = (R *)(d_ws_so + o_cld);
+            A.scr = (R *)(d_ws_so + o_scr); A.psum = (R *)(d_ws_so + o_psum);
+            const dim3 blk(256);
+            const unsigned gx = (unsigned)((nc + 255) / 256);
+            span_begin(12, st);
+            hipLaunchKernelGGL(k_sorad_prep<R>, dim3(gx), blk, 0, st, A);
+            hipLaunchKernelGGL(k_sorad_cloud<R>, dim3(gx, SO_NGRP), blk, 0, st, A, (const SoradDev<R> *)d_O);
+            span_end(st);
+            span_begin(13, st);
+            hipLaunchKernelGGL(k_sorad_pass<R>, dim3(gx, SO_NPASS), blk, 0, st, A, (const SoradDev<R> *)d_O);
+            span_end(st);
+            SoradOut<R> O{};
+            auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
+            O.flx = Q(SOO_FLX); O.flc = Q(SOO_FLC); O.fdiruv = Q(SOO_FDIRUV); O.fdifuv = Q(SOO_FDIFUV); O.fdirpar = Q(SOO_FDIRPAR);
+            O.fdifpar = Q(SOO_FDIFPAR); O.fdirir = Q(SOO_FDIRIR); O.fdifir = Q(SOO_FDIFIR); O.flxu = Q(SOO_FLXU); O.flcu = Q(SOO_FLCU);
+            O.flx_sfc_band = Q(SOO_SFCBAND); O.drband = Q(SOO_DRBAND); O.dfband = Q(SOO_DFBAND);
+            hipLaunchKernelGGL(k_sorad_reduce<R>, dim3(gx), blk, 0, st, A, (const SoradDev<R> *)d_O, O);
+        }
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int sorad_host(int m, int np, int nb, const void *const *in, double co2, int ict, int icb, const void *hk_uv, const void *hk_ir,
+                   void *const *out, int do_drfband) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (m <= 0 || np <= 0 || nb < 1) return fail(GEOSRAD_EINVAL, "bad m/np/nb");
+        const size_t cl = (size_t)m * np, cv = (size_t)m * (np + 1);
+        size_t insz[SI_NIN];
+        for (int k = 0; k < SI_NIN; k++) insz[k] = cl;
+        insz[SI_COSZ] = insz[SI_RSUVBM] = insz[SI_RSUVDF] = insz[SI_RSIRBM] = insz[SI_RSIRDF] = m; insz[SI_PL] = cv;
+        insz[SI_CWC] = insz[SI_REFF] = cl * 4; insz[SI_TAUA] = insz[SI_SSAA] = insz[SI_ASYA] = cl * nb;
+        size_t outsz[SOO_NOUT];
+        for (int k = 0; k < SOO_NOUT; k++) outsz[k] = m;
+        outsz[SOO_FLX] = outsz[SOO_FLC] = outsz[SOO_FLXU] = outsz[SOO_FLCU] = cv;
+        outsz[SOO_SFCBAND] = outsz[SOO_DRBAND] = outsz[SOO_DFBAND] = (size_t)m * 8;
+        size_t off = 0;
+        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
+        size_t ino[SI_NIN], outo[SOO_NOUT];
+        for (int k = 0; k < SI_NIN; k++) { if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array"); ino[k] = take(insz[k]); }
+        for (int k = 0; k < SOO_NOUT; k++) outo[k] = take(outsz[k]);
+        int rc = ensure_io(off);
+        if (rc) return rc;
+        const void *din[SI_NIN]; void *dout[SOO_NOUT];
+        for (int k = 0; k < SI_NIN; k++) {
+            din[k] = d_io + ino[k];
+            HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
+        }
+        for (int k = 0; k < SOO_NOUT; k++) dout[k] = d_io + outo[k];
+        rc = sorad_dev(stream, m, np, nb, din, co2, ict, icb, hk_uv, hk_ir, dout, do_drfband);
+        if (rc) return rc;
+        rc = check(stream);
+        if (rc) return rc;
+        for (int k = 0; k < SOO_NOUT; k++) {
+            if (!out[k]) continue;
+            if ((k == SOO_DRBAND || k == SOO_DFBAND) && !do_drfband) continue;
+            HIPCHK(hipMemcpyAsync(out[k], dout[k], outsz[k] * sizeof(R), hipMemcpyDeviceToHost, stream));
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        return GEOSRAD_OK;
+    }
+
     // ---- stand-alone McICA generator ---------------------------------------------------------------------------------
     char *d_mc = nullptr; size_t mc_bytes = 0;      // alpha / rcorr scratch of the stand-alone generator
     int mcica_dev(hipStream_t st, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
@@ -1445,6 +1594,42 @@ int geosrad_irrad_dev(geosrad_ctx *c, void *stream, int m, int np, const void *p
     return c->irrad_dev((hipStream_t)stream, m, np, in, co2, trace, ict, icb, ns, na, nb, aer, out);
 }
 
+int geosrad_set_tables_chou_sw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_chou_sw(blob, n) : GEOSRAD_EINVAL; }
+int geosrad_load_tables_chou_sw(geosrad_ctx *c, const char *path)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    std::vector<char> buf;
+    int rc = read_file(c, path, buf);
+    return rc ? rc : c->set_tables_chou_sw(buf.data(), buf.size());
+}
+
+#define SO_PACK()                                                                                                                    \
+    const void *in[SI_NIN] = {cosz, pl, ta, wa, oa, cwc, fcld, reff, taua, ssaa, asya, rsuvbm, rsuvdf, rsirbm, rsirdf};                 \
+    void *out[SOO_NOUT] = {flx, flc, fdiruv, fdifuv, fdirpar, fdifpar, fdirir, fdifir, flxu, flcu, flx_sfc_band, drband, dfband}
+
+int geosrad_sorad(geosrad_ctx *c, int m, int np, int nb, const void *cosz, const void *pl, const void *ta, const void *wa, const void *oa,
+                  double co2, const void *cwc, const void *fcld, int ict, int icb, const void *reff, const void *hk_uv, const void *hk_ir,
+                  const void *taua, const void *ssaa, const void *asya, const void *rsuvbm, const void *rsuvdf, const void *rsirbm,
+                  const void *rsirdf, void *flx, void *flc, void *fdiruv, void *fdifuv, void *fdirpar, void *fdifpar, void *fdirir,
+                  void *fdifir, void *flxu, void *flcu, void *flx_sfc_band, int do_drfband, void *drband, void *dfband)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    SO_PACK();
+    return c->sorad_host(m, np, nb, in, co2, ict, icb, hk_uv, hk_ir, out, do_drfband);
+}
+
+int geosrad_sorad_dev(geosrad_ctx *c, void *stream, int m, int np, int nb, const void *cosz, const void *pl, const void *ta, const void *wa,
+                      const void *oa, double co2, const void *cwc, const void *fcld, int ict, int icb, const void *reff, const void *hk_uv,
+                      const void *hk_ir, const void *taua, const void *ssaa, const void *asya, const void *rsuvbm, const void *rsuvdf,
+                      const void *rsirbm, const void *rsirdf, void *flx, void *flc, void *fdiruv, void *fdifuv, void *fdirpar,
+                      void *fdifpar, void *fdirir, void *fdifir, void *flxu, void *flcu, void *flx_sfc_band, int do_drfband,
+                      void *drband, void *dfband)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    SO_PACK();
+    return c->sorad_dev((hipStream_t)stream, m, np, nb, in, co2, ict, icb, hk_uv, hk_ir, out, do_drfband);
+}
+
 #define LW_PACK_IN()                                                                                                     \
     const void *in[I_NIN] = {play, plev, tlay, tlev, tsfc, emis, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, \
                              cfc12vmr, cfc22vmr, ccl4vmr, cldf, ciwp, clwp, rei, rel, tauaer, zm, alat}
@@ -1499,9 +1684,10 @@ int geosrad_profile_read(geosrad_ctx *c, int kernel_id, double *total_ms, long *
 }
 const char *geosrad_kernel_name(int kernel_id)
 {
-    static const char *nm[12] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce",
-                                 "k_sw_validate", "k_sw_setcoef", "k_sw_bands", "k_sw_reduce", "k_chou_prep", "k_chou_bands"};
-    return kernel_id >= 0 && kernel_id < 12 ? nm[kernel_id] : "";
+    static const char *nm[14] = {"k_validate_pwv", "k_setcoef", "k_overlap", "k_mcica", "k_lw_bands", "k_lw_reduce",
+                                 "k_sw_validate", "k_sw_setcoef", "k_sw_bands", "k_sw_reduce", "k_chou_prep", "k_chou_bands",
+                                 "k_sorad_prep", "k_sorad_pass"};
+    return kernel_id >= 0 && kernel_id < 14 ? nm[kernel_id] : "";
 }
 
 int geosrad_check(geosrad_ctx *c, void *stream) { return c ? c->check((hipStream_t)stream) : GEOSRAD_EINVAL; }

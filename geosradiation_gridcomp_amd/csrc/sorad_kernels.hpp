@@ -1,0 +1,498 @@
+// sorad_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) for the Chou-Suarez shortwave scheme `sorad`.
+//
+// Reference behaviour: GEOSsolar_GridComp/sorad.F90:43-1588 (SOLUV / SOLIR / CLDFLX inlined, O2 + CO2 flux reductions),
+// deledd :1592-1706; cloud optics GEOS_RadiationShared/getvistau.code, getnirtau.code.  Non-OVERCAST build.
+//
+// sorad is 35 independent spectral passes (5 UV/PAR bands + 3 NIR bands x 10 k-values), each a set of first-order vertical
+// recurrences (delta-Eddington layers + adding over 8 sky situations) -- the RRTMG_SW mapping applies: lane = column,
+// blockIdx.y = spectral pass, every per-level array of a pass in an HBM scratch plane [array][level][column] (coalesced):
+//   k_sorad_prep   : per column   - scaled absorber amounts, cloud-group covers, cloud top
+//   k_sorad_cloud  : per (column, optics group: UV/PAR + 3 NIR bands) - getvistau / getnirtau
+//   k_sorad_pass   : per (column, pass) - deledd of the clear / cloudy portion of every layer, CLDFLX
+//   k_sorad_reduce : per column   - weighted sum over the passes (hk_uv, hk_ir), flux reductions, surface rescaling
+// Sky situations of zero weight (ct = 0: a cloud group without cloud) are skipped: their contribution is `+ x * 0`.
+#pragma once
+#include "lw_kernels.hpp"
+
+namespace geosrad {
+
+constexpr int SO_NPASS = 35;      // 5 + 3 * 10
+constexpr int SO_NGRP = 4;        // cloud optics groups: 0 = UV/PAR, 1..3 = NIR bands
+
+template <typename R> struct SoradDev {
+    R zk_uv[5], wk_uv[5], ry_uv[5], xk_ir[10], ry_ir[3];
+    const R *coa, *cah, *caib, *caif;     // Fortran (62,101), (43,37), (11,9,11), (9,11)
+    R aig_uv[3], awg_uv[3], arg_uv[3], aib_uv, awb_uv[2], arb_uv[2], aib_nir, awb_nir[6], arb_nir[6], aia_nir[9], awa_nir[9], ara_nir[9],
+        aig_nir[9], awg_nir[9], arg_nir[9];
+};
+
+template <typename R> struct SoradArgs {
+    int m, ld, np, ict, icb, do_drfband;
+    R co2;
+    R hk[SO_NPASS];                       // hk_uv(1..5), then hk_ir(ib, ik) for ib = 1..3, ik = 1..10
+    const R *cosz, *pl, *ta, *wa, *oa, *cwc, *fcld, *reff, *taua, *ssaa, *asya, *rsuvbm, *rsuvdf, *rsirbm, *rsirdf;
+    // workspace
+    R *lay;          // [4][K2][m]: dp, wh, oh, scal
+    R *swh;          // [K2][m]    cumulative scaled water vapour (index k = 1..np+1)
+    R *colv;         // [8][m]: cc1, cc2, cc3, wvtoa, o3toa, scal0, ntop (as real), spare
+    R *cld;          // [SO_NGRP][4][K2][m]: tauclb, tauclf, asycl, ssacl
+    R *scr;          // [SO_NPASS][34][K2][m]: per-pass planes (see k_sorad_pass)
+    R *psum;         // [SO_NPASS][2][m]: fsdir, fsdif of the pass
+};
+template <typename R> struct SoradOut { R *flx, *flc, *fdiruv, *fdifuv, *fdirpar, *fdifpar, *fdirir, *fdifir, *flxu, *flcu, *flx_sfc_band, *drband, *dfband; };
+
+// deledd (:1592-1706) -- fp64 internally whatever the default real kind, as in the reference
+template <typename R> GR_DEV void so_deledd(R tau1, R ssc1, R g01, R cza1, R &rr1, R &tt1, R &td1)
+{
+    double zth = (double)cza1;
+    const double g0 = (double)g01, tau = (double)tau1, ssc = (double)ssc1;
+    const double ff = g0 * g0;
+    double xx = 1.0 - ff * ssc;
+    const double taup = tau * xx, sscp = ssc * (1.0 - ff) / xx, gp = g0 / (1.0 + g0);
+    xx = 3.0 * gp;
+    const double gm1 = (7.0 - sscp * (4.0 + xx)) * 0.25, gm2 = -(1.0 - sscp * (4.0 - xx)) * 0.25;
+    const double akk = sqrt((gm1 + gm2) * (gm1 - gm2));
+    xx = akk * zth;
+    double st7 = 1.0 - xx, st8 = 1.0 + xx, st3 = st7 * st8;
+    if (fabs(st3) < 1.e-8) {
+        zth = zth + 0.0010;
+        if (zth > 1.0) zth = zth - 0.0020;
+        xx = akk * zth; st7 = 1.0 - xx; st8 = 1.0 + xx; st3 = st7 * st8;
+    }
+    const double td = exp(-taup / zth);
+    const double gm3 = (2.0 - zth * 3.0 * gp) * 0.25;
+    xx = gm1 - gm2;
+    const double alf1 = gm1 - gm3 * xx, alf2 = gm2 + gm3 * xx;
+    xx = akk * 2.0;
+    const double all = (gm3 - alf2 * zth) * xx * td, bll = (1.0 - gm3 + alf1 * zth) * xx;
+    xx = akk * gm3;
+    const double cll = (alf2 + xx) * st7, dll = (alf2 - xx) * st8;
+    xx = akk * (1.0 - gm3);
+    const double fll = (alf1 + xx) * st8, ell = (alf1 - xx) * st7;
+    const double st2 = exp(-akk * taup), st4 = st2 * st2;
+    const double st1 = sscp / ((akk + gm1 + (akk - gm1) * st4) * st3);
+    double rr = (cll - dll * st4 - all * st2) * st1;
+    double tt = -((fll - ell * st4) * td - bll * st2) * st1;
+    rr = rr > 0 ? rr : 0;
+    tt = tt > 0 ? tt : 0;
+    tt = tt + td;
+    td1 = (R)td; rr1 = (R)rr; tt1 = (R)tt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sorad_prep (:271-357, 416-431, 1534-1541)
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_prep(SoradArgs<R> A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.m) return;
+    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
+#define AP(a, k) a[(size_t)((k) - 1) * ld + i]
+#define LAY(f, k) A.lay[((size_t)(f) * K2 + (k)) * m + i]
+    const R xtoa = AP(A.pl, 1) > (R)1.e-3 ? AP(A.pl, 1) : (R)1.e-3;
+    const R scal0 = xtoa * gr_pow<R>((R)0.5 * xtoa / (R)300., (R).8);
+    const R o3toa = (R)1.02 * AP(A.oa, 1) * xtoa * (R)466.7 + (R)1.0e-8;
+    const R wvtoa = (R)1.02 * AP(A.wa, 1) * scal0 * ((R)1.0 + (R)0.00135 * (AP(A.ta, 1) - (R)240.)) + (R)1.0e-9;
+    R sw = wvtoa, cc1 = 0, cc2 = 0, cc3 = 0;
+    int ntop = np + 1; bool found = false;
+    A.swh[(size_t)1 * m + i] = sw;
+    for (int k = 1; k <= np; k++) {
+        const R dp = AP(A.pl, k + 1) - AP(A.pl, k);
+        const R pa = (R)0.5 * (AP(A.pl, k) + AP(A.pl, k + 1));
+        const R scal = dp * gr_pow<R>(pa / (R)300., (R).8);
+        const R wh = (R)1.02 * AP(A.wa, k) * scal * ((R)1. + (R)0.00135 * (AP(A.ta, k) - (R)240.)) + (R)1.e-9;
+        sw = sw + wh;
+        A.swh[(size_t)(k + 1) * m + i] = sw;
+        LAY(0, k) = dp; LAY(1, k) = wh; LAY(2, k) = (R)1.02 * AP(A.oa, k) * dp * (R)466.7 + (R)1.e-8; LAY(3, k) = scal;
+        const R fc = AP(A.fcld, k);
+        if (k < A.ict) cc1 = cc1 > fc ? cc1 : fc; else if (k < A.icb) cc2 = cc2 > fc ? cc2 : fc; else cc3 = cc3 > fc ? cc3 : fc;
+        if (fc > (R)0.02 && !found) { found = true; ntop = k; }
+    }
+    R *cv = A.colv + i;
+    cv[0 * (size_t)m] = cc1; cv[1 * (size_t)m] = cc2; cv[2 * (size_t)m] = cc3; cv[3 * (size_t)m] = wvtoa; cv[4 * (size_t)m] = o3toa;
+    cv[5 * (size_t)m] = scal0; cv[6 * (size_t)m] = (R)ntop;
+#undef AP
+#undef LAY
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sorad_cloud: getvistau (grp 0) / getnirtau (grp = NIR band 1..3), one thread per (column, group)
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ib = blockIdx.y;
+    if (i >= A.m) return;
+    const SoradDev<R> &T = *Tp;
+    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
+    const R dm = (R)0.1, dt = (R)0.30103, da = (R)0.1, t1 = (R)-0.9031;
+    const R cosz = A.cosz[i];
+    const R cc[4] = {0, A.colv[0 * (size_t)m + i], A.colv[1 * (size_t)m + i], A.colv[2 * (size_t)m + i]};
+#define CLD(f, k) A.cld[(((size_t)ib * 4 + (f)) * K2 + (k)) * m + i]
+#define CAIB(a, b, c) T.caib[(((c) - 1) * 9 + ((b) - 1)) * 11 + ((a) - 1)]
+#define CAIF(a, b) T.caif[((b) - 1) * 9 + ((a) - 1)]
+#define N2(tab, j) tab[((j) - 1) * 3 + (ib - 1)]
+    for (int k = 1; k <= np; k++) {
+        const R dp_pa = A.lay[((size_t)0 * K2 + k) * m + i] * (R)100.;
+        const R wp = (dp_pa * (R)1.0e3) / (R)9.80665;                 // MAPL_GRAV
+        const R r1 = A.reff[((size_t)0 * np + (k - 1)) * ld + i], r2 = A.reff[((size_t)1 * np + (k - 1)) * ld + i],
+                r4 = A.reff[((size_t)3 * np + (k - 1)) * ld + i];
+        const R h1 = A.cwc[((size_t)0 * np + (k - 1)) * ld + i], h2 = A.cwc[((size_t)1 * np + (k - 1)) * ld + i],
+                h3 = A.cwc[((size_t)2 * np + (k - 1)) * ld + i], h4 = A.cwc[((size_t)3 * np + (k - 1)) * ld + i];
+        const R fc = A.fcld[(size_t)(k - 1) * ld + i];
+        const R rs = r4 < (R)112.0 ? r4 : (R)112.0;
+        R tc1, tc2, tc3, tc4;
+        if (ib == 0) {
+            tc1 = r1 <= 0 ? (R)0 : (wp * h1) * T.aib_uv / r1;
+            tc2 = r2 <= 0 ? (R)0 : (wp * h2) * (T.awb_uv[0] + T.awb_uv[1] / r2);
+            tc3 = (wp * h3) * T.arb_uv[0];
+            tc4 = rs <= 0 ? (R)0 : (wp * h4) * T.aib_uv / rs;
+        } else {
+            tc1 = r1 <= 0 ? (R)0 : (wp * h1) * T.aib_nir / r1;
+            tc2 = r2 <= 0 ? (R)0 : (wp * h2) * (N2(T.awb_nir, 1) + N2(T.awb_nir, 2) / r2);
+            tc3 = (wp * h3) * N2(T.arb_nir, 1);
+            tc4 = rs <= 0 ? (R)0 : (wp * h4) * T.aib_nir / rs;
+        }
+        R tb = 0, tf = 0;                                             // sums of the 4 species (taubeam / taudiff)
+        const int kk = k < ict ? 1 : (k < icb ? 2 : 3);
+        R tauc = tc1 + tc2 + tc3 + tc4;
+        const bool cloudy = tauc > (R)0.02 && fc > (R)0.01;
+        if (cloudy) {
+            R fa = ib == 0 ? fc / cc[kk] : (cc[kk] != 0 ? fc / cc[kk] : (R)0);
+            R tcap = tauc < (R)32. ? tauc : (R)32.;
+            R fm = cosz / dm, ft = (gr_log10<R>(tcap) - t1) / dt;
+            fa = fa / da;
+            int im = (int)(fm + (R)1.5), it = (int)(ft + (R)1.5), ia = (int)(fa + (R)1.5);
+            im = im > 2 ? im : 2; it = it > 2 ? it : 2; ia = ia > 2 ? ia : 2;
+            im = im < 10 ? im : 10; it = it < 8 ? it : 8; ia = ia < 10 ? ia : 10;
+            fm = fm - (R)(im - 1); ft = ft - (R)(it - 1); fa = fa - (R)(ia - 1);
+            const R c0 = CAIB(im, it, ia);
+            R xai = (-CAIB(im - 1, it, ia) * ((R)1. - fm) + CAIB(im + 1, it, ia) * ((R)1. + fm)) * fm * (R).5 + c0 * ((R)1. - fm * fm);
+            xai = xai + (-CAIB(im, it - 1, ia) * ((R)1. - ft) + CAIB(im, it + 1, ia) * ((R)1. + ft)) * ft * (R).5 + c0 * ((R)1. - ft * ft);
+            xai = xai + (-CAIB(im, it, ia - 1) * ((R)1. - fa) + CAIB(im, it, ia + 1) * ((R)1. + fa)) * fa * (R).5 + c0 * ((R)1. - fa * fa);
+            xai = xai - (R)2. * c0;
+            xai = xai > 0 ? xai : (R)0; xai = xai < 1 ? xai : (R)1;
+            tb = tc1 * xai + tc2 * xai + tc3 * xai + tc4 * xai;
+            const R f0 = CAIF(it, ia);
+            xai = (-CAIF(it - 1, ia) * ((R)1. - ft) + CAIF(it + 1, ia) * ((R)1. + ft)) * ft * (R).5 + f0 * ((R)1. - ft * ft);
+            xai = xai + (-CAIF(it, ia - 1) * ((R)1. - fa) + CAIF(it, ia + 1) * ((R)1. + fa)) * fa * (R).5 + f0 * ((R)1. - fa * fa);
+            xai = xai - f0;
+            xai = xai > 0 ? xai : (R)0; xai = xai < 1 ? xai : (R)1;
+            tf = tc1 * xai + tc2 * xai + tc3 * xai + tc4 * xai;
+        }
+        R asy = 1, ssa = (R)0.99999;
+        if (cloudy) {
+            if (ib == 0) {
+                const R g1 = (T.aig_uv[0] + (T.aig_uv[1] + T.aig_uv[2] * r1) * r1) * tc1;
+                const R g2 = (T.awg_uv[0] + (T.awg_uv[1] + T.awg_uv[2] * r2) * r2) * tc2;
+                const R g3 = T.arg_uv[0] * tc3;
+                const R g4 = (T.aig_uv[0] + (T.aig_uv[1] + T.aig_uv[2] * rs) * rs) * tc4;
+                asy = (g1 + g2 + g3 + g4) / tauc;
+            } else {
+                const R w1 = ((R)1. - (N2(T.aia_nir, 1) + (N2(T.aia_nir, 2) + N2(T.aia_nir, 3) * r1) * r1)) * tc1;
+                const R w2 = ((R)1. - (N2(T.awa_nir, 1) + (N2(T.awa_nir, 2) + N2(T.awa_nir, 3) * r2) * r2)) * tc2;
+                const R w3 = ((R)1. - N2(T.ara_nir, 1)) * tc3;
+                const R w4 = ((R)1. - (N2(T.aia_nir, 1) + (N2(T.aia_nir, 2) + N2(T.aia_nir, 3) * rs) * rs)) * tc4;
+                ssa = (w1 + w2 + w3 + w4) / tauc;
+                const R g1 = (N2(T.aig_nir, 1) + (N2(T.aig_nir, 2) + N2(T.aig_nir, 3) * r1) * r1) * w1;
+                const R g2 = (N2(T.awg_nir, 1) + (N2(T.awg_nir, 2) + N2(T.awg_nir, 3) * r2) * r2) * w2;
+                const R g3 = N2(T.arg_nir, 1) * w3;
+                const R g4 = (N2(T.aig_nir, 1) + (N2(T.aig_nir, 2) + N2(T.aig_nir, 3) * r4) * r4) * w4;      // reff(k,4), not the capped value
+                if (w1 + w2 + w3 + w4 != 0) asy = (g1 + g2 + g3 + g4) / (w1 + w2 + w3 + w4);
+            }
+        }
+        CLD(0, k) = tb; CLD(1, k) = tf; CLD(2, k) = asy; CLD(3, k) = ssa;
+    }
+#undef CLD
+#undef CAIB
+#undef CAIF
+#undef N2
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sorad_pass: one thread per (column, spectral pass).  Scratch planes of the pass (index q, level k):
+//   0..9  : rr, tt, td, rs, ts of the clear (q = 2 f) and cloudy (q = 2 f + 1) portion of layer k (k = 0 above the model top,
+//           np+1 = surface)
+//   10..21: tda, tta, rsa (ih, im) composites from the top       q = 10 + 4 f + 2 (ih-1) + (im-1)
+//   22..29: rra, rxa (im, is) composites from the surface        q = 22 + 4 f + 2 (im-1) + (is-1)
+//   30..33: fall, fclr, fupa, fupc
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pass = blockIdx.y;
+    if (i >= A.m) return;
+    const SoradDev<R> &T = *Tp;
+    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
+    const bool uv = pass < 5;
+    const int ib = uv ? pass + 1 : (pass - 5) / 10 + 1, ik = uv ? 0 : (pass - 5) % 10 + 1;   // band in its region, k-value
+    const int iv = uv ? ib : ib + 5;                                                         // aerosol band 1..8
+    const int grp = uv ? 0 : ib;
+    const R cz = A.cosz[i], dsm = (R)0.602;
+    const R cc1 = A.colv[0 * (size_t)m + i], cc2 = A.colv[1 * (size_t)m + i], cc3 = A.colv[2 * (size_t)m + i];
+    const R wvtoa = A.colv[3 * (size_t)m + i], o3toa = A.colv[4 * (size_t)m + i];
+    R *S = A.scr + (size_t)pass * 34 * K2 * m + i;
+#define P(q, k) S[((size_t)(q) * K2 + (k)) * m]
+#define LY(f, j, k) P(2 * (f) + (j) - 1, k)              // f: 0 rr 1 tt 2 td 3 rs 4 ts;  j: 1 clear, 2 cloudy
+#define TDA(k, a, b) P(10 + 2 * ((a) - 1) + (b) - 1, k)
+#define TTA(k, a, b) P(14 + 2 * ((a) - 1) + (b) - 1, k)
+#define RSA(k, a, b) P(18 + 2 * ((a) - 1) + (b) - 1, k)
+#define RRA(k, a, b) P(22 + 2 * ((a) - 1) + (b) - 1, k)
+#define RXA(k, a, b) P(26 + 2 * ((a) - 1) + (b) - 1, k)
+    // boundary "layers": surface (np+1) and the layer above the model top (0)  (:365-387, 914-936)
+    {
+        const R rb = uv ? A.rsuvbm[i] : A.rsirbm[i], rd = uv ? A.rsuvdf[i] : A.rsirdf[i];
+        const R td0 = uv ? gr_exp<R>(-(wvtoa * T.wk_uv[ib - 1] + o3toa * T.zk_uv[ib - 1]) / cz) : gr_exp<R>(-wvtoa * T.xk_ir[ik - 1] / cz);
+        for (int j = 1; j <= 2; j++) {
+            LY(0, j, np + 1) = rb; LY(3, j, np + 1) = rd; LY(2, j, np + 1) = 0; LY(1, j, np + 1) = 0; LY(4, j, np + 1) = 0;
+            LY(0, j, 0) = 0; LY(3, j, 0) = 0; LY(1, j, 0) = 1; LY(4, j, 0) = 1; LY(2, j, 0) = td0;
+        }
+    }
+    // ---- layers: clear and cloudy portion (:436-520, 996-1068) ---------------------------------------------------------
+    for (int k = 1; k <= np; k++) {
+        const R dp = A.lay[((size_t)0 * K2 + k) * m + i], wh = A.lay[((size_t)1 * K2 + k) * m + i], oh = A.lay[((size_t)2 * K2 + k) * m + i];
+        const size_t ja = ((size_t)(iv - 1) * np + (k - 1)) * ld + i;
+        const R ta_ = A.taua[ja], sa_ = A.ssaa[ja], as_ = A.asya[ja];
+        R taurs, tausto, ssatau;
+        if (uv) {
+            taurs = T.ry_uv[ib - 1] * dp;
+            tausto = taurs + T.zk_uv[ib - 1] * oh + T.wk_uv[ib - 1] * wh + ta_ + (R)1.0e-7;
+            ssatau = sa_ + taurs;
+        } else {
+            taurs = T.ry_ir[ib - 1] * dp;
+            tausto = taurs + T.xk_ir[ik - 1] * wh + ta_ + (R)1.0e-7;
+            ssatau = sa_ + taurs + (R)1.0e-8;
+        }
+        const R asysto = as_;
+        R tautob = tausto, asytob = asysto / ssatau, ssatob = ssatau / tautob + (R)1.0e-8;
+        ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
+        R rrt, ttt, tdt, rst, tst, dum;
+        so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
+        so_deledd<R>(tautob, ssatob, asytob, dsm, rst, tst, dum);
+        LY(0, 1, k) = rrt; LY(1, 1, k) = ttt; LY(2, 1, k) = tdt; LY(3, 1, k) = rst; LY(4, 1, k) = tst;
+        // the cloudy portion only matters in sky situations of non-zero weight, i.e. when the layer's group has cloud
+        const R ccg = k < ict ? cc1 : (k < icb ? cc2 : cc3);
+        if (ccg > 0) {
+            const R tcb = A.cld[(((size_t)grp * 4 + 0) * K2 + k) * m + i], tcf = A.cld[(((size_t)grp * 4 + 1) * K2 + k) * m + i],
+                    asyc = A.cld[(((size_t)grp * 4 + 2) * K2 + k) * m + i];
+            const R ssac = uv ? (R)1 : A.cld[(((size_t)grp * 4 + 3) * K2 + k) * m + i];
+            tautob = tausto + tcb;
+            ssatob = (uv ? (ssatau + tcb) : (ssatau + ssac * tcb)) / tautob + (R)1.0e-8;
+            ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
+            asytob = (uv ? (asysto + asyc * tcb) : (asysto + asyc * ssac * tcb)) / (ssatob * tautob);
+            const R tautof = tausto + tcf;
+            R ssatof = (uv ? (ssatau + tcf) : (ssatau + ssac * tcf)) / tautof + (R)1.0e-8;
+            ssatof = ssatof < (R)0.999999 ? ssatof : (R)0.999999;
+            const R asytof = (uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf)) / (ssatof * tautof);
+            so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
+            so_deledd<R>(tautof, ssatof, asytof, dsm, rst, tst, dum);
+        }
+        LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
+        P(30, k) = 0; P(31, k) = 0; P(32, k) = 0; P(33, k) = 0;
+    }
+    P(30, np + 1) = 0; P(31, np + 1) = 0; P(32, np + 1) = 0; P(33, np + 1) = 0;
+
+    // ---- CLDFLX (:689-872): composites from the top over the high and middle groups ---------------------------------------
+    const int nh = cc1 > 0 ? 2 : 1, nm = cc2 > 0 ? 2 : 1, ns = cc3 > 0 ? 2 : 1;       // portions of non-zero weight
+    for (int ih = 1; ih <= nh; ih++) {
+        R tda = LY(2, ih, 0), tta = LY(1, ih, 0), rsa = LY(3, ih, 0);
+        TDA(0, ih, 1) = tda; TTA(0, ih, 1) = tta; RSA(0, ih, 1) = rsa; TDA(0, ih, 2) = tda; TTA(0, ih, 2) = tta; RSA(0, ih, 2) = rsa;
+        for (int k = 1; k <= ict - 1; k++) {
+            const R rr = LY(0, ih, k), tt = LY(1, ih, k), td = LY(2, ih, k), rs = LY(3, ih, k), ts = LY(4, ih, k);
+            const R denm = ts / ((R)1. - rsa * rs);
+            const R ntta = tda * tt + (tda * rsa * rr + tta - tda) * denm;
+            const R nrsa = rs + ts * rsa * denm;
+            tda = tda * td; tta = ntta; rsa = nrsa;
+            TDA(k, ih, 1) = tda; TTA(k, ih, 1) = tta; RSA(k, ih, 1) = rsa; TDA(k, ih, 2) = tda; TTA(k, ih, 2) = tta; RSA(k, ih, 2) = rsa;
+        }
+        for (int im = 1; im <= nm; im++) {
+            R a = TDA(ict - 1, ih, im), b = TTA(ict - 1, ih, im), c = RSA(ict - 1, ih, im);
+            for (int k = ict; k <= icb - 1; k++) {
+                const R rr = LY(0, im, k), tt = LY(1, im, k), td = LY(2, im, k), rs = LY(3, im, k), ts = LY(4, im, k);
+                const R denm = ts / ((R)1. - c * rs);
+                const R nb = a * tt + (a * c * rr + b - a) * denm;
+                const R nc = rs + ts * c * denm;
+                a = a * td; b = nb; c = nc;
+                TDA(k, ih, im) = a; TTA(k, ih, im) = b; RSA(k, ih, im) = c;
+            }
+        }
+    }
+    // composites from the surface over the low and middle groups
+    for (int is = 1; is <= ns; is++) {
+        R rra = LY(0, is, np + 1), rxa = LY(3, is, np + 1);
+        RRA(np + 1, 1, is) = rra; RXA(np + 1, 1, is) = rxa; RRA(np + 1, 2, is) = rra; RXA(np + 1, 2, is) = rxa;
+        for (int k = np; k >= icb; k--) {
+            const R rr = LY(0, is, k), tt = LY(1, is, k), td = LY(2, is, k), rs = LY(3, is, k), ts = LY(4, is, k);
+            const R denm = ts / ((R)1. - rs * rxa);
+            const R nrra = rr + (td * rra + (tt - td) * rxa) * denm;
+            rxa = rs + ts * rxa * denm; rra = nrra;
+            RRA(k, 1, is) = rra; RXA(k, 1, is) = rxa; RRA(k, 2, is) = rra; RXA(k, 2, is) = rxa;
+        }
+        for (int im = 1; im <= nm; im++) {
+            R a = RRA(icb, im, is), b = RXA(icb, im, is);
+            for (int k = icb - 1; k >= ict; k--) {
+                const R rr = LY(0, im, k), tt = LY(1, im, k), td = LY(2, im, k), rs = LY(3, im, k), ts = LY(4, im, k);
+                const R denm = ts / ((R)1. - rs * b);
+                const R na = rr + (td * a + (tt - td) * b) * denm;
+                b = rs + ts * b * denm; a = na;
+                RRA(k, im, is) = a; RXA(k, im, is) = b;
+            }
+        }
+    }
+    // integration over the sky situations of non-zero weight
+    R fsdir = 0, fsdif = 0;
+    for (int ih = 1; ih <= nh; ih++) {
+        const R ch = ih == 1 ? (R)1.0 - cc1 : cc1;
+        for (int im = 1; im <= nm; im++) {
+            const R cm = im == 1 ? ch * ((R)1.0 - cc2) : ch * cc2;
+            for (int is = 1; is <= ns; is++) {
+                const R ct = is == 1 ? cm * ((R)1.0 - cc3) : cm * cc3;
+                {   // add one layer at a time, going down through the low group
+                    R a = TDA(icb - 1, ih, im), b = TTA(icb - 1, ih, im), c = RSA(icb - 1, ih, im);
+                    for (int k = icb; k <= np; k++) {
+                        const R rr = LY(0, is, k), tt = LY(1, is, k), td = LY(2, is, k), rs = LY(3, is, k), ts = LY(4, is, k);
+                        const R denm = ts / ((R)1. - c * rs);
+                        const R nb = a * tt + (a * rr * c + b - a) * denm;
+                        const R nc = rs + ts * c * denm;
+                        a = a * td; b = nb; c = nc;
+                        TDA(k, ih, im) = a; TTA(k, ih, im) = b; RSA(k, ih, im) = c;
+                    }
+                }
+                {   // going up through the high group
+                    R a = RRA(ict, im, is), b = RXA(ict, im, is);
+                    for (int k = ict - 1; k >= 0; k--) {
+                        const R rr = LY(0, ih, k), tt = LY(1, ih, k), td = LY(2, ih, k), rs = LY(3, ih, k), ts = LY(4, ih, k);
+                        const R denm = ts / ((R)1. - rs * b);
+                        const R na = rr + (td * a + (tt - td) * b) * denm;
+                        b = rs + ts * b * denm; a = na;
+                        RRA(k, im, is) = a; RXA(k, im, is) = b;
+                    }
+                }
+                R fdndir = 0, fdndif = 0;
+                for (int k = 1; k <= np + 1; k++) {      // Eqs. (6.15), (6.16)
+                    const R tda = TDA(k - 1, ih, im), tta = TTA(k - 1, ih, im), rsa = RSA(k - 1, ih, im), rra = RRA(k, im, is), rxa = RXA(k, im, is);
+                    const R denm = (R)1. / ((R)1. - rsa * rxa);
+                    fdndir = tda;
+                    const R xx4 = tda * rra, yy = tta - tda;
+                    fdndif = (xx4 * rsa + yy) * denm;
+                    const R fupdif = (xx4 + yy * rxa) * denm;
+                    const R flxdn = fdndir + fdndif - fupdif;
+                    if (ih == 1 && im == 1 && is == 1) { P(33, k) = fupdif; P(31, k) = flxdn; }
+                    P(32, k) = P(32, k) + fupdif * ct;
+                    P(30, k) = P(30, k) + flxdn * ct;
+                }
+                fsdir = fsdir + fdndir * ct;
+                fsdif = fsdif + fdndif * ct;
+            }
+        }
+    }
+    A.psum[((size_t)pass * 2 + 0) * m + i] = fsdir;
+    A.psum[((size_t)pass * 2 + 1) * m + i] = fsdif;
+#undef P
+#undef LY
+#undef TDA
+#undef TTA
+#undef RSA
+#undef RRA
+#undef RXA
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sorad_reduce: per column -- flux integration over the passes (Eq. 6.1), O2 / CO2 reductions (:1425-1552), surface rescaling
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_reduce(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp, SoradOut<R> O)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.m) return;
+    const SoradDev<R> &T = *Tp;
+    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
+#define OUT2(a, k) a[(size_t)((k) - 1) * ld + i]
+#define SCR(pass, q, k) A.scr[(((size_t)(pass) * 34 + (q)) * K2 + (k)) * m + i]
+    for (int k = 1; k <= np + 1; k++) {
+        R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int p = 0; p < SO_NPASS; p++) {
+            const R hk = A.hk[p];
+            s0 = s0 + SCR(p, 30, k) * hk; s1 = s1 + SCR(p, 31, k) * hk; s2 = s2 + SCR(p, 32, k) * hk; s3 = s3 + SCR(p, 33, k) * hk;
+        }
+        OUT2(O.flx, k) = s0; OUT2(O.flc, k) = s1; OUT2(O.flxu, k) = s2; OUT2(O.flcu, k) = s3;
+    }
+    // surface band fluxes and direct / diffuse partition
+    R fdiruv = 0, fdifuv = 0, fdirpar = 0, fdifpar = 0, fdirir = 0, fdifir = 0, band[8], drb[8], dfb[8];
+    for (int b = 0; b < 8; b++) { band[b] = 0; drb[b] = 0; dfb[b] = 0; }
+    for (int p = 0; p < SO_NPASS; p++) {
+        const R hk = A.hk[p], fs = A.psum[((size_t)p * 2 + 0) * m + i], fd = A.psum[((size_t)p * 2 + 1) * m + i];
+        const int b = p < 5 ? p : 5 + (p - 5) / 10;
+        band[b] = band[b] + SCR(p, 30, np + 1) * hk; drb[b] = drb[b] + fs * hk; dfb[b] = dfb[b] + fd * hk;
+        if (p < 4) { fdiruv = fdiruv + fs * hk; fdifuv = fdifuv + fd * hk; }
+        else if (p == 4) { fdirpar = fs * hk; fdifpar = fd * hk; }
+        else { fdirir = fdirir + fs * hk; fdifir = fdifir + fd * hk; }
+    }
+    // flux reductions: running column amounts, two table look-ups per level
+    const R snt = (R)1.0 / A.cosz[i];
+    const R scal0 = A.colv[5 * (size_t)m + i];
+    const int ntop = (int)A.colv[6 * (size_t)m + i];
+    const R cnt = (R)165.22 * snt;
+    R so2o = scal0 * cnt, so2c = ((R)789. * A.co2) * scal0;
+    const R flx_top = OUT2(O.flx, ntop);
+    R dftop = 0, dfsfc = 0;
+    for (int k = 1; k <= np + 1; k++) {
+        if (k > 1) { const R sc = A.lay[((size_t)3 * K2 + (k - 1)) * m + i]; so2o = so2o + sc * cnt; so2c = so2c + ((R)789. * A.co2) * sc; }
+        R df = (R)0.0633 * ((R)1. - gr_exp<R>((R)-0.000155 * sqrt(so2o)));
+        {
+            const R u1 = (R)-3.0, du = (R)0.15, w1 = (R)-4.0, dw = (R)0.15;
+            const R x0 = u1 + (R)43 * du, y0 = w1 + (R)37 * dw, x1 = u1 - (R)0.5 * du, y1 = w1 - (R)0.5 * dw;
+            R ulog = gr_log10<R>(so2c * snt); ulog = ulog < x0 ? ulog : x0;
+            R wlog = gr_log10<R>(A.swh[(size_t)k * m + i] * snt); wlog = wlog < y0 ? wlog : y0;
+            int ic = (int)((ulog - x1) / du + (R)1.), iw = (int)((wlog - y1) / dw + (R)1.);
+            ic = ic > 2 ? ic : 2; iw = iw > 2 ? iw : 2; ic = ic < 43 ? ic : 43; iw = iw < 37 ? iw : 37;
+            const R dc = ulog - (R)(ic - 2) * du - u1, dd = wlog - (R)(iw - 2) * dw - w1;
+#define CAH(a, b) T.cah[((b) - 1) * 43 + ((a) - 1)]
+            const R x2 = CAH(ic - 1, iw - 1) + (CAH(ic - 1, iw) - CAH(ic - 1, iw - 1)) / dw * dd;
+            R y2 = x2 + (CAH(ic, iw - 1) - CAH(ic - 1, iw - 1)) / du * dc;
+#undef CAH
+            y2 = y2 > 0 ? y2 : (R)0;
+            df = df + (R)1.5 * y2;
+        }
+        {
+            const R u1 = (R)0.000250, du = (R)0.000050, w1 = (R)-2.0, dw = (R)0.05;
+            const R x0 = u1 + (R)62 * du, y0 = w1 + (R)101 * dw, x1 = u1 - (R)0.5 * du, y1 = w1 - (R)0.5 * dw;
+            R ulog = A.co2 * snt; ulog = ulog < x0 ? ulog : x0;
+            R wlog = gr_log10<R>(A.pl[(size_t)(k - 1) * ld + i]); wlog = wlog < y0 ? wlog : y0;
+            int ic = (int)((ulog - x1) / du + (R)1.), iw = (int)((wlog - y1) / dw + (R)1.);
+            ic = ic > 2 ? ic : 2; iw = iw > 2 ? iw : 2; ic = ic < 62 ? ic : 62; iw = iw < 101 ? iw : 101;
+            const R dc = ulog - (R)(ic - 2) * du - u1, dd = wlog - (R)(iw - 2) * dw - w1;
+#define COA(a, b) T.coa[((b) - 1) * 62 + ((a) - 1)]
+            const R x2 = COA(ic - 1, iw - 1) + (COA(ic - 1, iw) - COA(ic - 1, iw - 1)) / dw * dd;
+            R y2 = x2 + (COA(ic, iw - 1) - COA(ic - 1, iw - 1)) / du * dc;
+#undef COA
+            y2 = y2 > 0 ? y2 : (R)0;
+            df = df + (R)1.5 * y2;
+        }
+        // below the cloud top the reduction scales with the all-sky flux, Eq. (6.18)
+        if (k == ntop) dftop = df;
+        R fl = OUT2(O.flx, k);
+        if (k > ntop) { const R xx4 = fl / flx_top; df = dftop + xx4 * (df - dftop); }
+        df = df < fl - (R)1.0e-8 ? df : fl - (R)1.0e-8;
+        OUT2(O.flx, k) = fl - df;
+        OUT2(O.flc, k) = OUT2(O.flc, k) - df;
+        if (k == np + 1) dfsfc = df;
+    }
+    R xx4 = OUT2(O.flx, np + 1) + dfsfc;
+    const R eps = sizeof(R) == 4 ? (R)1.1920929e-07 : (R)2.220446049250313e-16;
+    if (fabs(xx4) > eps) { xx4 = (R)1.0 - dfsfc / xx4; xx4 = xx4 < 1 ? xx4 : (R)1; xx4 = xx4 > 0 ? xx4 : (R)0; }
+    else xx4 = 0;
+    O.fdirir[i] = xx4 * fdirir; O.fdifir[i] = xx4 * fdifir; O.fdiruv[i] = xx4 * fdiruv; O.fdifuv[i] = xx4 * fdifuv;
+    O.fdirpar[i] = xx4 * fdirpar; O.fdifpar[i] = xx4 * fdifpar;
+    for (int b = 0; b < 8; b++) {
+        O.flx_sfc_band[(size_t)b * ld + i] = xx4 * band[b];
+        if (A.do_drfband) { O.drband[(size_t)b * ld + i] = xx4 * drb[b]; O.dfband[(size_t)b * ld + i] = xx4 * dfb[b]; }
+    }
+#undef OUT2
+#undef SCR
+}
+
+}  // namespace geosrad

@@ -10,6 +10,8 @@
  *                                    GEOSsolar_GridComp/RRTMG/rrtmg_sw/gcm_model/src/rrtmg_sw_rad.F90:68-124
  *   geosrad_set_tables_sw         <- rrtmg_sw_init::rrtmg_sw_ini           .../src/rrtmg_sw_init.F90:23
  *   geosrad_irrad[_dev]           <- irradmod::irrad                       GEOSirrad_GridComp/irrad.F90:27-35
+ *   geosrad_sorad[_dev]           <- soradmod::sorad                       GEOSsolar_GridComp/sorad.F90:43-51
+ *   geosrad_set_tables_chou_sw    <- sorad_constants / rad_constants (data modules)  GEOSsolar_GridComp/soradconstants.F90
  *   geosrad_set_tables_chou_lw    <- irrad_constants / rad_constants (data modules)  GEOSirrad_GridComp/irradconstants.F90
  *   geosrad_mcica[_dev]           <- cloud_subcol_gen::generate_stochastic_clouds
  *                                    GEOS_RadiationShared/cloud_subcol_gen.F90:132-137
@@ -77,6 +79,9 @@ int geosrad_load_tables_sw(geosrad_ctx *ctx, const char *path);
 /* the coefficient tables of the Chou-Suarez LW scheme: irrad_constants + the IR part of rad_constants */
 int geosrad_set_tables_chou_lw(geosrad_ctx *ctx, const void *blob, size_t nbytes);
 int geosrad_load_tables_chou_lw(geosrad_ctx *ctx, const char *path);
+/* the coefficient tables of the Chou-Suarez SW scheme: sorad_constants + the UV / NIR part of rad_constants */
+int geosrad_set_tables_chou_sw(geosrad_ctx *ctx, const void *blob, size_t nbytes);
+int geosrad_load_tables_chou_sw(geosrad_ctx *ctx, const char *path);
 /* ih = 0 homogeneous (blob ignored), 1 beta, 2 gamma; blob = xcw(1000,140) table of that kind */
 int geosrad_set_inhomogeneity(geosrad_ctx *ctx, int ih, const void *xcw_blob, size_t nbytes);
 int geosrad_load_inhomogeneity(geosrad_ctx *ctx, int ih, const char *path);
@@ -125,7 +130,7 @@ int geosrad_check(geosrad_ctx *ctx, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, around every kernel the *_dev entry points
  * enqueue (kernel ids 0..5 = k_validate_pwv, k_setcoef, k_overlap, k_mcica, k_lw_bands, k_lw_reduce; 6..9 =
- * k_sw_validate, k_sw_setcoef, k_sw_bands, k_sw_reduce; 10..11 = k_chou_prep, k_chou_bands; k_overlap / k_mcica are shared).
+ * k_sw_validate, k_sw_setcoef, k_sw_bands, k_sw_reduce; 10..11 = k_chou_prep, k_chou_bands; 12..13 = k_sorad_prep (+ cloud), k_sorad_pass; k_overlap / k_mcica are shared).
  * geosrad_profile(ctx, 1) resets and enables, geosrad_profile_read() waits for the recorded events and
  * returns the accumulated milliseconds and launch count of one kernel. */
 int geosrad_profile(geosrad_ctx *ctx, int enable);
@@ -213,6 +218,25 @@ int geosrad_irrad_dev(geosrad_ctx *ctx, void *stream, int m, int np, const void 
                       int na, int nb, void *taua, void *ssaa, void *asya,
                       void *flxu, void *flcu, void *flau, void *flxau, void *flxd, void *flcd, void *flad, void *flxad,
                       void *dfdts, void *sfcem, void *taudiag);
+
+/* ---- Chou-Suarez shortwave -----------------------------------------------------------------------------
+ * sorad (GEOSsolar_GridComp/sorad.F90:43-51), same argument order.  Layers from the TOP down, pl in hPa; Fortran layouts:
+ * cosz, rsuvbm, rsuvdf, rsirbm, rsirdf (m); pl (m,np+1); ta, wa, oa, fcld (m,np); cwc, reff (m,np,4); taua, ssaa, asya
+ * (m,np,nb = 8) in the (tau, tau*ssa, tau*ssa*g) form the reference expects; hk_uv (5), hk_ir (3,10): HOST pointers in both
+ * variants; outputs flx, flc, flxu, flcu (m,np+1), fdir/fdif uv/par/ir (m), flx_sfc_band (m,8), drband, dfband (m,8; written
+ * only when do_drfband != 0, else may be NULL).  Fluxes are fractions of the TOA insolation.  Non-OVERCAST behaviour. */
+int geosrad_sorad(geosrad_ctx *ctx, int m, int np, int nb, const void *cosz, const void *pl, const void *ta, const void *wa,
+                  const void *oa, double co2, const void *cwc, const void *fcld, int ict, int icb, const void *reff,
+                  const void *hk_uv, const void *hk_ir, const void *taua, const void *ssaa, const void *asya,
+                  const void *rsuvbm, const void *rsuvdf, const void *rsirbm, const void *rsirdf,
+                  void *flx, void *flc, void *fdiruv, void *fdifuv, void *fdirpar, void *fdifpar, void *fdirir, void *fdifir,
+                  void *flxu, void *flcu, void *flx_sfc_band, int do_drfband, void *drband, void *dfband);
+int geosrad_sorad_dev(geosrad_ctx *ctx, void *stream, int m, int np, int nb, const void *cosz, const void *pl, const void *ta,
+                      const void *wa, const void *oa, double co2, const void *cwc, const void *fcld, int ict, int icb,
+                      const void *reff, const void *hk_uv, const void *hk_ir, const void *taua, const void *ssaa, const void *asya,
+                      const void *rsuvbm, const void *rsuvdf, const void *rsirbm, const void *rsirdf,
+                      void *flx, void *flc, void *fdiruv, void *fdifuv, void *fdirpar, void *fdifpar, void *fdirir, void *fdifir,
+                      void *flxu, void *flcu, void *flx_sfc_band, int do_drfband, void *drband, void *dfband);
 
 /* ---- McICA ------------------------------------------------------------------------------------------
  * generate_stochastic_clouds (cloud_subcol_gen.F90:132): profile inputs Fortran (nlay,dncol) there; here
