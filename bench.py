@@ -8,7 +8,8 @@ metric is "columns/sec (LW+SW, 72 layers)"; it is quoted on configs[3] (C360 til
 GPUs, full LW+SW with McICA clouds + aerosols).  The default workload is that configuration's per-GPU share:
 97 200 columns/GPU, 72 layers, RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points, every column lit), 60 % of
 the columns cloudy (McICA, ih = 1), aerosols on -- so the driver's N = 8 weak-scaling run IS configs[3].
-`--scheme lw --cloudy 0 --no-aerosol --ncol 100000` reproduces configs[1] (RRTMG_LW clear-sky).
+`--scheme lw --cloudy 0 --no-aerosol --ncol 100000` reproduces configs[1] (RRTMG_LW clear-sky); `--scheme chou` runs the
+Chou-Suarez pair irrad + sorad (configs[0] / configs[2] schemes), `--scheme irrad` / `--scheme sorad` one of them.
 Columns shard embarrassingly: every rank owns its own batch (weak scaling), there is no data-path
 collective; the only collectives are the timing barrier and the max-over-ranks of the time.
 
@@ -94,6 +95,18 @@ def _cpu_worker(args):
         t = time.perf_counter()
         clib.rrtmg_sw(inp, prec="f32", iaer=10 if aerosol else 0, normFlx=1)
         t_sw = time.perf_counter() - t
+    if scheme in ("chou", "irrad"):
+        ch = synth.chou_lw_inputs(inp, aerosol=aerosol)
+        clib.lib()
+        t = time.perf_counter()
+        clib.irrad(ch, "f32")
+        t_lw = time.perf_counter() - t
+    if scheme in ("chou", "sorad"):
+        cs = synth.chou_sw_inputs(inp, aerosol=aerosol)
+        clib.lib()
+        t = time.perf_counter()
+        clib.sorad(cs, "f32")
+        t_sw = time.perf_counter() - t
     return t_lw, t_sw
 
 
@@ -103,6 +116,8 @@ def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
     from oracle import reflib
     lw_kind = "reference" if reflib.available("r4") else "port"
     kind = lw_kind if scheme == "lw" else "port"
+    if scheme in ("chou", "irrad", "sorad"):
+        per_core = 1024
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     ctx = mp.get_context("fork")
@@ -119,6 +134,10 @@ def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
                     f"{per_core / lw_s:.0f} col/s/core")
     if "sw" in scheme:
         legs.append(f"rrtmg_sw = plain-C oracle (reference driver needs ESMF/MAPL: unbuildable here) {per_core / sw_s:.0f} col/s/core")
+    if scheme in ("chou", "irrad"):
+        legs.append(f"irrad = plain-C oracle (irrad.F90 needs MAPL: unbuildable here) {per_core / lw_s:.0f} col/s/core")
+    if scheme in ("chou", "sorad"):
+        legs.append(f"sorad = plain-C oracle (sorad.F90 needs MAPL: unbuildable here) {per_core / sw_s:.0f} col/s/core")
     return {"value": cores * per_core / busy, "unit": "columns/s", "cores": cores, "kind": kind,
             "sample": f"{cores} processes x {per_core} columns of the bench workload ({nlay} layers, cloudy fraction {cloudy}, "
                       f"aerosol {aerosol}); " + "; ".join(legs) + f"; slowest process {busy:.2f} s (pool wall {wall:.2f} s incl. input generation)",
@@ -133,13 +152,16 @@ def main():
     ap.add_argument("--ncol", type=int, default=97_200, help="columns per GPU (default: C360 tile / 8)")
     ap.add_argument("--nlay", type=int, default=72)
     ap.add_argument("--real", type=int, default=4, choices=[4, 8], help="arithmetic type: 4 = the reference's default real")
-    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw"])
+    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw", "chou", "irrad", "sorad"])
     ap.add_argument("--cloudy", type=float, default=0.6, help="fraction of cloudy columns (0 = clear-sky)")
     ap.add_argument("--no-aerosol", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     a = ap.parse_args()
     aerosol = not a.no_aerosol
     do_lw, do_sw = "lw" in a.scheme, "sw" in a.scheme
+    do_irrad, do_sorad = a.scheme in ("chou", "irrad"), a.scheme in ("chou", "sorad")
+    if (do_irrad or do_sorad) and a.ncol == 97_200:
+        a.ncol = 20_000              # the Chou kernels carry O(np^2) / 35-pass scratch: a smaller default batch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,7 +197,29 @@ def main():
     d["fswband"] = torch.zeros((14, ncol), device=dev, dtype=tdt)
     d["clearCounts"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
     d["clearCounts_sw"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
+    ch = cs = None
+    if do_irrad:
+        ch = synth.chou_lw_inputs(inp, aerosol=aerosol)
+        for k in ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg", "tv", "ev", "rv",
+                  "taua", "ssaa", "asya"):
+            d["ch_" + k] = torch.from_numpy(np.ascontiguousarray(ch[k])).to(dev, dtype=tdt)
+        for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts"):
+            d["ch_" + k] = torch.zeros((nlay + 1, ncol), device=dev, dtype=tdt)
+        d["ch_sfcem"] = torch.zeros(ncol, device=dev, dtype=tdt)
+        d["ch_taudiag"] = torch.zeros((10, nlay, ncol), device=dev, dtype=tdt)
+        aer0 = {k: d["ch_" + k].clone() for k in ("taua", "ssaa", "asya")}
+    if do_sorad:
+        cs = synth.chou_sw_inputs(inp, aerosol=aerosol)
+        for k in ("cosz", "pl", "ta", "wa", "oa", "cwc", "fcld", "reff", "taua", "ssaa", "asya", "rsuvbm", "rsuvdf", "rsirbm", "rsirdf"):
+            d["so_" + k] = torch.from_numpy(np.ascontiguousarray(cs[k])).to(dev, dtype=tdt)
+        for k in ("flx", "flc", "flxu", "flcu"):
+            d["so_" + k] = torch.zeros((nlay + 1, ncol), device=dev, dtype=tdt)
+        for k in ("fdiruv", "fdifuv", "fdirpar", "fdifpar", "fdirir", "fdifir"):
+            d["so_" + k] = torch.zeros(ncol, device=dev, dtype=tdt)
+        d["so_flx_sfc_band"] = torch.zeros((8, ncol), device=dev, dtype=tdt)
     ptr = {k: v.data_ptr() for k, v in d.items()}
+    ptr_ch = {k[3:]: v for k, v in ptr.items() if k.startswith("ch_")}
+    ptr_so = {k[3:]: v for k, v in ptr.items() if k.startswith("so_")}
 
     ctx = Context(a.real, device=local_rank)
     ctx.set_inhomogeneity(1 if a.cloudy > 0 else 0)          # GEOS default RAD_CONDENSATE_INHOMOGENEITY=1
@@ -187,6 +231,12 @@ def main():
             ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
         if do_sw:      # GEOS call: isolvar 0 scaled to scon, normalised fluxes (SOL:6230-6300)
             ctx.rrtmg_sw_dev(stream, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 10 if aerosol else 0, lm, mh, normFlx=1)
+        if do_irrad:
+            for k in aer0:                    # taua / ssaa / asya are in-out (rescaled in place): restore the inputs
+                d["ch_" + k].copy_(aer0[k])
+            ctx.irrad_dev(stream, ncol, nlay, ptr_ch, ch["co2"], True, ch["ict"], ch["icb"], ch["ns"], ch["na"], ch["nb"])
+        if do_sorad:
+            ctx.sorad_dev(stream, ncol, nlay, 8, ptr_so, cs["co2"], cs["ict"], cs["icb"], cs["hk_uv"], cs["hk_ir"])
 
     for _ in range(a.warmup):
         step()
@@ -213,15 +263,21 @@ def main():
         value = total_cols / elapsed
         # dominant kernel = largest total time; its algorithmic bytes are those of the solver it belongs to
         # (compulsory bytes at the solver API, every input read once + every output written once)
-        cand = {k: v for k, v in prof.items() if k in ("k_lw_bands", "k_sw_bands") and v[1] > 0}
+        cand = {k: v for k, v in prof.items() if k in ("k_lw_bands", "k_sw_bands", "k_chou_bands", "k_sorad_pass") and v[1] > 0}
         kname = max(cand, key=lambda k: cand[k][0])
         ms, n = prof[kname]
         launches_per_step = n / a.steps
-        abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(nlay, a.real, aerosol)
+        if kname == "k_chou_bands":
+            abytes = 19476 * a.real // 4                # Chou irrad 3 491 in + 1 378 out reals @72 layers
+        elif kname == "k_sorad_pass":
+            abytes = 11904 * a.real // 4                # Chou sorad 2 670 in + 306 out reals
+        else:
+            abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(nlay, a.real, aerosol)
         per_launch_s = (ms / max(n, 1)) * 1e-3
         achieved = abytes * (ncol / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
-                   "sw": "RRTMG_SW (112 g-points)"}[a.scheme]
+                   "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
+                   "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]
         if a.scheme == "lw" and a.cloudy == 0 and not aerosol:
             wl = "BASELINE configs[1]: %d columns/GPU, %d layers, RRTMG_LW 140 g-points clear-sky" % (ncol, nlay)
         else:
@@ -233,7 +289,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.real == 4 else "f64", "data": "synthetic",
-            "config": {"workload": wl, "schemes": schemes + " (Chou irrad/sorad: later rounds)", "columns_per_gpu": ncol, "layers": nlay,
+            "config": {"workload": wl, "schemes": schemes, "columns_per_gpu": ncol, "layers": nlay,
                        "cloudy_fraction": a.cloudy, "aerosol": aerosol,
                        "sharding": "independent column batches per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
