@@ -5,7 +5,7 @@ module geosrad_c
    use iso_fortran_env, only : error_unit
    implicit none
    private
-   public :: geosrad_ctx_handle, geosrad_fail, geosrad_warn, geosrad_data_path, geosrad_load_tables_sw, geosrad_rrtmg_sw
+   public :: geosrad_ctx_handle, geosrad_fail, geosrad_warn, geosrad_data_path, geosrad_load_tables_sw, geosrad_rrtmg_sw, geosrad_load_tables_chou_lw, geosrad_load_tables_chou_sw, geosrad_irrad, geosrad_sorad
    public :: geosrad_create, geosrad_destroy, geosrad_last_error, geosrad_load_tables_lw, geosrad_load_inhomogeneity
    public :: geosrad_set_corr_lengths, geosrad_rrtmg_lw, geosrad_mcica, geosrad_clearcounts
 
@@ -42,6 +42,36 @@ module geosrad_c
          type(c_ptr), value :: coszen, play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr, cld, ciwp, clwp, rei, rel, zm, alat, &
             tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, clearCounts, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, &
             parf, uvrr, uvrf, fswband, cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, drband, dfband, bndscl, indsolvar
+      end function
+      integer(c_int) function geosrad_load_tables_chou_lw(ctx, path) bind(C, name='geosrad_load_tables_chou_lw')
+         import :: c_int, c_ptr, c_char
+         type(c_ptr), value :: ctx
+         character(kind=c_char) :: path(*)
+      end function
+      integer(c_int) function geosrad_load_tables_chou_sw(ctx, path) bind(C, name='geosrad_load_tables_chou_sw')
+         import :: c_int, c_ptr, c_char
+         type(c_ptr), value :: ctx
+         character(kind=c_char) :: path(*)
+      end function
+      integer(c_int) function geosrad_irrad(ctx, m, np, ple, ta, wa, oa, tb, co2, trace, n2o, ch4, cfc11, cfc12, cfc22, cwc, fcld, ict, icb, &
+            reff, ns, fs, tg, eg, tv, ev, rv, na, nb, taua, ssaa, asya, flxu, flcu, flau, flxau, flxd, flcd, flad, flxad, dfdts, sfcem, &
+            taudiag) bind(C, name='geosrad_irrad')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: m, np, trace, ict, icb, ns, na, nb
+         real(c_double), value :: co2
+         type(c_ptr), value :: ple, ta, wa, oa, tb, n2o, ch4, cfc11, cfc12, cfc22, cwc, fcld, reff, fs, tg, eg, tv, ev, rv, taua, ssaa, asya, &
+            flxu, flcu, flau, flxau, flxd, flcd, flad, flxad, dfdts, sfcem, taudiag
+      end function
+      integer(c_int) function geosrad_sorad(ctx, m, np, nb, cosz, pl, ta, wa, oa, co2, cwc, fcld, ict, icb, reff, hk_uv, hk_ir, taua, ssaa, &
+            asya, rsuvbm, rsuvdf, rsirbm, rsirdf, flx, flc, fdiruv, fdifuv, fdirpar, fdifpar, fdirir, fdifir, flxu, flcu, flx_sfc_band, &
+            do_drfband, drband, dfband) bind(C, name='geosrad_sorad')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: m, np, nb, ict, icb, do_drfband
+         real(c_double), value :: co2
+         type(c_ptr), value :: cosz, pl, ta, wa, oa, cwc, fcld, reff, hk_uv, hk_ir, taua, ssaa, asya, rsuvbm, rsuvdf, rsirbm, rsirdf, flx, flc, &
+            fdiruv, fdifuv, fdirpar, fdifpar, fdirir, fdifir, flxu, flcu, flx_sfc_band, drband, dfband
       end function
       integer(c_int) function geosrad_load_inhomogeneity(ctx, ih, path) bind(C, name='geosrad_load_inhomogeneity')
          import; type(c_ptr), value :: ctx; integer(c_int), value :: ih; character(kind=c_char), intent(in) :: path(*)

@@ -94,3 +94,55 @@ def test_fortran_sw_caller_matches_oracle(tmp_path, kind):
     # RC convention: the reference's _FAIL paths return a non-zero RC instead of stopping (GEOS rejects isolvar 1 itself)
     rc, _ = run(1, 1361.0)
     assert rc != 0
+
+
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_chou_caller_matches_oracle(tmp_path, kind):
+    """chou_driver.F90 calls irrad(...) and sorad(...) with the reference's module names and argument lists
+    (GEOS_IrradGridComp.F90:2093-2101), linked against chou_shims.F90."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    exe = os.path.join(FDIR, "bin", f"chou_driver_{kind}")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    m, nlay = 24, 72
+    inp = synth.make_columns(m, nlay, start=808, aerosol=True, cloudy_frac=0.6)
+    ch = synth.chou_lw_inputs(inp, aerosol=True)
+    cs = synth.chou_sw_inputs(inp, aerosol=True)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        np.array([m, nlay, ch["ict"], ch["icb"], ch["na"]], dtype=np.int32).tofile(f)
+        np.array([ch["co2"]], dtype=np.float32).tofile(f)
+        for k in ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg", "tv", "ev", "rv",
+                  "taua", "ssaa", "asya"):
+            np.ascontiguousarray(ch[k], dtype=np.float32).tofile(f)
+        for k in ("cosz", "pl", "taua", "ssaa", "asya", "rsuvbm", "rsuvdf", "rsirbm", "rsirdf"):
+            np.ascontiguousarray(cs[k], dtype=np.float32).tofile(f)
+        np.concatenate([cs["hk_uv"].ravel(), cs["hk_ir"].ravel()]).astype(np.float32).tofile(f)
+    env = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
+    subprocess.check_call([exe, str(fin), str(fout)], env=env)
+    raw = np.fromfile(fout, dtype=np.float64)
+    n1 = (nlay + 1) * m
+    off = 0
+
+    def take(n, shape):
+        nonlocal off
+        a = raw[off: off + n].reshape(shape); off += n
+        return a
+    got = {k: take(n1, (nlay + 1, m)) for k in ("flxu", "flxd", "flcu", "dfdts")}
+    got["sfcem"] = take(m, (m,))
+    sgot = {k: take(n1, (nlay + 1, m)) for k in ("flx", "flc", "flxu")}
+    sgot["fdirpar"] = take(m, (m,)); sgot["flx_sfc_band"] = take(8 * m, (8, m)); sgot["drband"] = take(8 * m, (8, m))
+    # the driver reads float32 inputs: feed the oracle the same rounded values
+    ch32 = {k: (np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) else v) for k, v in ch.items()}
+    ch32["co2"] = float(np.float32(ch["co2"]))
+    cs32 = {k: (np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) else v) for k, v in cs.items()}
+    cs32["co2"] = ch32["co2"]
+    o = clib.irrad(ch32, kind)
+    s = clib.sorad(cs32, kind)
+    tol = 1e-6 if kind == "r8" else 2e-2
+    for k, v in got.items():
+        assert np.abs(v - o[k].astype(np.float64)).max() <= (tol if k != "dfdts" else tol * 1e-2), k
+    tol = 1e-9 if kind == "r8" else 2e-5
+    for k, v in sgot.items():
+        assert np.abs(v - s[k].astype(np.float64)).max() <= tol, k
