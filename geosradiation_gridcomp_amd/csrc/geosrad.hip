@@ -851,7 +851,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return GEOSRAD_OK;
     }
 
-    struct WsSw { R *sc; uint32_t *scidx; uint8_t *colcloudy; int32_t *perm, *nclear; R *alpha, *rcorr, *taucmc, *ssacmc, *asmcmc, *cotsum, *cell, *part, *bsfc, *cot; };
+    struct WsSw { R *sc; uint32_t *scidx; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *alpha, *rcorr, *taucmc, *ssacmc, *asmcmc, *cotsum, *cell, *part, *bsfc, *cot; };
     size_t ws_layout_sw(int nc, int nlay, WsSw *w, char *base) const
     {
         size_t off = 0;
@@ -863,6 +863,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(nc); if (w) w->colcloudy = (uint8_t *)p;
         p = take((size_t)nc * 4); if (w) w->perm = (int32_t *)p;
         p = take(4); if (w) w->nclear = (int32_t *)p;
+        p = take(cl); if (w) w->laycloudy = (uint8_t *)p;
         p = take(cl * sizeof(R)); if (w) w->alpha = (R *)p;
         p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
         p = take(NG_SW * cl * sizeof(R)); if (w) w->taucmc = (R *)p;
@@ -963,7 +964,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.tauaer = iaer == 10 ? P(S_TAUAER) : nullptr; A.ssaaer = iaer == 10 ? P(S_SSAAER) : nullptr;
             A.asmaer = iaer == 10 ? P(S_ASMAER) : nullptr;
             A.coszen = P(S_COSZEN); A.asdir = P(S_ASDIR); A.asdif = P(S_ASDIF); A.aldir = P(S_ALDIR); A.aldif = P(S_ALDIF);
-            A.sc = w.sc; A.scidx = w.scidx; A.colcloudy = w.colcloudy; A.perm = w.perm; A.nclear = w.nclear; A.alpha = w.alpha; A.rcorr = w.rcorr;
+            A.sc = w.sc; A.scidx = w.scidx; A.colcloudy = w.colcloudy; A.laycloudy = w.laycloudy; A.perm = w.perm; A.nclear = w.nclear; A.alpha = w.alpha; A.rcorr = w.rcorr;
             A.taucmc = w.taucmc; A.ssacmc = w.ssacmc; A.asmcmc = w.asmcmc; A.cotsum = w.cotsum; A.cell = w.cell; A.part = w.part;
             A.bsfc = w.bsfc; A.cot = w.cot;
             A.err = d_err + 1;
@@ -979,7 +980,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, st, nc, (const uint8_t *)w.colcloudy, w.perm, w.nclear); span_end(st);
             span_begin(7, st); hipLaunchKernelGGL(k_sw_setcoef<R>, dim3(gx, nlay), blk, 0, st, A, (const SwDev<R> *)d_S); span_end(st);
             span_begin(2, st); hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), blk, 0, st, nc, ncol, nlay, dyofyr, A.zm, A.alat,
-                               (const int32_t *)w.perm, (const int32_t *)w.nclear, (const LwDev<R> *)d_T, A.alpha, A.rcorr, (uint8_t *)nullptr); span_end(st);
+                               (const int32_t *)w.perm, (const int32_t *)w.nclear, (const LwDev<R> *)d_T, A.alpha, A.rcorr, A.laycloudy); span_end(st);
             McArgs<R> M{};
             M.ncol = nc; M.ld = ncol; M.nlay = nlay; M.nsubcol = NG_SW; M.doy = dyofyr; M.cloudLM = cloudLM; M.cloudMH = cloudMH;
             M.iceflg = iceflg; M.liqflg = liqflg;
@@ -987,7 +988,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.cwp_tiny = (R)1.e-20;
             M.play = A.play; M.cldf = A.cld; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
             M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
-            M.taucmc = A.taucmc; M.ssacmc = A.ssacmc; M.asmcmc = A.asmcmc; M.cotsum = A.cotsum; M.clearCounts = A.clearCounts; M.err = d_err + 1;
+            M.taucmc = A.taucmc; M.ssacmc = A.ssacmc; M.asmcmc = A.asmcmc; M.laycloudy = A.laycloudy; M.cotsum = A.cotsum; M.clearCounts = A.clearCounts; M.err = d_err + 1;
             {
                 McPlan MP; int nseg = 0;
                 rc = mc_plan(2, NG_SW, nlay, MP, nseg);

@@ -397,16 +397,23 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
                 if (in_mid) any_mid |= 1u << s;
                 if (in_lo) any_lo |= 1u << s;
             }
+            // cells of a layer without cloud fraction are clear in every sub-column: they are neither written here nor read by
+            // the band kernels (which test laycloudy, set only where some sub-column has an optically non-zero cloud)
             if (MODE == 0) {
-                R tau = 0;
-                if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, rei, rel, err);
-                M.taucmc[tb0 + (size_t)s * n + (size_t)il * tbs] = tau;
-                if (tau > 0) M.laycloudy[w] = 1;
+                if (cf > 0) {
+                    R tau = 0;
+                    if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, rei, rel, err);
+                    M.taucmc[tb0 + (size_t)s * n + (size_t)il * tbs] = tau;
+                    if (tau > 0) M.laycloudy[w] = 1;
+                }
             } else if (MODE == 2) {
                 R taor = 0, tauc = 0, ssac = 1, asmc = 0;
                 if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, rei, rel, taor, tauc, ssac, asmc);
-                const size_t oc = tb0 + (size_t)s * n + (size_t)il * tbs;
-                M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
+                if (cf > 0) {
+                    const size_t oc = tb0 + (size_t)s * n + (size_t)il * tbs;
+                    M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
+                    if (tauc > 0) M.laycloudy[w] = 1;
+                }
                 // super-layer sums of the un-scaled tau for the PAR diagnostics (SW/rrtmg_sw_spcvmc.F90:760-800)
                 if (il < M.cloudLM) cs_lo[s] += taor; else if (il < M.cloudMH) cs_mid[s] += taor; else cs_hi[s] += taor;
             } else {

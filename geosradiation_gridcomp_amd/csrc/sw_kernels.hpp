@@ -63,6 +63,7 @@ template <typename R> struct SwArgs {
     int32_t *perm, *nclear;              // k_partition: compacted position -> column; number of clear columns
     R *alpha, *rcorr;
     R *taucmc, *ssacmc, *asmcmc;         // McICA cloud optics, band-major planes [band][lay][g][col]
+    uint8_t *laycloudy;                  // [lay][col] some sub-column of the layer has cloud (only those layers' planes are valid)
     R *cotsum;                           // [3][NG_SW][ncol]  per-sub-column low|mid|high sums of the un-scaled cloud tau
     R *cell;                             // [16][band-major plane]: 8 parked values per cell, clear sky then total sky
     R *part;                             // [4][14][nlay+1][ncol]: cu, cd, fu, fd per band
@@ -559,6 +560,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
             ta = ldg(A.tauaer + bo, ab); om = ldg(A.ssaaer + bo, ab); as = ldg(A.asmaer + bo, ab);
         }
         const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
+        const bool laycld = CLD && ccol && ldg(A.laycloudy, (uint32_t)lay * (uint32_t)n + ucol) != 0;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             R tg[W], tr[W];
@@ -600,7 +602,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 stg(CELL(4), ct4, dbt); stg(CELL(5), ct4, tdbt[g]); stg(CELL(6), ct4, ztdn[g]); stg(CELL(7), ct4, prdnd[g]);
                 if (CLD && ccol) {
                     // total sky: cloudy cells get the (already delta-scaled) cloud optics added (:512-536, 541, 547-559)
-                    const R tc = ldg(tcb, cb4);
+                    const R tc = laycld ? ldg(tcb, cb4) : (R)0;
                     const bool cellcld = tc > 0;
                     if (cellcld) {
                         const R oc = ldg(ocb, cb4), gc = ldg(gcb, cb4);
