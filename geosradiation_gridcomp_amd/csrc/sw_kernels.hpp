@@ -546,6 +546,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
 #pragma unroll
     for (int g = 0; g < NG; g++) { tdbt[g] = 1; ztdn[g] = 1; prdnd[g] = 0; tdbtT[g] = 1; ztdnT[g] = 1; prdndT[g] = 0; }
     uint32_t cmask = 0;      // bit g: the layer processed last (finally: the surface layer) is cloudy in sub-column g
+    uint32_t dmask = 0;      // bit g: a cloudy cell has been met in sub-column g (total sky diverged from clear sky)
     for (int jk = 0; jk < nlay; jk++) {
         const int lay = nlay - 1 - jk;
         cmask = 0;
@@ -599,11 +600,20 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                     tdbt[g] = dbt * tdbt[g]; ztdn[g] = zt; prdnd[g] = pr;
                 }
                 stg(CELL(0), ct4, ref); stg(CELL(1), ct4, refd); stg(CELL(2), ct4, tra); stg(CELL(3), ct4, trad);
-                stg(CELL(4), ct4, dbt); stg(CELL(5), ct4, tdbt[g]); stg(CELL(6), ct4, ztdn[g]); stg(CELL(7), ct4, prdnd[g]);
-                if (CLD && ccol) {
+                stg(CELL(4), ct4, dbt); stg(CELL(6), ct4, ztdn[g]); stg(CELL(7), ct4, prdnd[g]);
+                const R tdbt_clear = tdbt[g];
+                bool cellcld = false;
+                R tc = 0;
+                if (CLD && ccol && laycld) { tc = ldg(tcb, cb4); cellcld = tc > 0; }
+                // Above the highest cloudy cell of a sub-column the total-sky downward state IS the clear-sky one (same recurrences,
+                // same inputs): nothing is computed or parked for it there; the sign bit of the parked clear-sky T_dir^cum tells
+                // sweep B from which level on the total sky has values of its own.
+                const bool divg = CLD && ccol && (((dmask >> g) & 1u) || cellcld);
+                stg(CELL(5), ct4, divg ? -tdbt_clear : tdbt_clear);
+                if (CLD && ccol && !divg) { tdbtT[g] = tdbt[g]; ztdnT[g] = ztdn[g]; prdndT[g] = prdnd[g]; }
+                if (divg) {
+                    dmask |= 1u << g;
                     // total sky: cloudy cells get the (already delta-scaled) cloud optics added (:512-536, 541, 547-559)
-                    const R tc = laycld ? ldg(tcb, cb4) : (R)0;
-                    const bool cellcld = tc > 0;
                     if (cellcld) {
                         const R oc = ldg(ocb, cb4), gc = ldg(gcb, cb4);
                         R g2 = ztauo * zomco * zgco + tc * oc * gc;
@@ -679,16 +689,20 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
             const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
             const R zi = zinc[g] * prmu0;
             R ref = ldg(CELL(0), c4), refd = ldg(CELL(1), c4), tra = ldg(CELL(2), c4), trad = ldg(CELL(3), c4), dbt = ldg(CELL(4), c4);
+            R tbc, ztc, prc;
+            bool ldiv = false;
             {
                 const R zrj = f_rcp<R>((R)1. - prupd[g] * refd);
                 const R pu = ref + (trad * ((tra - dbt) * prupd[g] + dbt * prup[g])) * zrj;
                 const R pd = refd + trad * trad * prupd[g] * zrj;
                 prup[g] = pu; prupd[g] = pd;
-                R tb = 1, zt = 1, pr = 0;
-                if (jk > 0) { tb = ldg(CELL(5), u4); zt = ldg(CELL(6), u4); pr = ldg(CELL(7), u4); }
-                const R zr = f_rcp<R>((R)1. - pr * pd);
-                cu = cu + zi * ((tb * pu + (zt - tb) * pd) * zr);
-                cd = cd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
+                if (jk > 0) {
+                    tbc = ldg(CELL(5), u4); ztc = ldg(CELL(6), u4); prc = ldg(CELL(7), u4);
+                    if (CLD) { ldiv = __builtin_signbit(tbc); tbc = ldiv ? -tbc : tbc; }
+                } else { tbc = 1; ztc = 1; prc = 0; ldiv = false; }
+                const R zr = f_rcp<R>((R)1. - prc * pd);
+                cu = cu + zi * ((tbc * pu + (ztc - tbc) * pd) * zr);
+                cd = cd + zi * (tbc + (ztc - tbc + tbc * pu * prc) * zr);
             }
             if (CLD && ccol) {
                 if (cmask & (1u << g)) {
@@ -698,8 +712,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 const R pu = ref + (trad * ((tra - dbt) * prupdT[g] + dbt * prupT[g])) * zrj;
                 const R pd = refd + trad * trad * prupdT[g] * zrj;
                 prupT[g] = pu; prupdT[g] = pd;
-                R tb = 1, zt = 1, pr = 0;
-                if (jk > 0) {
+                R tb = tbc, zt = ztc, pr = prc;              // above the sub-column's highest cloud: the clear-sky values
+                if (ldiv) {
                     tb = ldg(CELL(13), u4); zt = ldg(CELL(14), u4); pr = ldg(CELL(15), u4);
                     if (__builtin_signbit(tb)) { cnext |= 1u << g; tb = -tb; }
                 }
