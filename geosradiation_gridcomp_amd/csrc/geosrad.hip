@@ -364,6 +364,12 @@ template <typename R> struct Ctx : geosrad_ctx {
         HIPCHK(hipMalloc((void **)&d_S, sizeof(SwDev<R>)));
         HIPCHK(hipMalloc((void **)&d_C, sizeof(ChouDev<R>)));
         HIPCHK(hipMalloc((void **)&d_O, sizeof(SoradDev<R>)));
+        if (lw_bands_lds_bytes<R>() > 64 * 1024) {      // the LDS copy of the LW transmittance table (fp32 build)
+            const int lds = (int)lw_bands_lds_bytes<R>();
+            HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        }
         // Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
         const double adl[4] = {1.4315, 2.1219, 7., -25.584}, rdl[4] = {0.72192, 0.78996, 8.5, 40.404};
         for (int i = 0; i < 4; i++) { h_T.aam[i] = (R)(sizeof(R) == 4 ? (float)adl[i] : adl[i]); h_T.ram[i] = (R)(sizeof(R) == 4 ? (float)rdl[i] : rdl[i]); }
@@ -667,11 +673,12 @@ template <typename R> struct Ctx : geosrad_ctx {
                 span_end(st);
             }
             span_begin(4, st);
+            const size_t lds = lw_bands_lds_bytes<R>();
             if (A.dbg_taug) {
-                hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             } else {
-                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
-                hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, 0, st, A, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             }
             span_end(st);
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };

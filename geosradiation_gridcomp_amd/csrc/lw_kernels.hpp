@@ -974,14 +974,24 @@ template <typename R> GR_DEV R planck_at(const R *__restrict__ totplnk, int ib, 
 // CLD = false: 256-column block without any cloud (clear == total, one stream);
 // CLD = true : general case, per-lane `ccol` predicate, separate clear-sky stream once the streams part.
 // DBG = true : additionally dumps taug/pfracs in the reference's (nlay,140,ncol) layout (test hook only).
+// the transmittance table lives in LDS for 4-byte reals: 2 blocks x 80 KB fill a CU's 160 KB, which is the 2 waves/SIMD the
+// band kernels' register count allows anyway; the 8-byte table (160 KB) stays in L2
+template <typename R> struct LwLutInLds { static constexpr bool value = sizeof(R) == 4; };
+template <typename R> constexpr size_t lw_bands_lds_bytes() { return LwLutInLds<R>::value ? (size_t)(NTBL + 1) * 2 * sizeof(R) : 0; }
+
 template <typename R, typename BAND, bool CLD, bool DBG>
-GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear)
+GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear, const typename Vec2<R>::T *luts)
 {
     constexpr int NG = BAND::NG, IB = BAND::IB, G0 = BAND::G0;
     constexpr int W = NG >= 4 ? 4 : 2;
     constexpr int NQ = (NG + W - 1) / W;
     using R2 = typename Vec2<R>::T;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
+    // (1 - transmittance, tfac) of a discretised optical depth: from the block's LDS copy of the table when there is one
+    auto lut_at = [&](int i) -> R2 {
+        if constexpr (LwLutInLds<R>::value) return luts[i];
+        else return ldg(T.lut, (uint32_t)i * (uint32_t)sizeof(R2));
+    };
     const bool dudTs = A.dudTs != 0;
     const R bpade = T.bpade, tblint = (R)NTBL;
     const R sumfac = (R)0.5 * T.delwave[IB] * T.fluxfac;
@@ -1083,7 +1093,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                 if (odepth < 0) odepth = 0;
                 const R tblind = odepth / (bpade + odepth);
                 itg[j] = (int)(tblint * tblind + (R)0.5);
-                eg[j] = ldg(T.lut, (uint32_t)itg[j] * (uint32_t)sizeof(R2));
+                eg[j] = lut_at(itg[j]);
             }
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: only now write the PREVIOUS group's (a, B-up) pairs.  Loads and stores share one in-order counter
@@ -1122,7 +1132,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                         const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
                         const R tb2 = odtot / (bpade + odtot);
                         const int ittot = (int)(tblint * tb2 + (R)0.5);
-                        const R2 e2 = ldg(T.lut, (uint32_t)ittot * (uint32_t)sizeof(R2));
+                        const R2 e2 = lut_at(ittot);
                         atot = (R)1. - e2.x;
                         const R bbdtot = pf[j] * (blay + e2.y * dplankdn);
                         bbutot = pf[j] * (blay + e2.y * dplankup);
@@ -1178,7 +1188,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                 if (odepth < 0) odepth = 0;
                 const R tblind = odepth / (bpade + odepth);
                 const int itgas = (int)(tblint * tblind + (R)0.5);
-                const R2 e = ldg(T.lut, (uint32_t)itgas * (uint32_t)sizeof(R2));
+                const R2 e = lut_at(itgas);
                 const R agas = (R)1. - e.x, tfacgas = e.y;
                 const R bbdgas = pf[j] * (blay + tfacgas * dplankdn);
                 const R bbugas = pf[j] * (blay + tfacgas * dplankup);
@@ -1195,7 +1205,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                         const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
                         const R tb2 = odtot / (bpade + odtot);
                         const int ittot = (int)(tblint * tb2 + (R)0.5);
-                        const R2 e2 = ldg(T.lut, (uint32_t)ittot * (uint32_t)sizeof(R2));
+                        const R2 e2 = lut_at(ittot);
                         atot = (R)1. - e2.x;
                         const R bbdtot = pf[j] * (blay + e2.y * dplankdn);
                         bbutot = pf[j] * (blay + e2.y * dplankup);
@@ -1311,26 +1321,37 @@ __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
     const int bstart = (int)(blockIdx.x * blockDim.x);
     const int bend = bstart + (int)blockDim.x < A.ncol ? bstart + (int)blockDim.x : A.ncol;
     if (!DBG && (CLD ? bend <= nclear : bstart >= nclear)) return;
+    // fp32: the (1 - exp(-tau), tfac) table (80 KB) is copied into LDS once per block - every cell looks it up at an index that
+    // differs from lane to lane, which costs up to 64 cache lines per wave from L2 and a few LDS cycles from here
+    using R2 = typename Vec2<R>::T;
+    extern __shared__ __align__(16) unsigned char lw_lds[];
+    const R2 *luts = nullptr;
+    if constexpr (LwLutInLds<R>::value) {
+        R2 *const l = reinterpret_cast<R2 *>(lw_lds);
+        for (int i = threadIdx.x; i <= NTBL; i += (int)blockDim.x) l[i] = ldg(T.lut, (uint32_t)i * (uint32_t)sizeof(R2));
+        __syncthreads();
+        luts = l;
+    }
     const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
     if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
     switch (LW_BAND_ORDER[blockIdx.y]) {
-        case 1: band_body<R, Band1, CLD, DBG>(A, T, col, nclear); break;
-        case 2: band_body<R, Band2, CLD, DBG>(A, T, col, nclear); break;
-        case 3: band_body<R, Band3, CLD, DBG>(A, T, col, nclear); break;
-        case 4: band_body<R, Band4, CLD, DBG>(A, T, col, nclear); break;
-        case 5: band_body<R, Band5, CLD, DBG>(A, T, col, nclear); break;
-        case 6: band_body<R, Band6, CLD, DBG>(A, T, col, nclear); break;
-        case 7: band_body<R, Band7, CLD, DBG>(A, T, col, nclear); break;
-        case 8: band_body<R, Band8, CLD, DBG>(A, T, col, nclear); break;
-        case 9: band_body<R, Band9, CLD, DBG>(A, T, col, nclear); break;
-        case 10: band_body<R, Band10, CLD, DBG>(A, T, col, nclear); break;
-        case 11: band_body<R, Band11, CLD, DBG>(A, T, col, nclear); break;
-        case 12: band_body<R, Band12, CLD, DBG>(A, T, col, nclear); break;
-        case 13: band_body<R, Band13, CLD, DBG>(A, T, col, nclear); break;
-        case 14: band_body<R, Band14, CLD, DBG>(A, T, col, nclear); break;
-        case 15: band_body<R, Band15, CLD, DBG>(A, T, col, nclear); break;
-        default: band_body<R, Band16, CLD, DBG>(A, T, col, nclear); break;
+        case 1: band_body<R, Band1, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 2: band_body<R, Band2, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 3: band_body<R, Band3, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 4: band_body<R, Band4, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 5: band_body<R, Band5, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 6: band_body<R, Band6, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 7: band_body<R, Band7, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 8: band_body<R, Band8, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 9: band_body<R, Band9, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 10: band_body<R, Band10, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 11: band_body<R, Band11, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 12: band_body<R, Band12, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 13: band_body<R, Band13, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 14: band_body<R, Band14, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 15: band_body<R, Band15, CLD, DBG>(A, T, col, nclear, luts); break;
+        default: band_body<R, Band16, CLD, DBG>(A, T, col, nclear, luts); break;
     }
 }
 
