@@ -54,6 +54,12 @@ def lib():
         if not os.path.exists(SO):
             raise RuntimeError(f"{SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        # PyTorch ships its own copy of the HIP runtime; when it is going to be used in this process (device tensors and streams
+        # handed to the `_dev` entry points) it has to be the one this library binds to, so it is loaded first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(SO)
         L.geosrad_last_error.restype = ctypes.c_char_p
         L.geosrad_last_error.argtypes = [ctypes.c_void_p]
