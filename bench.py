@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw", "chou", "irrad", "sorad"])
     ap.add_argument("--cloudy", type=float, default=0.6, help="fraction of cloudy columns (0 = clear-sky)")
     ap.add_argument("--no-aerosol", action="store_true")
+    ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     a = ap.parse_args()
     aerosol = not a.no_aerosol
@@ -185,6 +186,12 @@ def main():
     # ---- inputs resident in HBM -------------------------------------------------------------------------------
     ncol, nlay = a.ncol, a.nlay
     inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
+    if a.coherent > 1:
+        # sensitivity knob, not a headline configuration: runs of `coherent` identical profiles (neighbouring lanes then gather the
+        # same k-distribution rows, as spatially smooth model fields largely do; the default columns are independent draws)
+        src = (np.arange(ncol) // a.coherent) * a.coherent
+        inp = {k: (np.ascontiguousarray(v[..., src]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v)
+               for k, v in inp.items()}
     tdt = torch.float32 if a.real == 4 else torch.float64
     names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + LW_IN2D + (["tauaer"] if aerosol else [])
     if do_sw:
