@@ -19,6 +19,8 @@ EXPORTS = [
     "geosrad_check", "geosrad_profile", "geosrad_profile_read", "geosrad_kernel_name", "geosrad_rrtmg_lw_taumol", "geosrad_mcica", "geosrad_clearcounts",
     "geosrad_set_tables_sw", "geosrad_load_tables_sw", "geosrad_rrtmg_sw", "geosrad_rrtmg_sw_dev", "geosrad_rrtmg_sw_taumol", "geosrad_mcica_dev",
     "geosrad_set_tables_chou_lw", "geosrad_load_tables_chou_lw", "geosrad_irrad", "geosrad_irrad_dev",
+    "geosrad_lw_driver_rrtmg_dev", "geosrad_sw_driver_rrtmg_dev", "geosrad_lw_update_flx_dev", "geosrad_sw_update_export_dev",
+    "geosrad_rad_tendencies_dev",
     "geosrad_set_tables_chou_sw", "geosrad_load_tables_chou_sw", "geosrad_sorad", "geosrad_sorad_dev",
 ]
 

@@ -342,6 +342,61 @@ class Context:
             v("dflx"), v("uflxc"), v("dflxc"), v("duflx_dTs"), v("duflxc_dTs"), _p(bo), v("olrb"), v("dolrb_dTs"))
         self._chk(rc)
 
+    # ---- GridComp data path either side of the solvers (device pointers, GEOS layout) ---------------------------------------
+    @staticmethod
+    def _ptr_array(names, ptr):
+        arr = (ctypes.c_void_p * len(names))()
+        for i, k in enumerate(names):
+            arr[i] = ptr.get(k) or None
+        return arr
+
+    def lw_driver_rrtmg_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, doy, lcldlm, lcldmh, band_output=None):
+        """RRTMG branch of LW_Driver (GEOS_IrradGridComp.F90:3188-3615).  `ptr`: name -> device address for gridcomp.LWD_IN and
+        gridcomp.LWD_OUT (missing / 0 = not associated); `consts` in gridcomp.LWD_CONST order; lcldlm / lcldmh in MODEL ordering."""
+        from . import gridcomp as G
+        bo = np.zeros(NBNDLW, dtype=np.int32) if band_output is None else np.ascontiguousarray(band_output, dtype=np.int32)
+        cs = (ctypes.c_double * len(G.LWD_CONST))(*consts)
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_lw_driver_rrtmg_dev(
+            self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nb_aer), self._ptr_array(G.LWD_IN, ptr), cs, ci(iceflg), ci(liqflg),
+            ci(int(doy)), ci(int(lcldlm)), ci(int(lcldmh)), _p(bo), self._ptr_array(G.LWD_OUT, ptr)))
+
+    def sw_driver_rrtmg_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, sc, dist, isolvar, dyofyr, include_aerosols,
+                            lcldlm, lcldmh, normflx=1, bndsolvar=None, indsolvar=None):
+        """RRTMG branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:6113-6450)."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        cs = (ctypes.c_double * len(G.SWD_CONST))(*consts)
+        bs = None if bndsolvar is None else np.ascontiguousarray(bndsolvar, dtype=self.dtype)
+        ins = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=self.dtype)
+        self._chk(self.L.geosrad_sw_driver_rrtmg_dev(
+            self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nb_aer), self._ptr_array(G.SWD_IN, ptr), cs, ci(iceflg), ci(liqflg),
+            ctypes.c_double(sc), ctypes.c_double(dist), ci(isolvar), ci(int(dyofyr)), ci(1 if include_aerosols else 0), ci(int(lcldlm)),
+            ci(int(lcldmh)), ci(normflx), None if bs is None else _p(bs), None if ins is None else _p(ins),
+            self._ptr_array(G.SWD_OUT, ptr)))
+
+    def lw_update_flx_dev(self, stream, ncol, lm, rrtmg, lev_mid_high, lev_low_mid, undef, ptr):
+        """Update_Flx (GEOS_IrradGridComp.F90:3796-3999): `ptr` holds gridcomp.LWU_IN internals and the requested gridcomp.LWU_OUT."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_lw_update_flx_dev(
+            self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(1 if rrtmg else 0), ci(int(lev_mid_high)), ci(int(lev_low_mid)),
+            ctypes.c_double(undef), self._ptr_array(G.LWU_IN, ptr), self._ptr_array(G.LWU_OUT, ptr)))
+
+    def sw_update_export_dev(self, stream, ncol, lm, nbands, ptr):
+        """flux part of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7540-7579)."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_sw_update_export_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nbands),
+                                                      self._ptr_array(G.SWU_IN, ptr), self._ptr_array(G.SWU_OUT, ptr)))
+
+    def rad_tendencies_dev(self, stream, ncol, lm, grav, cp, ptr):
+        """heating rates of the parent GridComp (GEOS_RadiationGridComp.F90:798-819)."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_rad_tendencies_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ctypes.c_double(grav),
+                                                    ctypes.c_double(cp), self._ptr_array(G.RT_IN, ptr), self._ptr_array(G.RT_OUT, ptr)))
+
     def profile(self, enable=True):
         self._chk(self.L.geosrad_profile(self.h, ctypes.c_int(1 if enable else 0)))
 

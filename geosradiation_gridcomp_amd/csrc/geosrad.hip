@@ -10,6 +10,7 @@
 #include <tuple>
 #include <vector>
 
+#include <cstddef>
 #include "../../include/geosrad.h"
 #include "lw_device.hpp"
 #include "lw_kernels.hpp"
@@ -17,6 +18,7 @@
 #include "mcica_kernels.hpp"
 #include "chou_kernels.hpp"
 #include "sorad_kernels.hpp"
+#include "gridcomp_kernels.hpp"
 
 using namespace geosrad;
 
@@ -260,6 +262,16 @@ struct geosrad_ctx {
     virtual int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg,
                        int liqflg, int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
                        int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
+    virtual int lw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg,
+                              int liqflg, int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out) = 0;
+    virtual int sw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg,
+                              int liqflg, double sc, double dist, int isolvar, int dyofyr, int include_aerosols, int lcldlm,
+                              int lcldmh, int normflx, const void *bndsolvar, const void *indsolvar, void *const *out) = 0;
+    virtual int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
+                                  const void *const *in, void *const *out) = 0;
+    virtual int sw_update_export_dev(hipStream_t st, int ncol, int lm, int nbands, const void *const *in, void *const *out) = 0;
+    virtual int rad_tendencies_dev(hipStream_t st, int ncol, int lm, double grav, double cp, const void *const *in,
+                                   void *const *out) = 0;
     virtual int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
                         int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
                         int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
@@ -322,6 +334,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     ChouDev<R> *d_C = nullptr;
     bool have_chou = false;
     char *d_ws_ch = nullptr; size_t ws_ch_bytes = 0;
+    char *d_ws_drv = nullptr; size_t ws_drv_bytes = 0;      // RRTMG-side arrays of the GridComp drivers
     // McICA segment plans (jump-ahead constants), cached per (mode, nsubcol, nlay, inhomogeneous?)
     struct PlanEntry { McSegDev *d_seg; int nseg; KissJump jsub, jhalf; };
     std::map<std::tuple<int, int, int, int>, PlanEntry> plans;
@@ -346,6 +359,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_ws_so) (void)hipFree(d_ws_so);
         if (d_C) (void)hipFree(d_C);
         if (d_ws_ch) (void)hipFree(d_ws_ch);
+        if (d_ws_drv) (void)hipFree(d_ws_drv);
         if (d_S) (void)hipFree(d_S);
         if (d_ws_sw) (void)hipFree(d_ws_sw);
         if (d_err) (void)hipFree(d_err);
@@ -523,7 +537,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return sync_T();
     }
 
-    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
+    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + ws_drv_bytes + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
     struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
@@ -687,6 +701,246 @@ template <typename R> struct Ctx : geosrad_ctx {
             O.olrb = (R *)out[O_OLRB]; O.dolrb_dTs = (R *)out[O_DOLRB]; O.col0 = c0;
             span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, A, O); span_end(st);
         }
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    // ---- GridComp drivers (gridcomp_kernels.hpp) ---------------------------------------------------------------------------
+    int drv_reserve(size_t need)
+    {
+        if (need <= ws_drv_bytes) return GEOSRAD_OK;
+        if (d_ws_drv) { HIPCHK(hipFree(d_ws_drv)); d_ws_drv = nullptr; ws_drv_bytes = 0; }
+        if (hipMalloc((void **)&d_ws_drv, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the driver workspace failed");
+        ws_drv_bytes = need;
+        return GEOSRAD_OK;
+    }
+
+    int lw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg, int liqflg,
+                      int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm < 4 || nb < 0 || nb > 16) return fail(GEOSRAD_EINVAL, "bad ncol/lm/nb_aer");
+        for (int k = 0; k < GEOSRAD_LWD_NIN; k++)
+            if (!in[k] && k != GEOSRAD_LWD_CO2_3D && k != GEOSRAD_LWD_TAUA && k != GEOSRAD_LWD_SSAA) return fail(GEOSRAD_EINVAL, "null input array");
+        if ((in[GEOSRAD_LWD_TAUA] == nullptr) != (in[GEOSRAD_LWD_SSAA] == nullptr)) return fail(GEOSRAD_EINVAL, "TAUA and SSAA go together");
+        const size_t n = (size_t)ncol, cl = n * lm, cv = n * (lm + 1);
+        size_t off = 0;
+        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
+        size_t o_lay[18], o_lev[2], o_flux[6];
+        for (auto &o : o_lay) o = take(cl);
+        for (auto &o : o_lev) o = take(cv);
+        const size_t o_tsfc = take(n), o_alat = take(n), o_emis = take(n * 16), o_aer = take(cl * 16);
+        for (auto &o : o_flux) o = take(cv);
+        const size_t o_olrb = take(n * 16), o_dolrb = take(n * 16), o_cc = take(n * 4);
+        int rc = drv_reserve(off);
+        if (rc) return rc;
+        auto P = [&](size_t o) { return (R *)(d_ws_drv + o); };
+        LwdArgs<R> A{};
+        A.ncol = ncol; A.lm = lm; A.nb = in[GEOSRAD_LWD_TAUA] ? nb : 0; A.iceflg = iceflg; A.liqflg = liqflg;
+        auto I = [&](int k) { return (const R *)in[k]; };
+        A.ple = I(GEOSRAD_LWD_PLE); A.pl = I(GEOSRAD_LWD_PL); A.t = I(GEOSRAD_LWD_T); A.q = I(GEOSRAD_LWD_Q); A.o3 = I(GEOSRAD_LWD_O3);
+        A.ch4 = I(GEOSRAD_LWD_CH4); A.n2o = I(GEOSRAD_LWD_N2O); A.co2_3d = I(GEOSRAD_LWD_CO2_3D); A.cfc11 = I(GEOSRAD_LWD_CFC11);
+        A.cfc12 = I(GEOSRAD_LWD_CFC12); A.hcfc22 = I(GEOSRAD_LWD_HCFC22); A.fcld = I(GEOSRAD_LWD_FCLD);
+        A.cwc_liq = I(GEOSRAD_LWD_CWC_LIQ); A.cwc_ice = I(GEOSRAD_LWD_CWC_ICE); A.reff_liq = I(GEOSRAD_LWD_REFF_LIQ);
+        A.reff_ice = I(GEOSRAD_LWD_REFF_ICE); A.taua = I(GEOSRAD_LWD_TAUA); A.ssaa = I(GEOSRAD_LWD_SSAA); A.ts = I(GEOSRAD_LWD_TS);
+        A.emis = I(GEOSRAD_LWD_EMIS); A.lats = I(GEOSRAD_LWD_LATS); A.t2m = I(GEOSRAD_LWD_T2M);
+        A.co2_fixed = (R)consts[GEOSRAD_LWD_C_CO2_FIXED]; A.o2 = (R)consts[GEOSRAD_LWD_C_O2]; A.ccl4 = (R)consts[GEOSRAD_LWD_C_CCL4];
+        // (MAPL_AIRMW/MAPL_H2OMW), (MAPL_AIRMW/MAPL_O3MW): constant expressions of the caller's real kind
+        A.airmw_over_h2omw = (R)consts[GEOSRAD_C_AIRMW] / (R)consts[GEOSRAD_C_H2OMW];
+        A.airmw_over_o3mw = (R)consts[GEOSRAD_C_AIRMW] / (R)consts[GEOSRAD_C_O3MW];
+        A.rgas = (R)consts[GEOSRAD_C_RGAS]; A.grav = (R)consts[GEOSRAD_C_GRAV];
+        A.play = P(o_lay[0]); A.tlay = P(o_lay[1]); A.h2o = P(o_lay[2]); A.o3_r = P(o_lay[3]); A.co2_r = P(o_lay[4]); A.ch4_r = P(o_lay[5]);
+        A.n2o_r = P(o_lay[6]); A.o2_r = P(o_lay[7]); A.cfc11_r = P(o_lay[8]); A.cfc12_r = P(o_lay[9]); A.cfc22_r = P(o_lay[10]);
+        A.ccl4_r = P(o_lay[11]); A.cldf = P(o_lay[12]); A.ciwp = P(o_lay[13]); A.clwp = P(o_lay[14]); A.rei = P(o_lay[15]);
+        A.rel = P(o_lay[16]); A.zm = P(o_lay[17]); A.plev = P(o_lev[0]); A.tlev = P(o_lev[1]); A.tsfc = P(o_tsfc); A.alat = P(o_alat);
+        A.emis_r = P(o_emis); A.tauaer = P(o_aer);
+        const dim3 blk(256);
+        const unsigned gx = (unsigned)((ncol + 255) / 256);
+        hipLaunchKernelGGL((k_lwd_prep<R>), dim3(gx, lm), blk, 0, st, A);
+        hipLaunchKernelGGL((k_lwd_zm<R>), dim3(gx), blk, 0, st, A);
+        // reverse the super-layer interface indices (IRR:3237-3239) and call the solver with Ts_derivs = .true.
+        const int cloudMH = lm - lcldmh + 1, cloudLM = lm - lcldlm + 1;
+        const void *lin[I_NIN];
+        lin[I_PLAY] = A.play; lin[I_PLEV] = A.plev; lin[I_TLAY] = A.tlay; lin[I_TLEV] = A.tlev; lin[I_TSFC] = A.tsfc; lin[I_EMIS] = A.emis_r;
+        lin[I_H2O] = A.h2o; lin[I_O3] = A.o3_r; lin[I_CO2] = A.co2_r; lin[I_CH4] = A.ch4_r; lin[I_N2O] = A.n2o_r; lin[I_O2] = A.o2_r;
+        lin[I_CFC11] = A.cfc11_r; lin[I_CFC12] = A.cfc12_r; lin[I_CFC22] = A.cfc22_r; lin[I_CCL4] = A.ccl4_r; lin[I_CLDF] = A.cldf;
+        lin[I_CIWP] = A.ciwp; lin[I_CLWP] = A.clwp; lin[I_REI] = A.rei; lin[I_REL] = A.rel; lin[I_TAUAER] = A.tauaer; lin[I_ZM] = A.zm;
+        lin[I_ALAT] = A.alat;
+        void *lout[O_NOUT] = {P(o_flux[0]), P(o_flux[1]), P(o_flux[2]), P(o_flux[3]), P(o_flux[4]), P(o_flux[5]),
+                              out[GEOSRAD_LWD_OLRB] ? out[GEOSRAD_LWD_OLRB] : (void *)P(o_olrb),
+                              out[GEOSRAD_LWD_DOLRB] ? out[GEOSRAD_LWD_DOLRB] : (void *)P(o_dolrb)};
+        int32_t *cc = (int32_t *)(d_ws_drv + o_cc);
+        static const int32_t no_bands[16] = {0};
+        rc = lw_dev(st, ncol, lm, 1, lin, iceflg, liqflg, doy, cloudLM, cloudMH, cc, lout, band_output ? band_output : no_bands, nullptr,
+                    nullptr);
+        if (rc) return rc;
+        LwdPost<R> Q{};
+        Q.ncol = ncol; Q.lm = lm; Q.ngpt = NG_LW;
+        Q.uflx = P(o_flux[0]); Q.dflx = P(o_flux[1]); Q.uflxc = P(o_flux[2]); Q.dflxc = P(o_flux[3]); Q.duflx = P(o_flux[4]);
+        Q.duflxc = P(o_flux[5]); Q.clearCounts = cc; Q.emis = A.emis; Q.ts = A.ts;
+        auto O = [&](int k) { return (R *)out[k]; };
+        Q.flxu_int = O(GEOSRAD_LWD_FLXU_INT); Q.flxd_int = O(GEOSRAD_LWD_FLXD_INT); Q.flcu_int = O(GEOSRAD_LWD_FLCU_INT);
+        Q.flcd_int = O(GEOSRAD_LWD_FLCD_INT); Q.dfdts = O(GEOSRAD_LWD_DFDTS); Q.dfdtsc = O(GEOSRAD_LWD_DFDTSC);
+        Q.dfdtsna = O(GEOSRAD_LWD_DFDTSNA); Q.dfdtscna = O(GEOSRAD_LWD_DFDTSCNA); Q.flx_int = O(GEOSRAD_LWD_FLX_INT);
+        Q.flc_int = O(GEOSRAD_LWD_FLC_INT); Q.sfcem_int = O(GEOSRAD_LWD_SFCEM_INT); Q.ts_int = O(GEOSRAD_LWD_TS_INT);
+        Q.cldttlw = O(GEOSRAD_LWD_CLDTTLW); Q.cldhilw = O(GEOSRAD_LWD_CLDHILW); Q.cldmdlw = O(GEOSRAD_LWD_CLDMDLW);
+        Q.cldlolw = O(GEOSRAD_LWD_CLDLOLW);
+        hipLaunchKernelGGL((k_lwd_post<R>), dim3(gx, lm + 1), blk, 0, st, Q);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int sw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg, int liqflg,
+                      double sc, double dist, int isolvar, int dyofyr, int include_aerosols, int lcldlm, int lcldmh, int normflx,
+                      const void *bndsolvar, const void *indsolvar, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm < 4 || nb < 0 || nb > 14) return fail(GEOSRAD_EINVAL, "bad ncol/lm/nb_aer");
+        for (int k = 0; k < GEOSRAD_SWD_NIN; k++)
+            if (!in[k] && k != GEOSRAD_SWD_TAUA && k != GEOSRAD_SWD_SSAA && k != GEOSRAD_SWD_ASYA) return fail(GEOSRAD_EINVAL, "null input array");
+        const bool aer = in[GEOSRAD_SWD_TAUA] != nullptr;
+        if (aer && (!in[GEOSRAD_SWD_SSAA] || !in[GEOSRAD_SWD_ASYA])) return fail(GEOSRAD_EINVAL, "TAUA, SSAA and ASYA go together");
+        if (aer && nb != 14) return fail(GEOSRAD_EINVAL, "RRTMG_SW aerosol arrays have 14 bands");
+        const size_t n = (size_t)ncol, cl = n * lm, cv = n * (lm + 1);
+        size_t off = 0;
+        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
+        size_t o_lay[13], o_lev[2], o_aer[3], o_flux[4], o_sc[6], o_cot[8];
+        for (auto &o : o_lay) o = take(cl);
+        for (auto &o : o_lev) o = take(cv);
+        for (auto &o : o_aer) o = take(cl * 14);
+        for (auto &o : o_flux) o = take(cv);
+        for (auto &o : o_sc) o = take(n);
+        for (auto &o : o_cot) o = take(n);
+        const size_t o_band = take(n * 14), o_cc = take(n * 4);
+        int rc = drv_reserve(off);
+        if (rc) return rc;
+        auto P = [&](size_t o) { return (R *)(d_ws_drv + o); };
+        auto I = [&](int k) { return (const R *)in[k]; };
+        SwdArgs<R> A{};
+        A.ncol = ncol; A.lm = lm; A.nb = 14; A.iceflg = iceflg; A.liqflg = liqflg;
+        A.ple = I(GEOSRAD_SWD_PLE); A.pl = I(GEOSRAD_SWD_PL); A.t = I(GEOSRAD_SWD_T); A.q = I(GEOSRAD_SWD_Q); A.o3 = I(GEOSRAD_SWD_O3);
+        A.ch4 = I(GEOSRAD_SWD_CH4); A.cl = I(GEOSRAD_SWD_CL); A.ts = I(GEOSRAD_SWD_TS); A.qq_ice = I(GEOSRAD_SWD_QQ_ICE);
+        A.qq_liq = I(GEOSRAD_SWD_QQ_LIQ); A.rr_ice = I(GEOSRAD_SWD_RR_ICE); A.rr_liq = I(GEOSRAD_SWD_RR_LIQ);
+        A.taua = (R *)in[GEOSRAD_SWD_TAUA]; A.ssaa = (R *)in[GEOSRAD_SWD_SSAA]; A.asya = (R *)in[GEOSRAD_SWD_ASYA];
+        A.co2 = (R)consts[GEOSRAD_SWD_C_CO2]; A.o2 = (R)consts[GEOSRAD_SWD_C_O2];
+        A.airmw_over_h2omw = (R)consts[GEOSRAD_SWD_C_AIRMW] / (R)consts[GEOSRAD_SWD_C_H2OMW];
+        A.airmw_over_o3mw = (R)consts[GEOSRAD_SWD_C_AIRMW] / (R)consts[GEOSRAD_SWD_C_O3MW];
+        A.rgas = (R)consts[GEOSRAD_SWD_C_RGAS]; A.grav = (R)consts[GEOSRAD_SWD_C_GRAV];
+        A.play = P(o_lay[0]); A.tlay = P(o_lay[1]); A.h2o = P(o_lay[2]); A.o3_r = P(o_lay[3]); A.co2_r = P(o_lay[4]); A.ch4_r = P(o_lay[5]);
+        A.o2_r = P(o_lay[6]); A.cldf = P(o_lay[7]); A.ciwp = P(o_lay[8]); A.clwp = P(o_lay[9]); A.rei = P(o_lay[10]); A.rel = P(o_lay[11]);
+        A.zl = P(o_lay[12]); A.plev = P(o_lev[0]); A.tlev = P(o_lev[1]); A.tauaer = P(o_aer[0]); A.ssaaer = P(o_aer[1]); A.asmaer = P(o_aer[2]);
+        const dim3 blk(256);
+        const unsigned gx = (unsigned)((ncol + 255) / 256);
+        hipLaunchKernelGGL((k_swd_prep<R>), dim3(gx, lm), blk, 0, st, A);
+        hipLaunchKernelGGL((k_swd_zm<R>), dim3(gx), blk, 0, st, A);
+        const void *sin[S_NIN];
+        sin[S_PLAY] = A.play; sin[S_PLEV] = A.plev; sin[S_TLAY] = A.tlay; sin[S_H2O] = A.h2o; sin[S_O3] = A.o3_r; sin[S_CO2] = A.co2_r;
+        sin[S_CH4] = A.ch4_r; sin[S_O2] = A.o2_r; sin[S_CLD] = A.cldf; sin[S_CIWP] = A.ciwp; sin[S_CLWP] = A.clwp; sin[S_REI] = A.rei;
+        sin[S_REL] = A.rel; sin[S_ZM] = A.zl; sin[S_ALAT] = in[GEOSRAD_SWD_ALAT]; sin[S_TAUAER] = A.tauaer; sin[S_SSAAER] = A.ssaaer;
+        sin[S_ASMAER] = A.asmaer; sin[S_COSZEN] = in[GEOSRAD_SWD_ZT]; sin[S_ASDIR] = in[GEOSRAD_SWD_ALBVR]; sin[S_ASDIF] = in[GEOSRAD_SWD_ALBVF];
+        sin[S_ALDIR] = in[GEOSRAD_SWD_ALBNR]; sin[S_ALDIF] = in[GEOSRAD_SWD_ALBNF];
+        void *sout[SO_NOUT] = {};
+        for (int k = 0; k < 4; k++) sout[SO_UFLX + k] = P(o_flux[k]);
+        const int sc_ix[6] = {GEOSRAD_SWD_NIRR, GEOSRAD_SWD_NIRF, GEOSRAD_SWD_PARR, GEOSRAD_SWD_PARF, GEOSRAD_SWD_UVRR, GEOSRAD_SWD_UVRF};
+        for (int k = 0; k < 6; k++) sout[SO_NIRR + k] = out[sc_ix[k]] ? out[sc_ix[k]] : (void *)P(o_sc[k]);
+        sout[SO_FSWBAND] = out[GEOSRAD_SWD_FSWBAND] ? out[GEOSRAD_SWD_FSWBAND] : (void *)P(o_band);
+        for (int k = 0; k < 8; k++) sout[SO_COT0 + k] = P(o_cot[k]);      // cotd t/h/m/l then cotn t/h/m/l
+        int32_t *cc = (int32_t *)(d_ws_drv + o_cc);
+        // IAER = 10 always (SOL:6235; without aerosols the arrays are zero); super-layer indices flipped in the call (SOL:6341)
+        rc = sw_dev(st, ncol, lm, sc, dist, isolvar, sin, iceflg, liqflg, dyofyr, 10, lm - lcldlm + 1, lm - lcldmh + 1,
+                    normflx, cc, sout, 0, bndsolvar, indsolvar, nullptr);
+        if (rc) return rc;
+        SwdPost<R> Q{};
+        Q.ncol = ncol; Q.lm = lm; Q.ngpt = NG_SW; Q.aerosols = include_aerosols; Q.undef = (R)consts[GEOSRAD_SWD_C_UNDEF];
+        Q.swuflx = P(o_flux[0]); Q.swdflx = P(o_flux[1]); Q.swuflxc = P(o_flux[2]); Q.swdflxc = P(o_flux[3]); Q.clearCounts = cc;
+        for (int k = 0; k < 4; k++) { Q.cotd[k] = P(o_cot[k]); Q.cotn[k] = P(o_cot[4 + k]); Q.cot[k] = (R *)out[GEOSRAD_SWD_COTTP + k]; }
+        Q.fsw = (R *)out[GEOSRAD_SWD_FSW]; Q.fsc = (R *)out[GEOSRAD_SWD_FSC]; Q.fswu = (R *)out[GEOSRAD_SWD_FSWU]; Q.fscu = (R *)out[GEOSRAD_SWD_FSCU];
+        Q.cldts = (R *)out[GEOSRAD_SWD_CLDTS]; Q.cldhs = (R *)out[GEOSRAD_SWD_CLDHS]; Q.cldms = (R *)out[GEOSRAD_SWD_CLDMS];
+        Q.cldls = (R *)out[GEOSRAD_SWD_CLDLS];
+        hipLaunchKernelGGL((k_swd_post<R>), dim3(gx, lm + 1), blk, 0, st, Q);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
+                          const void *const *in, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/lm");
+        if (lev_mid_high < 1 || lev_mid_high > lm || lev_low_mid < 1 || lev_low_mid > lm) return fail(GEOSRAD_EINVAL, "bad super-layer levels");
+        auto na = [](int k) {
+            return k == GEOSRAD_LWU_FLXA_INT || k == GEOSRAD_LWU_FLA_INT || k == GEOSRAD_LWU_FLXAU_INT || k == GEOSRAD_LWU_FLAU_INT ||
+                   k == GEOSRAD_LWU_FLXAD_INT || k == GEOSRAD_LWU_FLAD_INT || k == GEOSRAD_LWU_DFDTSNA || k == GEOSRAD_LWU_DFDTSCNA;
+        };
+        for (int k = 0; k < GEOSRAD_LWU_NIN; k++)
+            if (!in[k] && !(rrtmg && na(k))) return fail(GEOSRAD_EINVAL, "null internal-state array");
+        LwUpd<R> U{};
+        U.ncol = ncol; U.lm = lm; U.rrtmg = rrtmg; U.lev_mid_high = lev_mid_high; U.lev_low_mid = lev_low_mid; U.undef = (R)undef;
+        auto I = [&](int k) { return (const R *)in[k]; };
+        U.tsinst = I(GEOSRAD_LWU_TSINST); U.ts_int = I(GEOSRAD_LWU_TS_INT); U.sfcem_int = I(GEOSRAD_LWU_SFCEM_INT); U.fcld = I(GEOSRAD_LWU_FCLD);
+        U.flx_int = I(GEOSRAD_LWU_FLX_INT); U.flxa_int = I(GEOSRAD_LWU_FLXA_INT); U.flc_int = I(GEOSRAD_LWU_FLC_INT); U.fla_int = I(GEOSRAD_LWU_FLA_INT);
+        U.flxu_int = I(GEOSRAD_LWU_FLXU_INT); U.flxau_int = I(GEOSRAD_LWU_FLXAU_INT); U.flcu_int = I(GEOSRAD_LWU_FLCU_INT);
+        U.flau_int = I(GEOSRAD_LWU_FLAU_INT); U.flxd_int = I(GEOSRAD_LWU_FLXD_INT); U.flxad_int = I(GEOSRAD_LWU_FLXAD_INT);
+        U.flcd_int = I(GEOSRAD_LWU_FLCD_INT); U.flad_int = I(GEOSRAD_LWU_FLAD_INT); U.dfdts = I(GEOSRAD_LWU_DFDTS);
+        U.dfdtsna = I(GEOSRAD_LWU_DFDTSNA); U.dfdtsc = I(GEOSRAD_LWU_DFDTSC); U.dfdtscna = I(GEOSRAD_LWU_DFDTSCNA);
+        static_assert(offsetof(LwUpd<R>, cldtt) - offsetof(LwUpd<R>, flx) == (GEOSRAD_LWU_NOUT - 1) * sizeof(void *), "LwUpd export layout");
+        R **o3 = &U.flx;       // the export pointers are laid out in the order of the GEOSRAD_LWU_* output enum
+        for (int k = 0; k < GEOSRAD_LWU_NOUT; k++) o3[k] = (R *)out[k];
+        hipLaunchKernelGGL((k_lw_update_flx<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, U);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int sw_update_export_dev(hipStream_t st, int ncol, int lm, int nbands, const void *const *in, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm <= 0 || nbands < 0) return fail(GEOSRAD_EINVAL, "bad ncol/lm/nbands");
+        SwUpd<R> U{};
+        U.ncol = ncol; U.lm = lm; U.nbands = nbands;
+        static_assert(offsetof(SwUpd<R>, fswbandnan) - offsetof(SwUpd<R>, slr) == (GEOSRAD_SWU_NIN - 1) * sizeof(void *), "SwUpd input layout");
+        static_assert(offsetof(SwUpd<R>, osrcna) - offsetof(SwUpd<R>, fsw) == (GEOSRAD_SWU_NOUT - 1) * sizeof(void *), "SwUpd export layout");
+        const R **ip = &U.slr;      // members in the order of the GEOSRAD_SWU_* enums
+        for (int k = 0; k < GEOSRAD_SWU_NIN; k++) ip[k] = (const R *)in[k];
+        R **op = &U.fsw;
+        for (int k = 0; k < GEOSRAD_SWU_NOUT; k++) op[k] = (R *)out[k];
+        if (!U.slr) return fail(GEOSRAD_EINVAL, "SLR is required");
+        // an export needs the internals it is computed from
+        auto need = [&](const R *o, const R *a, const R *b = (const R *)1) { return !o || (a && b); };
+        const bool ok = need(U.fsw, U.fswn) && need(U.fsc, U.fscn) && need(U.fswna, U.fswnan) && need(U.fscna, U.fscnan) &&
+                        need(U.fswu, U.fswun) && need(U.fscu, U.fscun) && need(U.fswuna, U.fswunan) && need(U.fscuna, U.fscunan) &&
+                        need(U.fswd, U.fswn, U.fswun) && need(U.fscd, U.fscn, U.fscun) && need(U.fswdna, U.fswnan, U.fswunan) &&
+                        need(U.fscdna, U.fscnan, U.fscunan) && need(U.fswband, U.fswbandn) && need(U.fswbandna, U.fswbandnan) &&
+                        need(U.rsr, U.fswn) && need(U.rsrs, U.fswn) && need(U.osr, U.fswn) && need(U.rsc, U.fscn) && need(U.rscs, U.fscn) &&
+                        need(U.osrclr, U.fscn) && need(U.rsrna, U.fswnan) && need(U.rsrsna, U.fswnan) && need(U.osrna, U.fswnan) &&
+                        need(U.rscna, U.fscnan) && need(U.rscsna, U.fscnan) && need(U.osrcna, U.fscnan);
+        if (!ok) return fail(GEOSRAD_EINVAL, "an export was requested without the internal field it is computed from");
+        hipLaunchKernelGGL((k_sw_update_export<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1 + nbands), dim3(256), 0, st, U);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int rad_tendencies_dev(hipStream_t st, int ncol, int lm, double grav, double cp, const void *const *in, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/lm");
+        RadTend<R> P{};
+        P.ncol = ncol; P.lm = lm; P.grav = (R)grav; P.cp = (R)cp;
+        static_assert(offsetof(RadTend<R>, trd) - offsetof(RadTend<R>, ple) == (GEOSRAD_RT_NIN - 1) * sizeof(void *), "RadTend input layout");
+        static_assert(offsetof(RadTend<R>, radsrf) - offsetof(RadTend<R>, dtdt) == (GEOSRAD_RT_NOUT - 1) * sizeof(void *), "RadTend export layout");
+        const R **ip = &P.ple;
+        for (int k = 0; k < GEOSRAD_RT_NIN; k++) ip[k] = (const R *)in[k];
+        R **op = &P.dtdt;
+        for (int k = 0; k < GEOSRAD_RT_NOUT; k++) op[k] = (R *)out[k];
+        auto need = [&](const R *o, const R *a, const R *b = (const R *)1, const R *c = (const R *)1) { return !o || (a && b && c); };
+        const bool any3 = P.radlw || P.radsw || P.radlwc || P.radswc || P.radswna || P.radlwcna || P.radswcna;
+        const bool ok = need(P.dtdt, P.flw, P.fsw) && (!any3 || P.ple) && need(P.radlw, P.flw) && need(P.radsw, P.fsw) &&
+                        need(P.radlwc, P.flwclr) && need(P.radswc, P.fswclr) && need(P.radswna, P.fswna) && need(P.radlwcna, P.fla) &&
+                        need(P.radswcna, P.fscna) && need(P.blw, P.dsfdts) && need(P.alw, P.sfcem, P.dsfdts, P.trd) &&
+                        need(P.radsrf, P.fsw, P.flw);
+        if (!ok) return fail(GEOSRAD_EINVAL, "an export was requested without the field it is computed from");
+        if (!P.ple) P.ple = P.flw ? P.flw : P.fsw;      // never dereferenced for a result (no 3-D rate requested), but k_rad_tendencies forms dmi
+        if (!P.ple) return fail(GEOSRAD_EINVAL, "nothing to do");
+        hipLaunchKernelGGL((k_rad_tendencies<R>), dim3((unsigned)((ncol + 255) / 256), lm), dim3(256), 0, st, P);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -1671,6 +1925,42 @@ int geosrad_rrtmg_lw_dev(geosrad_ctx *c, void *stream, int ncol, int nlay, int p
     void *out[O_NOUT] = {uflx, dflx, uflxc, dflxc, duflx_dTs, duflxc_dTs, olrb, dolrb_dTs};
     return c->lw_dev((hipStream_t)stream, ncol, nlay, dudTs, in, iceflglw, liqflglw, dyofyr, cloudLM, cloudMH, clearCounts, out,
                      band_output, nullptr, nullptr);
+}
+
+int geosrad_lw_driver_rrtmg_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nb_aer, const void *const *in, const double *consts,
+                                int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out)
+{
+    if (!c || !in || !consts || !out) return GEOSRAD_EINVAL;
+    return c->lw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflglw, liqflglw, doy, lcldlm, lcldmh, band_output, out);
+}
+
+int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nb_aer, const void *const *in, const double *consts,
+                                int iceflgsw, int liqflgsw, double sc, double dist, int isolvar, int dyofyr, int include_aerosols,
+                                int lcldlm, int lcldmh, int normflx, const void *bndsolvar, const void *indsolvar, void *const *out)
+{
+    if (!c || !in || !consts || !out) return GEOSRAD_EINVAL;
+    return c->sw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflgsw, liqflgsw, sc, dist, isolvar, dyofyr,
+                            include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, out);
+}
+
+int geosrad_lw_update_flx_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
+                              const void *const *in, void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->lw_update_flx_dev((hipStream_t)stream, ncol, lm, rrtmg, lev_mid_high, lev_low_mid, undef, in, out);
+}
+
+int geosrad_sw_update_export_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nbands, const void *const *in, void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->sw_update_export_dev((hipStream_t)stream, ncol, lm, nbands, in, out);
+}
+
+int geosrad_rad_tendencies_dev(geosrad_ctx *c, void *stream, int ncol, int lm, double grav, double cp, const void *const *in,
+                               void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->rad_tendencies_dev((hipStream_t)stream, ncol, lm, grav, cp, in, out);
 }
 
 int geosrad_profile(geosrad_ctx *c, int enable)

@@ -1,0 +1,495 @@
+// gridcomp_kernels.hpp -- the data path of the GridComp drivers either side of the RRTMG solvers,
+// as HBM-streaming kernels (gfx950):
+//   k_lwd_prep / k_lwd_zm / k_lwd_post   the RRTMG branch of LW_Driver (GEOSirrad_GridComp/GEOS_IrradGridComp.F90:3188-3372 and
+//                                        :3487-3533, :3601-3615): unit conversions, level temperatures, effective-radius limits,
+//                                        absorption aerosol optical depth, vertical flip; after the solver: flip back, sign
+//                                        conventions, SFCEM, net fluxes, super-layer cloud fractions
+//   k_swd_prep / k_swd_zm / k_swd_post   the same for SORADCORE's RRTMG branch (GEOSsolar_GridComp/GEOS_SolarGridComp.F90:6113-6219,
+//                                        :6395-6454)
+//   k_lw_update_flx                      Update_Flx (IRR:3861-3999): the heartbeat linearisation of the LW fluxes in the surface
+//                                        temperature, every model step between two full calculations
+//   k_sw_update_export                   the 3-D / TOA / surface flux part of UPDATE_EXPORT (SOL:7540-7579): normalised fluxes x SLR
+//   k_rad_tendencies                     the parent's heating rates (GEOS_RadiationGridComp.F90:798-819)
+// GEOS fields are (IM,JM,levels): column index fastest, which is the [level][column] layout of every kernel here (lane = column,
+// blockIdx.y = level): all accesses are coalesced, nothing is transposed, the vertical flip is an index calculation.
+// A null output pointer = Fortran "not associated" (export not requested).
+#pragma once
+#include "lw_device.hpp"
+
+namespace geosrad {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LW_Driver, RRTMG branch
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename R> struct LwdArgs {
+    int ncol, lm, nb;                 // columns (IM*JM), layers, aerosol bands of TAUA/SSAA (16)
+    int iceflg, liqflg;
+    // GEOS side, model ordering (k = 1 top .. LM bottom); ple has LM+1 levels (0..LM)
+    const R *ple, *pl, *t, *q, *o3, *ch4, *n2o, *co2_3d, *cfc11, *cfc12, *hcfc22, *fcld;
+    const R *cwc_liq, *cwc_ice, *reff_liq, *reff_ice;      // CWC(:,:,:,KLIQUID|KICE), REFF(...)
+    const R *taua, *ssaa;                                  // (IM,JM,LM,nb) or null
+    const R *ts, *emis, *lats, *t2m;
+    R co2_fixed, o2, ccl4, airmw_over_h2omw, airmw_over_o3mw, rgas, grav;
+    // RRTMG side, 1 = bottom layer; [K][ncol]
+    R *play, *plev, *tlay, *tlev, *tsfc, *emis_r, *h2o, *o3_r, *co2_r, *ch4_r, *n2o_r, *o2_r, *cfc11_r, *cfc12_r, *cfc22_r, *ccl4_r,
+        *cldf, *ciwp, *clwp, *rei, *rel, *tauaer, *zm, *alat;
+};
+
+// interface temperature of model level k (1..LM+1), IRR:3248-3256
+template <typename R> GR_DEV R lwd_tlev(const LwdArgs<R> &A, int k, int ij)
+{
+    const int n = A.ncol, lm = A.lm;
+    if (k == lm + 1) return A.t2m[ij];
+    if (k == 1) k = 2;
+    auto PLE = [&](int l) { return A.ple[(size_t)l * n + ij]; };
+    auto T = [&](int l) { return A.t[(size_t)(l - 1) * n + ij]; };
+    const R dpk = PLE(k) - PLE(k - 1), dpm = PLE(k - 1) - PLE(k - 2);
+    return (T(k - 1) * dpk + T(k) * dpm) / (dpm + dpk);
+}
+
+template <typename R> GR_DEV R clampr(R x, R lo, R hi) { x = x > lo ? x : lo; return x < hi ? x : hi; }      // min(max(x,lo),hi)
+
+// effective-radius limits RRTMG assumes (IRR:3272-3291, SOL:6144-6170)
+template <typename R> GR_DEV void rrtmg_reff_limits(int iceflg, int liqflg, R &reice, R &reliq)
+{
+    if (liqflg == 0) reliq = clampr<R>(reliq, (R)5.0, (R)10.0);
+    else if (liqflg == 1) reliq = clampr<R>(reliq, (R)2.5, (R)60.0);
+    if (iceflg == 0) reice = clampr<R>(reice, (R)10.0, (R)30.0);
+    else if (iceflg == 1) reice = clampr<R>(reice, (R)13.0, (R)130.0);
+    else if (iceflg == 2) reice = clampr<R>(reice, (R)5.0, (R)131.0);
+    else if (iceflg == 3) reice = clampr<R>(reice, (R)5.0, (R)140.0);
+    else if (iceflg == 4) reice = clampr<R>(reice * (R)2., (R)1.0, (R)200.0);
+}
+
+// one thread per (column, RRTMG layer K = 1..LM); blockIdx.y = K - 1, and K = LM additionally writes the top level
+template <typename R> __global__ void __launch_bounds__(256) k_lwd_prep(LwdArgs<R> A)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= A.ncol) return;
+    const int n = A.ncol, lm = A.lm, K = blockIdx.y + 1, LV = lm - K + 1;
+    const size_t o = (size_t)(K - 1) * n + ij;          // RRTMG layer K
+    const size_t g = (size_t)(LV - 1) * n + ij;         // GEOS layer LV
+    const R pleb = A.ple[(size_t)LV * n + ij], plet = A.ple[(size_t)(LV - 1) * n + ij];
+    const R dp = pleb - plet;
+    // content [kg/kg] -> path [g/m2]: 1000*dp/g ~ 1.02*100*dp (IRR:3262-3267)
+    const R xx = (R)1.02 * (R)100 * dp;
+    A.clwp[o] = xx * A.cwc_liq[g];
+    A.ciwp[o] = xx * A.cwc_ice[g];
+    R reliq = A.reff_liq[g], reice = A.reff_ice[g];
+    rrtmg_reff_limits<R>(A.iceflg, A.liqflg, reice, reliq);
+    A.rel[o] = reliq; A.rei[o] = reice;
+    // levels: PLE_R(0:LM) = PLE(LM:0)/100, TLEV_R(0:LM) = TLEV(LM+1:1) (IRR:3293-3299, :3340-3342)
+    A.plev[o] = pleb / (R)100.;
+    A.tlev[o] = lwd_tlev<R>(A, LV + 1, ij);
+    if (K == lm) {
+        A.plev[(size_t)lm * n + ij] = A.ple[ij] / (R)100.;
+        A.tlev[(size_t)lm * n + ij] = lwd_tlev<R>(A, 1, ij);
+    }
+    // layers (IRR:3301-3322) with the clean-up of negatives (IRR:3361-3371)
+    auto pos = [](R x) { return x < 0 ? (R)0 : x; };
+    A.play[o] = A.pl[g] / (R)100.;
+    A.tlay[o] = A.t[g];
+    const R q = A.q[g];
+    A.h2o[o] = pos(q / ((R)1. - q) * A.airmw_over_h2omw);
+    A.o3_r[o] = pos(A.o3[g] * A.airmw_over_o3mw);
+    A.ch4_r[o] = pos(A.ch4[g]);
+    A.n2o_r[o] = pos(A.n2o[g]);
+    A.co2_r[o] = pos(A.co2_3d ? A.co2_3d[g] : A.co2_fixed);
+    A.o2_r[o] = pos(A.o2);
+    A.ccl4_r[o] = pos(A.ccl4);
+    A.cfc11_r[o] = pos(A.cfc11[g]);
+    A.cfc12_r[o] = pos(A.cfc12[g]);
+    A.cfc22_r[o] = pos(A.hcfc22[g]);
+    A.cldf[o] = pos(A.fcld[g]);
+    // absorption aerosol optical thickness (IRR:3324-3335); tauaer is (ncol,nlay,16)
+    for (int b = 0; b < 16; b++) {
+        R v = 0;
+        if (A.taua && b < A.nb) {
+            const size_t ga = ((size_t)b * lm + (LV - 1)) * n + ij;
+            v = A.taua[ga] - A.ssaa[ga];
+            v = v > 0 ? v : (R)0;
+        }
+        A.tauaer[((size_t)b * lm + (K - 1)) * n + ij] = v;
+    }
+    if (K == 1) {
+        A.tsfc[ij] = A.ts[ij];
+        A.alat[ij] = A.lats[ij];
+        const R e = A.emis[ij];
+        for (int b = 0; b < 16; b++) A.emis_r[(size_t)b * n + ij] = e;      // all bands get the same emissivity (IRR:3244)
+    }
+}
+
+// layer mid-point heights, a running sum up the column (IRR:3344-3356): one thread per column
+template <typename R> __global__ void __launch_bounds__(256) k_lwd_zm(LwdArgs<R> A)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= A.ncol) return;
+    const int n = A.ncol, lm = A.lm;
+    R z = 0;
+    A.zm[ij] = 0;
+    R plm = A.play[ij];
+    for (int K = 2; K <= lm; K++) {
+        const R plk = A.play[(size_t)(K - 1) * n + ij];
+        // dz ~ RT/g x dp/p; the jump from LAYER K-1 to K is centred on LEVEL K-1 (0-based levels)
+        z = z + A.rgas * A.tlev[(size_t)(K - 1) * n + ij] / A.grav * (plm - plk) / A.plev[(size_t)(K - 1) * n + ij];
+        A.zm[(size_t)(K - 1) * n + ij] = z;
+        plm = plk;
+    }
+}
+
+template <typename R> struct LwdPost {
+    int ncol, lm, ngpt;
+    const R *uflx, *dflx, *uflxc, *dflxc, *duflx, *duflxc;      // RRTMG (ncol, LM+1), 1 = surface
+    const int32_t *clearCounts;                                 // (ncol,4)
+    const R *emis, *ts;
+    // GEOS internal state (IM,JM,0:LM); any may be null
+    R *flxu_int, *flxd_int, *flcu_int, *flcd_int, *dfdts, *dfdtsc, *dfdtsna, *dfdtscna, *flx_int, *flc_int;
+    R *sfcem_int, *ts_int, *cldttlw, *cldhilw, *cldmdlw, *cldlolw;
+};
+
+// one thread per (column, GEOS level K = 0..LM) (IRR:3487-3533, :3601-3615, :3560-3565)
+template <typename R> __global__ void __launch_bounds__(256) k_lwd_post(LwdPost<R> P)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const int n = P.ncol, lm = P.lm, K = blockIdx.y, LV = lm - K + 1;
+    const size_t s = (size_t)(LV - 1) * n + ij, o = (size_t)K * n + ij;
+    // upward negative in the GEOS convention
+    const R fu = -P.uflx[s], fd = P.dflx[s], cu = -P.uflxc[s], cd = P.dflxc[s], du = -P.duflx[s], dc = -P.duflxc[s];
+    if (P.flxu_int) P.flxu_int[o] = fu;
+    if (P.flxd_int) P.flxd_int[o] = fd;
+    if (P.flcu_int) P.flcu_int[o] = cu;
+    if (P.flcd_int) P.flcd_int[o] = cd;
+    if (P.dfdts) P.dfdts[o] = du;
+    if (P.dfdtsc) P.dfdtsc[o] = dc;
+    if (P.dfdtsna) P.dfdtsna[o] = du;        // RRTMG has no no-aerosol derivatives (IRR:3560-3565)
+    if (P.dfdtscna) P.dfdtscna[o] = dc;
+    if (P.flx_int) P.flx_int[o] = fd + fu;   // net downward (IRR:3601-3604)
+    if (P.flc_int) P.flc_int[o] = cd + cu;
+    if (K == lm) {
+        // surface emitted: reflected LW is not counted; first negative (Chou-Suarez convention), then reverted (IRR:3512, :3608)
+        R sf = -(P.uflx[ij] - P.dflx[ij] * ((R)1. - P.emis[ij]));
+        sf = -sf;
+        if (P.sfcem_int) P.sfcem_int[ij] = sf;
+        if (P.ts_int) P.ts_int[ij] = P.ts[ij];
+        const R ng = (R)P.ngpt;
+        if (P.cldttlw) P.cldttlw[ij] = (R)1.0 - (R)P.clearCounts[(size_t)0 * n + ij] / ng;
+        if (P.cldhilw) P.cldhilw[ij] = (R)1.0 - (R)P.clearCounts[(size_t)1 * n + ij] / ng;
+        if (P.cldmdlw) P.cldmdlw[ij] = (R)1.0 - (R)P.clearCounts[(size_t)2 * n + ij] / ng;
+        if (P.cldlolw) P.cldlolw[ij] = (R)1.0 - (R)P.clearCounts[(size_t)3 * n + ij] / ng;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Update_Flx (IRR:3796-3999)
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename R> struct LwUpd {
+    int ncol, lm, rrtmg;                 // rrtmg != 0: the no-aerosol flavours are MAPL_UNDEF (IRR:3927-3990)
+    int lev_mid_high, lev_low_mid;       // 1-based model levels separating the cloud super-layers (IRR:3811-3829)
+    R undef;
+    // internal state
+    const R *tsinst, *ts_int, *sfcem_int, *fcld;
+    const R *flx_int, *flxa_int, *flc_int, *fla_int, *flxu_int, *flxau_int, *flcu_int, *flau_int, *flxd_int, *flxad_int, *flcd_int,
+        *flad_int, *dfdts, *dfdtsna, *dfdtsc, *dfdtscna;
+    // exports, (IM,JM,0:LM)
+    R *flx, *flxa, *flc, *fla, *flxu, *flxau, *flcu, *flau, *flxd, *flxad, *flcd, *flad;
+    // exports, (IM,JM)
+    R *olr, *olra, *olc, *ola, *olcc5, *dsfdts, *sfcem, *lws, *lwsa, *lcs, *las, *lcsc5, *flns, *flnsna, *flnsc, *flnsa, *dsfdts0,
+        *sfcem0, *tsreff, *cldtt;
+};
+
+// one thread per (column, level K = 0..LM); the 2-D exports are written by the K = 0 / K = LM threads
+template <typename R> __global__ void __launch_bounds__(256) k_lw_update_flx(LwUpd<R> U)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= U.ncol) return;
+    const int n = U.ncol, lm = U.lm, K = blockIdx.y;
+    const size_t o = (size_t)K * n + ij;
+    const R delt = U.tsinst[ij] - U.ts_int[ij];      // surface temperature change since the last full calculation
+    const bool rr = U.rrtmg != 0;
+    const R d = U.dfdts[o], dc = U.dfdtsc[o];
+    const R dna = rr ? (R)0 : U.dfdtsna[o], dcna = rr ? (R)0 : U.dfdtscna[o];
+    // net downward, negated upward (linearised), downward (not linearised)
+    if (U.flx) U.flx[o] = U.flx_int[o] + d * delt;
+    if (U.flc) U.flc[o] = U.flc_int[o] + dc * delt;
+    if (U.flxu) U.flxu[o] = U.flxu_int[o] + d * delt;
+    if (U.flcu) U.flcu[o] = U.flcu_int[o] + dc * delt;
+    if (U.flxd) U.flxd[o] = U.flxd_int[o];
+    if (U.flcd) U.flcd[o] = U.flcd_int[o];
+    if (U.flxa) U.flxa[o] = rr ? U.undef : U.flxa_int[o] + dna * delt;
+    if (U.fla) U.fla[o] = rr ? U.undef : U.fla_int[o] + dcna * delt;
+    if (U.flxau) U.flxau[o] = rr ? U.undef : U.flxau_int[o] + dna * delt;
+    if (U.flau) U.flau[o] = rr ? U.undef : U.flau_int[o] + dcna * delt;
+    if (U.flxad) U.flxad[o] = rr ? U.undef : U.flxad_int[o];
+    if (U.flad) U.flad[o] = rr ? U.undef : U.flad_int[o];
+    if (K != 0 && K != lm) return;
+    // 2-D total cloud fraction, max overlap within / random between the super-layers (IRR:3831-3846)
+    R cldtt = 0;
+    const bool need_cld = U.cldtt || U.olcc5 || U.lcsc5;
+    if (need_cld) {
+        R a = 0, b = 0, c = 0;
+        for (int k = 1; k <= U.lev_mid_high - 1; k++) { const R f = U.fcld[(size_t)(k - 1) * n + ij]; a = a > f ? a : f; }
+        for (int k = U.lev_mid_high; k <= U.lev_low_mid - 1; k++) { const R f = U.fcld[(size_t)(k - 1) * n + ij]; b = b > f ? b : f; }
+        for (int k = U.lev_low_mid; k <= lm; k++) { const R f = U.fcld[(size_t)(k - 1) * n + ij]; c = c > f ? c : f; }
+        R x = ((R)1 - a);
+        x = x * ((R)1 - b);
+        cldtt = (R)1.0 - x * ((R)1 - c);
+    }
+    if (K == 0) {
+        // TOA: outgoing longwave radiation (IRR:3879-3893)
+        if (U.olr) U.olr[ij] = -(U.flx_int[o] + d * delt);
+        if (U.olc) U.olc[ij] = -(U.flc_int[o] + dc * delt);
+        if (U.olra) U.olra[ij] = rr ? U.undef : -(U.flxa_int[o] + dna * delt);
+        if (U.ola) U.ola[ij] = rr ? U.undef : -(U.fla_int[o] + dcna * delt);
+        if (U.olcc5) U.olcc5[ij] = cldtt <= (R)0.05 ? -(U.flc_int[o] + dc * delt) : U.undef;
+        if (U.cldtt) U.cldtt[ij] = cldtt;
+    }
+    if (K == lm) {
+        // surface (IRR:3895-3925, :3991-3999)
+        const R se = U.sfcem_int[ij];
+        if (U.dsfdts) U.dsfdts[ij] = -d;
+        if (U.sfcem) U.sfcem[ij] = se - d * delt;
+        if (U.lws) U.lws[ij] = U.flx_int[o] + se;
+        if (U.lcs) U.lcs[ij] = U.flc_int[o] + se;
+        if (U.lwsa) U.lwsa[ij] = rr ? U.undef : U.flxa_int[o] + se;
+        if (U.las) U.las[ij] = rr ? U.undef : U.fla_int[o] + se;
+        if (U.lcsc5) U.lcsc5[ij] = cldtt <= (R)0.05 ? U.flc_int[o] + se : U.undef;
+        if (U.flns) U.flns[ij] = U.flx_int[o] + d * delt;
+        if (U.flnsc) U.flnsc[ij] = U.flc_int[o] + dc * delt;
+        if (U.flnsna) U.flnsna[ij] = rr ? U.undef : U.flxa_int[o] + dna * delt;
+        if (U.flnsa) U.flnsa[ij] = rr ? U.undef : U.fla_int[o] + dcna * delt;
+        if (U.dsfdts0) U.dsfdts0[ij] = -d;
+        if (U.sfcem0) U.sfcem0[ij] = se - d * delt;
+        if (U.tsreff) U.tsreff[ij] = U.tsinst[ij];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SORADCORE, RRTMG branch (works on the packed daytime columns; ple has LM+1 levels 1..LM+1)
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename R> struct SwdArgs {
+    int ncol, lm, nb;                 // nb = 14 aerosol bands
+    int iceflg, liqflg;
+    const R *ple, *pl, *t, *q, *o3, *ch4, *cl, *ts;
+    const R *qq_ice, *qq_liq, *rr_ice, *rr_liq;      // QQ3(:,:,1|2), RR3(:,:,1|2)
+    R *taua, *ssaa, *asya;                           // (ncol,LM,nb) GEOS side: normalised IN PLACE like the reference (SOL:6116-6125)
+    R co2, o2, airmw_over_h2omw, airmw_over_o3mw, rgas, grav;
+    R *play, *plev, *tlay, *tlev, *h2o, *o3_r, *co2_r, *ch4_r, *o2_r, *cldf, *ciwp, *clwp, *rei, *rel, *zl, *tauaer, *ssaaer, *asmaer;
+};
+
+template <typename R> GR_DEV R swd_tlev(const SwdArgs<R> &A, int k, int ij)      // TLEV(1..LM+1), SOL:6172-6176
+{
+    const int n = A.ncol, lm = A.lm;
+    if (k == lm + 1) return A.ts[ij];
+    if (k == 1) k = 2;
+    auto PLE = [&](int l) { return A.ple[(size_t)(l - 1) * n + ij]; };
+    auto T = [&](int l) { return A.t[(size_t)(l - 1) * n + ij]; };
+    const R dpk = PLE(k + 1) - PLE(k), dpm = PLE(k) - PLE(k - 1);        // DPR(k), DPR(k-1)
+    return (T(k - 1) * dpk + T(k) * dpm) / (dpm + dpk);
+}
+
+template <typename R> __global__ void __launch_bounds__(256) k_swd_prep(SwdArgs<R> A)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= A.ncol) return;
+    const int n = A.ncol, lm = A.lm, K = blockIdx.y + 1, LV = lm - K + 1;
+    const size_t o = (size_t)(K - 1) * n + ij, g = (size_t)(LV - 1) * n + ij;
+    const R dpr = A.ple[(size_t)LV * n + ij] - A.ple[(size_t)(LV - 1) * n + ij];      // DPR(LV) = PLE(LV+1) - PLE(LV)
+    const R xx = (R)1.02 * (R)100 * dpr;
+    A.ciwp[o] = xx * A.qq_ice[g];
+    A.clwp[o] = xx * A.qq_liq[g];
+    R reice = A.rr_ice[g], reliq = A.rr_liq[g];
+    // SW limits (SOL:6144-6170): liqflg 0 is 10..30 here
+    if (A.liqflg == 0) reliq = clampr<R>(reliq, (R)10., (R)30.);
+    else if (A.liqflg == 1) reliq = clampr<R>(reliq, (R)2.5, (R)60.);
+    if (A.iceflg == 0) reice = clampr<R>(reice, (R)10., (R)30.);
+    else if (A.iceflg == 1) reice = clampr<R>(reice, (R)13., (R)130.);
+    else if (A.iceflg == 2) reice = clampr<R>(reice, (R)5., (R)131.);
+    else if (A.iceflg == 3) reice = clampr<R>(reice, (R)5., (R)140.);
+    else if (A.iceflg == 4) reice = clampr<R>(reice * (R)2., (R)1., (R)200.);
+    A.rei[o] = reice; A.rel[o] = reliq;
+    // PLE_R(1:LM+1) = PLE(LM+1:1)/100, TLEV_R likewise (SOL:6180-6181)
+    A.plev[o] = A.ple[(size_t)LV * n + ij] / (R)100.;      // PLE(LV+1)
+    A.tlev[o] = swd_tlev<R>(A, LV + 1, ij);
+    if (K == lm) {
+        A.plev[(size_t)lm * n + ij] = A.ple[ij] / (R)100.;
+        A.tlev[(size_t)lm * n + ij] = swd_tlev<R>(A, 1, ij);
+    }
+    auto pos = [](R x) { return x < 0 ? (R)0 : x; };
+    A.play[o] = A.pl[g] / (R)100.;
+    A.tlay[o] = A.t[g];
+    const R q = A.q[g];
+    A.h2o[o] = pos(q / ((R)1. - q) * A.airmw_over_h2omw);
+    A.o3_r[o] = pos(A.o3[g] * A.airmw_over_o3mw);
+    A.ch4_r[o] = pos(A.ch4[g]);
+    A.co2_r[o] = pos(A.co2);
+    A.o2_r[o] = pos(A.o2);
+    A.cldf[o] = pos(A.cl[g]);
+    // aerosols: normalise (SOL:6116-6125) and flip (SOL:6210-6212)
+    for (int b = 0; b < A.nb; b++) {
+        R ta = 0, ss = 0, as = 0;
+        if (A.taua) {
+            const size_t ga = ((size_t)b * lm + (LV - 1)) * n + ij;
+            ta = A.taua[ga]; ss = A.ssaa[ga]; as = A.asya[ga];
+            if (ta > 0 && ss > 0) { as = as / ss; ss = ss / ta; }
+            else { ta = 0; ss = 0; as = 0; }
+            A.taua[ga] = ta; A.ssaa[ga] = ss; A.asya[ga] = as;
+        }
+        const size_t oa = ((size_t)b * lm + (K - 1)) * n + ij;
+        A.tauaer[oa] = ta; A.ssaaer[oa] = ss; A.asmaer[oa] = as;
+    }
+}
+
+// ZL_R (SOL:6200-6207): note the level index differs from LW (levels are 1-based here)
+template <typename R> __global__ void __launch_bounds__(256) k_swd_zm(SwdArgs<R> A)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= A.ncol) return;
+    const int n = A.ncol, lm = A.lm;
+    R z = 0;
+    A.zl[ij] = 0;
+    R plm = A.play[ij];
+    for (int k = 2; k <= lm; k++) {
+        const R plk = A.play[(size_t)(k - 1) * n + ij];
+        z = z + A.rgas * A.tlev[(size_t)(k - 1) * n + ij] / A.grav * (plm - plk) / A.plev[(size_t)(k - 1) * n + ij];
+        A.zl[(size_t)(k - 1) * n + ij] = z;
+        plm = plk;
+    }
+}
+
+template <typename R> struct SwdPost {
+    int ncol, lm, ngpt, aerosols;
+    R undef;
+    const R *swuflx, *swdflx, *swuflxc, *swdflxc;          // RRTMG (ncol, LM+1), 1 = surface
+    const int32_t *clearCounts;
+    const R *cotn[4], *cotd[4];                            // COTN?P / COTD?P: T, H, M, L
+    R *fsw, *fsc, *fswu, *fscu;                            // (ncol, LM+1) model ordering
+    R *cldts, *cldhs, *cldms, *cldls, *cot[4];
+};
+
+template <typename R> __global__ void __launch_bounds__(256) k_swd_post(SwdPost<R> P)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const int n = P.ncol, lm = P.lm, L = blockIdx.y;      // model level index 0..LM of the un-flipped arrays
+    const size_t s = (size_t)(lm - L) * n + ij, o = (size_t)L * n + ij;
+    const R u = P.swuflx[s], d = P.swdflx[s], uc = P.swuflxc[s], dcl = P.swdflxc[s];
+    if (P.fsw) P.fsw[o] = d - u;                          // SOL:6447-6450
+    if (P.fsc) P.fsc[o] = dcl - uc;
+    if (P.fswu) P.fswu[o] = u;
+    if (P.fscu) P.fscu[o] = uc;
+    if (L == 0) {
+        const R ng = (R)P.ngpt;
+        if (P.aerosols) {                                  // SOL:6405-6410
+            if (P.cldts) P.cldts[ij] = (R)1. - (R)P.clearCounts[(size_t)0 * n + ij] / ng;
+            if (P.cldhs) P.cldhs[ij] = (R)1. - (R)P.clearCounts[(size_t)1 * n + ij] / ng;
+            if (P.cldms) P.cldms[ij] = (R)1. - (R)P.clearCounts[(size_t)2 * n + ij] / ng;
+            if (P.cldls) P.cldls[ij] = (R)1. - (R)P.clearCounts[(size_t)3 * n + ij] / ng;
+        }
+        for (int k = 0; k < 4; k++)                        // SOL:6416-6438
+            if (P.cot[k]) {
+                const R a = P.cotn[k][ij], b = P.cotd[k][ij];
+                P.cot[k][ij] = (a > 0 && b > 0) ? a / b : P.undef;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// UPDATE_EXPORT, flux part (SOL:7540-7579): exports = normalised internals x SLR
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename R> struct SwUpd {
+    int ncol, lm, nbands;
+    const R *slr;
+    const R *fswn, *fscn, *fswnan, *fscnan, *fswun, *fscun, *fswunan, *fscunan;      // (IM,JM,0:LM)
+    const R *fswbandn, *fswbandnan;                                                  // (IM,JM,nbands)
+    R *fsw, *fsc, *fswna, *fscna, *fswu, *fscu, *fswuna, *fscuna, *fswd, *fscd, *fswdna, *fscdna;
+    R *fswband, *fswbandna;
+    R *rsr, *rsc, *rsrna, *rscna, *rsrs, *rscs, *rsrsna, *rscsna, *osr, *osrclr, *osrna, *osrcna;
+};
+
+// blockIdx.y = level 0..LM, then the bands
+template <typename R> __global__ void __launch_bounds__(256) k_sw_update_export(SwUpd<R> U)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= U.ncol) return;
+    const int n = U.ncol, lm = U.lm;
+    const R slr = U.slr[ij];
+    if ((int)blockIdx.y > lm) {
+        const size_t o = (size_t)(blockIdx.y - lm - 1) * n + ij;
+        if (U.fswband) U.fswband[o] = U.fswbandn[o] * slr;
+        if (U.fswbandna) U.fswbandna[o] = U.fswbandnan[o] * slr;
+        return;
+    }
+    const int L = blockIdx.y;
+    const size_t o = (size_t)L * n + ij;
+    const bool edge = L == 0 || L == lm;
+    R w = 0, c = 0, wna = 0, cna = 0;
+    if (U.fsw || U.fswd || (edge && (U.rsr || U.rsrs || U.osr))) w = U.fswn[o];
+    if (U.fsc || U.fscd || (edge && (U.rsc || U.rscs || U.osrclr))) c = U.fscn[o];
+    if (U.fswna || U.fswdna || (edge && (U.rsrna || U.rsrsna || U.osrna))) wna = U.fswnan[o];
+    if (U.fscna || U.fscdna || (edge && (U.rscna || U.rscsna || U.osrcna))) cna = U.fscnan[o];
+    if (U.fsw) U.fsw[o] = w * slr;
+    if (U.fsc) U.fsc[o] = c * slr;
+    if (U.fswna) U.fswna[o] = wna * slr;
+    if (U.fscna) U.fscna[o] = cna * slr;
+    if (U.fswu) U.fswu[o] = U.fswun[o] * slr;
+    if (U.fscu) U.fscu[o] = U.fscun[o] * slr;
+    if (U.fswuna) U.fswuna[o] = U.fswunan[o] * slr;
+    if (U.fscuna) U.fscuna[o] = U.fscunan[o] * slr;
+    if (U.fswd) U.fswd[o] = (w + U.fswun[o]) * slr;
+    if (U.fscd) U.fscd[o] = (c + U.fscun[o]) * slr;
+    if (U.fswdna) U.fswdna[o] = (wna + U.fswunan[o]) * slr;
+    if (U.fscdna) U.fscdna[o] = (cna + U.fscunan[o]) * slr;
+    if (L == 0) {
+        if (U.rsr) U.rsr[ij] = w * slr;
+        if (U.rsc) U.rsc[ij] = c * slr;
+        if (U.rsrna) U.rsrna[ij] = wna * slr;
+        if (U.rscna) U.rscna[ij] = cna * slr;
+        if (U.osr) U.osr[ij] = ((R)1. - w) * slr;
+        if (U.osrclr) U.osrclr[ij] = ((R)1. - c) * slr;
+        if (U.osrna) U.osrna[ij] = ((R)1. - wna) * slr;
+        if (U.osrcna) U.osrcna[ij] = ((R)1. - cna) * slr;
+    }
+    if (L == lm) {
+        if (U.rsrs) U.rsrs[ij] = w * slr;
+        if (U.rscs) U.rscs[ij] = c * slr;
+        if (U.rsrsna) U.rsrsna[ij] = wna * slr;
+        if (U.rscsna) U.rscsna[ij] = cna * slr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// parent RUN: heating rates from the net fluxes (GEOS_RadiationGridComp.F90:798-819)
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename R> struct RadTend {
+    int ncol, lm;
+    R grav, cp;
+    const R *ple, *flw, *fsw, *flwclr, *fswclr, *fswna, *fla, *fscna;      // (IM,JM,0:LM); any flux may be null with its export
+    const R *dsfdts, *sfcem, *trd;
+    R *dtdt, *radlw, *radsw, *radlwc, *radswc, *radswna, *radlwcna, *radswcna;      // (IM,JM,LM)
+    R *blw, *alw, *radsrf;
+};
+
+template <typename R> __global__ void __launch_bounds__(256) k_rad_tendencies(RadTend<R> P)
+{
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const int n = P.ncol, lm = P.lm, k = blockIdx.y;      // layer k+1 lies between levels k and k+1
+    const size_t t = (size_t)k * n + ij, b = (size_t)(k + 1) * n + ij;
+    if (P.dtdt) P.dtdt[t] = ((P.flw[t] - P.flw[b]) + (P.fsw[t] - P.fsw[b])) * (P.grav / P.cp);
+    const R dmi = P.grav / (P.cp * (P.ple[b] - P.ple[t]));
+    if (P.radlw) P.radlw[t] = (P.flw[t] - P.flw[b]) * dmi;
+    if (P.radsw) P.radsw[t] = (P.fsw[t] - P.fsw[b]) * dmi;
+    if (P.radlwc) P.radlwc[t] = (P.flwclr[t] - P.flwclr[b]) * dmi;
+    if (P.radswc) P.radswc[t] = (P.fswclr[t] - P.fswclr[b]) * dmi;
+    if (P.radswna) P.radswna[t] = (P.fswna[t] - P.fswna[b]) * dmi;
+    if (P.radlwcna) P.radlwcna[t] = (P.fla[t] - P.fla[b]) * dmi;
+    if (P.radswcna) P.radswcna[t] = (P.fscna[t] - P.fscna[b]) * dmi;
+    if (k == lm - 1) {
+        if (P.blw) P.blw[ij] = P.dsfdts[ij];
+        if (P.alw) P.alw[ij] = P.sfcem[ij] - P.dsfdts[ij] * P.trd[ij];
+        if (P.radsrf) P.radsrf[ij] = P.fsw[b] + P.flw[b];
+    }
+}
+
+}  // namespace geosrad

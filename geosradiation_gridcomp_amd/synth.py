@@ -237,3 +237,59 @@ def chou_sw_inputs(inp, aerosol=False):
     else:
         out["taua"] = np.zeros((8, nlay, m), dtype=f32); out["ssaa"] = np.zeros_like(out["taua"]); out["asya"] = np.zeros_like(out["taua"])
     return out
+
+
+def geos_lw_fields(inp):
+    """GEOS-side (model ordering, 1 = top, SI units) fields of gridcomp.LWD_IN that lead LW_Driver's prep
+    (GEOS_IrradGridComp.F90:3243-3371) back to (nearly) the RRTMG-side columns `inp` of make_columns; plus the model-ordering
+    super-layer interface indices.  float64 numpy; [k][ij]."""
+    from . import gridcomp as G
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    flip = lambda a: f64(a)[::-1].copy()
+    lm = inp["play"].shape[0]
+    f = {}
+    f["PLE"] = flip(inp["plev"]) * 100.0
+    f["PL"] = flip(inp["play"]) * 100.0
+    f["T"] = flip(inp["tlay"])
+    x = flip(inp["h2ovmr"]) * (G.MAPL["H2OMW"] / G.MAPL["AIRMW"])
+    f["Q"] = x / (1.0 + x)
+    f["O3"] = flip(inp["o3vmr"]) * (G.MAPL["O3MW"] / G.MAPL["AIRMW"])
+    f["CH4"] = flip(inp["ch4vmr"]); f["N2O"] = flip(inp["n2ovmr"]); f["CO2_3D"] = None
+    f["CFC11"] = flip(inp["cfc11vmr"]); f["CFC12"] = flip(inp["cfc12vmr"]); f["HCFC22"] = flip(inp["cfc22vmr"])
+    f["FCLD"] = flip(inp["cldf"])
+    dp = f["PLE"][1:] - f["PLE"][:-1]
+    f["CWC_LIQ"] = flip(inp["clwp"]) / (1.02 * 100 * dp)
+    f["CWC_ICE"] = flip(inp["ciwp"]) / (1.02 * 100 * dp)
+    f["REFF_LIQ"] = flip(inp["rel"]); f["REFF_ICE"] = flip(inp["rei"])
+    ta = f64(inp["tauaer"])[:, ::-1, :]
+    f["TAUA"] = 10.0 * ta; f["SSAA"] = 9.0 * ta            # extinction and scattering: absorption = TAUA - SSAA = tauaer
+    f["TS"] = f64(inp["tsfc"]); f["EMIS"] = f64(inp["emis"])[0]; f["LATS"] = f64(inp["alat"]); f["T2M"] = f64(inp["tlev"])[0]
+    # RRTMG's cloudLM = LM - LCLDLM + 1 (IRR:3238-3239)
+    f["LCLDLM"] = lm - int(inp["cloudLM"]) + 1; f["LCLDMH"] = lm - int(inp["cloudMH"]) + 1
+    return f
+
+
+def geos_sw_fields(inp):
+    """same for SORADCORE's RRTMG branch (GEOS_SolarGridComp.F90:6113-6219): gridcomp.SWD_IN on packed daytime columns, aerosol
+    triplet in the un-normalised (tau, tau*ssa, tau*ssa*g) form the aerosol bundle delivers."""
+    from . import gridcomp as G
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    flip = lambda a: f64(a)[::-1].copy()
+    lm = inp["play"].shape[0]
+    f = {}
+    f["PLE"] = flip(inp["plev"]) * 100.0
+    f["PL"] = flip(inp["play"]) * 100.0
+    f["T"] = flip(inp["tlay"])
+    x = flip(inp["h2ovmr"]) * (G.MAPL["H2OMW"] / G.MAPL["AIRMW"])
+    f["Q"] = x / (1.0 + x)
+    f["O3"] = flip(inp["o3vmr"]) * (G.MAPL["O3MW"] / G.MAPL["AIRMW"])
+    f["CH4"] = flip(inp["ch4vmr"]); f["CL"] = flip(inp["cldf"]); f["TS"] = f64(inp["tsfc"])
+    dp = f["PLE"][1:] - f["PLE"][:-1]
+    f["QQ_ICE"] = flip(inp["ciwp"]) / (1.02 * 100 * dp); f["QQ_LIQ"] = flip(inp["clwp"]) / (1.02 * 100 * dp)
+    f["RR_ICE"] = flip(inp["rei"]); f["RR_LIQ"] = flip(inp["rel"])
+    ta = f64(inp["tauaer_sw"])[:, ::-1, :]; ss = f64(inp["ssaaer_sw"])[:, ::-1, :]; g = f64(inp["asmaer_sw"])[:, ::-1, :]
+    f["TAUA"] = ta.copy(); f["SSAA"] = ta * ss; f["ASYA"] = ta * ss * g
+    f["ZT"] = f64(inp["coszen"]); f["ALAT"] = f64(inp["alat"])
+    f["ALBVR"] = f64(inp["asdir"]); f["ALBVF"] = f64(inp["asdif"]); f["ALBNR"] = f64(inp["aldir"]); f["ALBNF"] = f64(inp["aldif"])
+    f["LCLDLM"] = lm - int(inp["cloudLM"]) + 1; f["LCLDMH"] = lm - int(inp["cloudMH"]) + 1
+    return f

@@ -255,6 +255,82 @@ int geosrad_mcica_dev(geosrad_ctx *ctx, void *stream, int ncol, int nsubcol, int
 int geosrad_clearcounts(geosrad_ctx *ctx, int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH,
                         const int32_t *cldy_stoch, int32_t *clearCnts);
 
+/* ---- GridComp data path either side of the solvers -------------------------------------
+ * All arrays are DEVICE pointers of the context's real kind in the GEOS layout (IM*JM columns fastest, then the level /
+ * layer index in MODEL ordering, 1 = top), asynchronous on `stream`.  A NULL output = Fortran "not associated" (export
+ * not requested).  MAPL's physical constants are not defined in the reference repository: the caller passes them.
+ *
+ * geosrad_lw_driver_rrtmg_dev: the RRTMG branch of LW_Driver (GEOS_IrradGridComp.F90:3188-3372 prep / flip, :3470-3477 the
+ * rrtmg_lw call with Ts_derivs = .true., :3487-3533 + :3560-3565 + :3601-3615 un-flip, sign conventions, SFCEM, net fluxes).
+ * lcldlm / lcldmh are the MODEL-ordering super-layer interface indices (the routine flips them like IRR:3237-3239). */
+enum { GEOSRAD_LWD_PLE /*(ncol,0:LM) Pa*/, GEOSRAD_LWD_PL /*(ncol,LM) Pa*/, GEOSRAD_LWD_T, GEOSRAD_LWD_Q, GEOSRAD_LWD_O3,
+       GEOSRAD_LWD_CH4, GEOSRAD_LWD_N2O, GEOSRAD_LWD_CO2_3D /*nullable: CO2_FIXED is used*/, GEOSRAD_LWD_CFC11, GEOSRAD_LWD_CFC12,
+       GEOSRAD_LWD_HCFC22, GEOSRAD_LWD_FCLD, GEOSRAD_LWD_CWC_LIQ, GEOSRAD_LWD_CWC_ICE, GEOSRAD_LWD_REFF_LIQ, GEOSRAD_LWD_REFF_ICE,
+       GEOSRAD_LWD_TAUA /*(ncol,LM,nb) nullable*/, GEOSRAD_LWD_SSAA, GEOSRAD_LWD_TS /*(ncol)*/, GEOSRAD_LWD_EMIS, GEOSRAD_LWD_LATS,
+       GEOSRAD_LWD_T2M, GEOSRAD_LWD_NIN };
+enum { GEOSRAD_LWD_C_CO2_FIXED, GEOSRAD_LWD_C_O2, GEOSRAD_LWD_C_CCL4, GEOSRAD_C_AIRMW, GEOSRAD_C_H2OMW, GEOSRAD_C_O3MW,
+       GEOSRAD_C_RGAS, GEOSRAD_C_GRAV, GEOSRAD_LWD_NCONST };
+enum { GEOSRAD_LWD_FLXU_INT /*(ncol,0:LM)*/, GEOSRAD_LWD_FLXD_INT, GEOSRAD_LWD_FLCU_INT, GEOSRAD_LWD_FLCD_INT, GEOSRAD_LWD_DFDTS,
+       GEOSRAD_LWD_DFDTSC, GEOSRAD_LWD_DFDTSNA, GEOSRAD_LWD_DFDTSCNA, GEOSRAD_LWD_FLX_INT, GEOSRAD_LWD_FLC_INT,
+       GEOSRAD_LWD_SFCEM_INT /*(ncol), positive*/, GEOSRAD_LWD_TS_INT, GEOSRAD_LWD_CLDTTLW, GEOSRAD_LWD_CLDHILW, GEOSRAD_LWD_CLDMDLW,
+       GEOSRAD_LWD_CLDLOLW, GEOSRAD_LWD_OLRB /*(16,ncol)*/, GEOSRAD_LWD_DOLRB, GEOSRAD_LWD_NOUT };
+int geosrad_lw_driver_rrtmg_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nb_aer, const void *const *in,
+                                const double *consts, int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh,
+                                const int32_t *band_output, void *const *out);
+
+/* geosrad_sw_driver_rrtmg_dev: the RRTMG branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:6113-6219
+ * prep / flip incl. the in-place aerosol normalisation, :6330-6388 the rrtmg_sw call, :6395-6450 un-flip, cloud fractions,
+ * in-cloud optical thickness, net fluxes).  ple is (ncol,LM+1).  solvar = {bndscl[14], indsolvar[2]} host pointers or NULL. */
+enum { GEOSRAD_SWD_PLE, GEOSRAD_SWD_PL, GEOSRAD_SWD_T, GEOSRAD_SWD_Q, GEOSRAD_SWD_O3, GEOSRAD_SWD_CH4, GEOSRAD_SWD_CL,
+       GEOSRAD_SWD_TS, GEOSRAD_SWD_QQ_ICE, GEOSRAD_SWD_QQ_LIQ, GEOSRAD_SWD_RR_ICE, GEOSRAD_SWD_RR_LIQ,
+       GEOSRAD_SWD_TAUA /*(ncol,LM,nb) in/out, nullable*/, GEOSRAD_SWD_SSAA, GEOSRAD_SWD_ASYA, GEOSRAD_SWD_ZT /*cos zenith*/,
+       GEOSRAD_SWD_ALAT, GEOSRAD_SWD_ALBVR, GEOSRAD_SWD_ALBVF, GEOSRAD_SWD_ALBNR, GEOSRAD_SWD_ALBNF, GEOSRAD_SWD_NIN };
+enum { GEOSRAD_SWD_C_CO2, GEOSRAD_SWD_C_O2, GEOSRAD_SWD_C_AIRMW, GEOSRAD_SWD_C_H2OMW, GEOSRAD_SWD_C_O3MW, GEOSRAD_SWD_C_RGAS,
+       GEOSRAD_SWD_C_GRAV, GEOSRAD_SWD_C_UNDEF, GEOSRAD_SWD_NCONST };
+enum { GEOSRAD_SWD_FSW /*(ncol,LM+1) model ordering*/, GEOSRAD_SWD_FSC, GEOSRAD_SWD_FSWU, GEOSRAD_SWD_FSCU, GEOSRAD_SWD_NIRR,
+       GEOSRAD_SWD_NIRF, GEOSRAD_SWD_PARR, GEOSRAD_SWD_PARF, GEOSRAD_SWD_UVRR, GEOSRAD_SWD_UVRF, GEOSRAD_SWD_FSWBAND /*(ncol,14)*/,
+       GEOSRAD_SWD_CLDTS, GEOSRAD_SWD_CLDHS, GEOSRAD_SWD_CLDMS, GEOSRAD_SWD_CLDLS, GEOSRAD_SWD_COTTP, GEOSRAD_SWD_COTHP,
+       GEOSRAD_SWD_COTMP, GEOSRAD_SWD_COTLP, GEOSRAD_SWD_NOUT };
+int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nb_aer, const void *const *in,
+                                const double *consts, int iceflgsw, int liqflgsw, double sc, double dist, int isolvar, int dyofyr,
+                                int include_aerosols, int lcldlm, int lcldmh, int normflx, const void *bndsolvar,
+                                const void *indsolvar, void *const *out);
+
+/* geosrad_lw_update_flx_dev: Update_Flx (GEOS_IrradGridComp.F90:3796-3999), the per-model-step linearisation of the LW fluxes in
+ * the surface temperature.  rrtmg != 0: the no-aerosol flavours are `undef` and their internals may be NULL (IRR:3927-3990).
+ * lev_mid_high / lev_low_mid: the model levels found from PREF (IRR:3811-3829). */
+enum { GEOSRAD_LWU_TSINST, GEOSRAD_LWU_TS_INT, GEOSRAD_LWU_SFCEM_INT, GEOSRAD_LWU_FCLD, GEOSRAD_LWU_FLX_INT, GEOSRAD_LWU_FLXA_INT,
+       GEOSRAD_LWU_FLC_INT, GEOSRAD_LWU_FLA_INT, GEOSRAD_LWU_FLXU_INT, GEOSRAD_LWU_FLXAU_INT, GEOSRAD_LWU_FLCU_INT,
+       GEOSRAD_LWU_FLAU_INT, GEOSRAD_LWU_FLXD_INT, GEOSRAD_LWU_FLXAD_INT, GEOSRAD_LWU_FLCD_INT, GEOSRAD_LWU_FLAD_INT,
+       GEOSRAD_LWU_DFDTS, GEOSRAD_LWU_DFDTSNA, GEOSRAD_LWU_DFDTSC, GEOSRAD_LWU_DFDTSCNA, GEOSRAD_LWU_NIN };
+enum { GEOSRAD_LWU_FLX, GEOSRAD_LWU_FLXA, GEOSRAD_LWU_FLC, GEOSRAD_LWU_FLA, GEOSRAD_LWU_FLXU, GEOSRAD_LWU_FLXAU, GEOSRAD_LWU_FLCU,
+       GEOSRAD_LWU_FLAU, GEOSRAD_LWU_FLXD, GEOSRAD_LWU_FLXAD, GEOSRAD_LWU_FLCD, GEOSRAD_LWU_FLAD, GEOSRAD_LWU_OLR, GEOSRAD_LWU_OLRA,
+       GEOSRAD_LWU_OLC, GEOSRAD_LWU_OLA, GEOSRAD_LWU_OLCC5, GEOSRAD_LWU_DSFDTS, GEOSRAD_LWU_SFCEM, GEOSRAD_LWU_LWS, GEOSRAD_LWU_LWSA,
+       GEOSRAD_LWU_LCS, GEOSRAD_LWU_LAS, GEOSRAD_LWU_LCSC5, GEOSRAD_LWU_FLNS, GEOSRAD_LWU_FLNSNA, GEOSRAD_LWU_FLNSC, GEOSRAD_LWU_FLNSA,
+       GEOSRAD_LWU_DSFDTS0, GEOSRAD_LWU_SFCEM0, GEOSRAD_LWU_TSREFF, GEOSRAD_LWU_CLDTT, GEOSRAD_LWU_NOUT };
+int geosrad_lw_update_flx_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid,
+                              double undef, const void *const *in, void *const *out);
+
+/* geosrad_sw_update_export_dev: the flux part of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7540-7579): exports = normalised
+ * internals x SLR (3-D net / up / down, per-band, TOA and surface). */
+enum { GEOSRAD_SWU_SLR, GEOSRAD_SWU_FSWN, GEOSRAD_SWU_FSCN, GEOSRAD_SWU_FSWNAN, GEOSRAD_SWU_FSCNAN, GEOSRAD_SWU_FSWUN,
+       GEOSRAD_SWU_FSCUN, GEOSRAD_SWU_FSWUNAN, GEOSRAD_SWU_FSCUNAN, GEOSRAD_SWU_FSWBANDN, GEOSRAD_SWU_FSWBANDNAN, GEOSRAD_SWU_NIN };
+enum { GEOSRAD_SWU_FSW, GEOSRAD_SWU_FSC, GEOSRAD_SWU_FSWNA, GEOSRAD_SWU_FSCNA, GEOSRAD_SWU_FSWU, GEOSRAD_SWU_FSCU, GEOSRAD_SWU_FSWUNA,
+       GEOSRAD_SWU_FSCUNA, GEOSRAD_SWU_FSWD, GEOSRAD_SWU_FSCD, GEOSRAD_SWU_FSWDNA, GEOSRAD_SWU_FSCDNA, GEOSRAD_SWU_FSWBAND,
+       GEOSRAD_SWU_FSWBANDNA, GEOSRAD_SWU_RSR, GEOSRAD_SWU_RSC, GEOSRAD_SWU_RSRNA, GEOSRAD_SWU_RSCNA, GEOSRAD_SWU_RSRS, GEOSRAD_SWU_RSCS,
+       GEOSRAD_SWU_RSRSNA, GEOSRAD_SWU_RSCSNA, GEOSRAD_SWU_OSR, GEOSRAD_SWU_OSRCLR, GEOSRAD_SWU_OSRNA, GEOSRAD_SWU_OSRCNA,
+       GEOSRAD_SWU_NOUT };
+int geosrad_sw_update_export_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nbands, const void *const *in,
+                                 void *const *out);
+
+/* geosrad_rad_tendencies_dev: the parent's heating rates (GEOS_RadiationGridComp.F90:798-819). */
+enum { GEOSRAD_RT_PLE, GEOSRAD_RT_FLW, GEOSRAD_RT_FSW, GEOSRAD_RT_FLWCLR, GEOSRAD_RT_FSWCLR, GEOSRAD_RT_FSWNA, GEOSRAD_RT_FLA,
+       GEOSRAD_RT_FSCNA, GEOSRAD_RT_DSFDTS, GEOSRAD_RT_SFCEM, GEOSRAD_RT_TRD, GEOSRAD_RT_NIN };
+enum { GEOSRAD_RT_DTDT, GEOSRAD_RT_RADLW, GEOSRAD_RT_RADSW, GEOSRAD_RT_RADLWC, GEOSRAD_RT_RADSWC, GEOSRAD_RT_RADSWNA,
+       GEOSRAD_RT_RADLWCNA, GEOSRAD_RT_RADSWCNA, GEOSRAD_RT_BLW, GEOSRAD_RT_ALW, GEOSRAD_RT_RADSRF, GEOSRAD_RT_NOUT };
+int geosrad_rad_tendencies_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, double grav, double cp, const void *const *in,
+                               void *const *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,3 +310,119 @@ def sorad(cs, prec="f32", do_drfband=True):
         _p(out["flx_sfc_band"]), ci(1 if do_drfband else 0), _p(out["drband"]), _p(out["dfband"]))
     out["rc"] = rc
     return out
+
+
+# ---- GridComp data path either side of the solvers (gridcomp_oracle_impl.h; PARITY UNPINNED, see its header) -------------------
+LWD_RR = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr",
+          "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel", "tauaer", "zm", "alat"]
+SWD_RR = ["play", "plev", "tlay", "tlev", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm",
+          "tauaer_sw", "ssaaer_sw", "asmaer_sw"]
+
+
+def _parr(arrays):
+    """(ctypes array of pointers, keep-alive list); None entries -> NULL"""
+    arr = (ctypes.c_void_p * len(arrays))()
+    for i, a in enumerate(arrays):
+        arr[i] = None if a is None else a.ctypes.data
+    return arr
+
+
+def lwd_prep(f, consts, iceflg=3, liqflg=1, prec="f32"):
+    """RRTMG branch of LW_Driver, prep / flip (IRR:3188-3372).  `f`: GEOS-side fields by gridcomp.LWD_IN name, numpy [k][ij]."""
+    from geosradiation_gridcomp_amd import gridcomp as G
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    lm, ncol = f["T"].shape
+    nb = 0 if f.get("TAUA") is None else f["TAUA"].shape[0]
+    ins = [None if f.get(k) is None else _c(f[k], dt) for k in G.LWD_IN]
+    shp = {"plev": (lm + 1, ncol), "tlev": (lm + 1, ncol), "tsfc": (ncol,), "alat": (ncol,), "emis": (16, ncol), "tauaer": (16, lm, ncol)}
+    out = {k: np.zeros(shp.get(k, (lm, ncol)), dtype=dt) for k in LWD_RR}
+    cs = (ctypes.c_double * len(consts))(*consts)
+    getattr(L, f"oracle_lwd_prep_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), ctypes.c_int(nb), _parr(ins), cs, ctypes.c_int(iceflg),
+                                         ctypes.c_int(liqflg), _parr([out[k] for k in LWD_RR]))
+    return out
+
+
+def lwd_post(flux, clearCounts, emis, ts, prec="f32", want=None):
+    """un-flip, sign conventions, SFCEM, net fluxes, cloud fractions (IRR:3487-3615).  flux: uflx dflx uflxc dflxc duflx_dTs duflxc_dTs"""
+    from geosradiation_gridcomp_amd import gridcomp as G
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    n1, ncol = flux["uflx"].shape
+    lm = n1 - 1
+    fl = [_c(flux[k], dt) for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs")]
+    names = G.LWD_OUT[:16]
+    want = names if want is None else want
+    out = {k: np.zeros((n1, ncol) if k in G.LWD_OUT_3D else (ncol,), dtype=dt) for k in names if k in want}
+    cc = np.ascontiguousarray(clearCounts, dtype=np.int32)
+    getattr(L, f"oracle_lwd_post_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), ctypes.c_int(140), _parr(fl), _p(cc), _p(_c(emis, dt)),
+                                         _p(_c(ts, dt)), _parr([out.get(k) for k in names]))
+    return out
+
+
+def lw_update_flx(st, lm, rrtmg, lev_mid_high, lev_low_mid, undef, prec="f32", want=None):
+    """Update_Flx (IRR:3796-3999).  `st`: internals by gridcomp.LWU_IN name."""
+    from geosradiation_gridcomp_amd import gridcomp as G
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    ncol = st["TSINST"].shape[0]
+    ins = [None if st.get(k) is None else _c(st[k], dt) for k in G.LWU_IN]
+    want = G.LWU_OUT if want is None else want
+    out = {k: np.zeros((lm + 1, ncol) if k in G.LWU_OUT_3D else (ncol,), dtype=dt) for k in G.LWU_OUT if k in want}
+    getattr(L, f"oracle_lw_update_flx_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), ctypes.c_int(1 if rrtmg else 0), ctypes.c_int(lev_mid_high),
+                                              ctypes.c_int(lev_low_mid), ctypes.c_double(undef), _parr(ins),
+                                              _parr([out.get(k) for k in G.LWU_OUT]))
+    return out
+
+
+def swd_prep(f, consts, iceflg=3, liqflg=1, prec="f32"):
+    """RRTMG branch of SORADCORE, prep / flip (SOL:6113-6212).  Returns (rrtmg-side arrays, normalised TAUA/SSAA/ASYA)."""
+    from geosradiation_gridcomp_amd import gridcomp as G
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    lm, ncol = f["T"].shape
+    nb = 14
+    ins = [None if f.get(k) is None else _c(f[k], dt).copy() for k in G.SWD_IN[:15]]
+    shp = {"plev": (lm + 1, ncol), "tlev": (lm + 1, ncol), "tauaer_sw": (14, lm, ncol), "ssaaer_sw": (14, lm, ncol), "asmaer_sw": (14, lm, ncol)}
+    out = {k: np.zeros(shp.get(k, (lm, ncol)), dtype=dt) for k in SWD_RR}
+    cs = (ctypes.c_double * len(consts))(*consts)
+    getattr(L, f"oracle_swd_prep_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), ctypes.c_int(nb), _parr(ins), cs, ctypes.c_int(iceflg),
+                                         ctypes.c_int(liqflg), _parr([out[k] for k in SWD_RR]))
+    return out, {"TAUA": ins[12], "SSAA": ins[13], "ASYA": ins[14]}
+
+
+def swd_post(flux, clearCounts, cot8, aerosols, undef, prec="f32"):
+    """SOL:6395-6450.  flux: swuflx swdflx swuflxc swdflxc; cot8: cotdtp cotdhp cotdmp cotdlp cotntp cotnhp cotnmp cotnlp"""
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    n1, ncol = flux["swuflx"].shape
+    fl = [_c(flux[k], dt) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")]
+    c8 = [_c(cot8[k], dt) for k in ("cotdtp", "cotdhp", "cotdmp", "cotdlp", "cotntp", "cotnhp", "cotnmp", "cotnlp")]
+    names = ["FSW", "FSC", "FSWU", "FSCU", "CLDTS", "CLDHS", "CLDMS", "CLDLS", "COTTP", "COTHP", "COTMP", "COTLP"]
+    out = {k: np.zeros((n1, ncol) if k.startswith("FS") else (ncol,), dtype=dt) for k in names}
+    cc = np.ascontiguousarray(clearCounts, dtype=np.int32)
+    getattr(L, f"oracle_swd_post_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(n1 - 1), ctypes.c_int(112), ctypes.c_int(1 if aerosols else 0),
+                                         ctypes.c_double(undef), _parr(fl), _p(cc), _parr(c8), _parr([out[k] for k in names]))
+    return out
+
+
+def sw_update_export(st, lm, nbands, prec="f32", want=None):
+    """UPDATE_EXPORT flux part (SOL:7540-7579).  `st`: gridcomp.SWU_IN internals."""
+    from geosradiation_gridcomp_amd import gridcomp as G
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    ncol = st["SLR"].shape[0]
+    ins = [None if st.get(k) is None else _c(st[k], dt) for k in G.SWU_IN]
+    want = G.SWU_OUT if want is None else want
+    shape = lambda k: (lm + 1, ncol) if k in G.SWU_OUT_3D else ((nbands, ncol) if k in G.SWU_OUT_BAND else (ncol,))
+    out = {k: np.zeros(shape(k), dtype=dt) for k in G.SWU_OUT if k in want}
+    getattr(L, f"oracle_sw_update_export_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), ctypes.c_int(nbands), _parr(ins),
+                                                 _parr([out.get(k) for k in G.SWU_OUT]))
+    return out
+
+
+def rad_tendencies(st, lm, grav, cp, prec="f32", want=None):
+    """RAD:798-819.  `st`: gridcomp.RT_IN fields."""
+    from geosradiation_gridcomp_amd import gridcomp as G
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    ncol = st["DSFDTS"].shape[0]
+    ins = [None if st.get(k) is None else _c(st[k], dt) for k in G.RT_IN]
+    want = G.RT_OUT if want is None else want
+    out = {k: np.zeros((lm, ncol) if k in G.RT_OUT_3D else (ncol,), dtype=dt) for k in G.RT_OUT if k in want}
+    getattr(L, f"oracle_rad_tendencies_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), ctypes.c_double(grav), ctypes.c_double(cp), _parr(ins),
+                                               _parr([out.get(k) for k in G.RT_OUT]))
+    return out

@@ -1,5 +1,5 @@
 /* oracle/lw_oracle.c -- TEST INFRASTRUCTURE ONLY.  Builds the plain-C restatements (RRTMG_LW + McICA:
- * lw_oracle_impl.h; RRTMG_SW: sw_oracle_impl.h; Chou-Suarez irrad / sorad: chou_oracle_impl.h, chou_sw_oracle_impl.h) in both precisions (see those files for the reference citations).  gcc -O2 -ffp-contract=off -shared -fPIC. */
+ * lw_oracle_impl.h; RRTMG_SW: sw_oracle_impl.h; Chou-Suarez irrad / sorad: chou_oracle_impl.h, chou_sw_oracle_impl.h; GridComp data path: gridcomp_oracle_impl.h) in both precisions (see those files for the reference citations).  gcc -O2 -ffp-contract=off -shared -fPIC. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -18,6 +18,7 @@
 #include "sw_oracle_impl.h"
 #include "chou_oracle_impl.h"
 #include "chou_sw_oracle_impl.h"
+#include "gridcomp_oracle_impl.h"
 #undef LOG10
 #undef REAL
 #undef SFX
@@ -43,4 +44,5 @@
 #include "sw_oracle_impl.h"
 #include "chou_oracle_impl.h"
 #include "chou_sw_oracle_impl.h"
+#include "gridcomp_oracle_impl.h"
 #undef LOG10

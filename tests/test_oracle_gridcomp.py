@@ -1,0 +1,174 @@
+"""CPU tests of the plain-C restatement of the GridComp data path (oracle/gridcomp_oracle_impl.h; parity unpinned: the GridComps
+need ESMF/MAPL).  The restatement is checked against independently written numpy expressions of the reference statements
+(GEOS_IrradGridComp.F90:3188-3999, GEOS_SolarGridComp.F90:6113-6450 / :7540-7579, GEOS_RadiationGridComp.F90:798-819) and against
+synth.make_columns, whose columns were generated with the driver's own formulas."""
+import numpy as np
+import pytest
+
+from geosradiation_gridcomp_amd import gridcomp as G
+from geosradiation_gridcomp_amd import synth
+from oracle import clib
+
+
+@pytest.fixture(scope="module")
+def cols():
+    return synth.make_columns(24, 72, start=77, cloudy_frac=0.6, aerosol=True)
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("f64", 1e-14)])
+def test_lw_prep_leads_back_to_the_rrtmg_columns(cols, prec, tol):
+    f = synth.geos_lw_fields(cols)
+    rr = clib.lwd_prep(f, G.lwd_consts(), 3, 1, prec)
+    for k in ("play", "plev", "tlay", "h2ovmr", "o3vmr", "ch4vmr", "n2ovmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "cldf", "ciwp", "clwp",
+              "rei", "rel", "tauaer", "tsfc", "alat", "emis"):
+        b = np.asarray(cols[k], dtype=np.float64)
+        np.testing.assert_allclose(rr[k], b, rtol=max(tol, 2e-7), atol=1e-30, err_msg=k)     # `cols` itself is float32
+    np.testing.assert_allclose(rr["co2vmr"], G.GAS["CO2_FIXED"], rtol=1e-6)
+    np.testing.assert_allclose(rr["o2vmr"], G.GAS["O2"], rtol=1e-6)
+    np.testing.assert_allclose(rr["ccl4vmr"], G.GAS["CCL4"], rtol=1e-6)
+    # level temperatures: pressure-weighted means inside, 2-m temperature at the surface, top level = the one below
+    np.testing.assert_allclose(rr["tlev"], cols["tlev"], atol=1e-4)
+    np.testing.assert_array_equal(rr["tlev"][-1], rr["tlev"][-2])
+    # layer heights: hydrostatic running sum, zero at the lowest layer, increasing
+    assert np.all(rr["zm"][0] == 0) and np.all(np.diff(rr["zm"], axis=0) > 0)
+    np.testing.assert_allclose(rr["zm"], cols["zm"], rtol=2e-4)
+
+
+def test_lw_prep_limits_and_negatives(cols):
+    f = dict(synth.geos_lw_fields(cols))
+    f["REFF_ICE"] = f["REFF_ICE"] * 0 + 500.0
+    f["REFF_LIQ"] = f["REFF_LIQ"] * 0 + 1.0
+    f["Q"] = f["Q"].copy(); f["Q"][3] = -1e-6
+    f["FCLD"] = f["FCLD"].copy(); f["FCLD"][5] = -0.1
+    f["SSAA"] = f["TAUA"] * 1.5            # scattering > extinction must not give negative absorption (IRR:3335)
+    for iceflg, hi in ((0, 30.0), (1, 130.0), (2, 131.0), (3, 140.0), (4, 200.0)):
+        rr = clib.lwd_prep(f, G.lwd_consts(), iceflg, 1, "f64")
+        assert np.all(rr["rei"] == hi) and np.all(rr["rel"] == 2.5)
+        assert rr["h2ovmr"].min() == 0 and rr["cldf"].min() == 0 and rr["tauaer"].min() == 0 and rr["tauaer"].max() == 0
+    rr = clib.lwd_prep(f, G.lwd_consts(), 3, 0, "f64")
+    assert np.all(rr["rel"] == 5.0)
+    f["CO2_3D"] = f["T"] * 0 + 3.3e-4
+    assert np.all(clib.lwd_prep(f, G.lwd_consts(), 3, 1, "f64")["co2vmr"] == 3.3e-4)
+
+
+def test_lw_post_conventions():
+    rng = np.random.default_rng(5)
+    lm, n = 9, 7
+    fl = {k: rng.uniform(10, 400, (lm + 1, n)) for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs")}
+    cc = rng.integers(0, 141, (4, n)).astype(np.int32)
+    emis = rng.uniform(0.9, 1.0, n); ts = rng.uniform(270, 300, n)
+    o = clib.lwd_post(fl, cc, emis, ts, "f64")
+    np.testing.assert_array_equal(o["FLXU_INT"], -fl["uflx"][::-1])
+    np.testing.assert_array_equal(o["FLXD_INT"], fl["dflx"][::-1])
+    np.testing.assert_array_equal(o["FLCU_INT"], -fl["uflxc"][::-1])
+    np.testing.assert_array_equal(o["DFDTS"], -fl["duflx_dTs"][::-1])
+    np.testing.assert_array_equal(o["DFDTSNA"], o["DFDTS"]); np.testing.assert_array_equal(o["DFDTSCNA"], o["DFDTSC"])
+    np.testing.assert_array_equal(o["FLX_INT"], o["FLXD_INT"] + o["FLXU_INT"])
+    np.testing.assert_array_equal(o["FLC_INT"], o["FLCD_INT"] + o["FLCU_INT"])
+    np.testing.assert_allclose(o["SFCEM_INT"], fl["uflx"][0] - fl["dflx"][0] * (1 - emis), rtol=1e-15)
+    assert np.all(o["SFCEM_INT"] > 0)
+    np.testing.assert_array_equal(o["TS_INT"], ts)
+    for k, name in enumerate(("CLDTTLW", "CLDHILW", "CLDMDLW", "CLDLOLW")):
+        np.testing.assert_allclose(o[name], 1.0 - cc[k] / 140.0, rtol=1e-15)
+    # only what is asked for is written
+    assert set(clib.lwd_post(fl, cc, emis, ts, "f64", want=["FLX_INT", "SFCEM_INT"])) == {"FLX_INT", "SFCEM_INT"}
+
+
+def _lwu_state(rng, lm, n):
+    st = {k: rng.uniform(-400, 400, (lm + 1, n)) for k in G.LWU_IN if k not in ("TSINST", "TS_INT", "SFCEM_INT", "FCLD")}
+    st["TSINST"] = rng.uniform(270, 300, n); st["TS_INT"] = st["TSINST"] + rng.uniform(-3, 3, n)
+    st["SFCEM_INT"] = rng.uniform(300, 450, n)
+    st["FCLD"] = rng.uniform(0, 1, (lm, n)) * (rng.uniform(0, 1, (lm, n)) < 0.3)
+    st["FCLD"][:, :2] = 0.0           # two cloud-free columns
+    return st
+
+
+def test_lw_update_flx_against_numpy():
+    rng = np.random.default_rng(11)
+    lm, n, lmh, llm = 12, 9, 5, 9
+    st = _lwu_state(rng, lm, n)
+    undef = G.MAPL["UNDEF"]
+    o = clib.lw_update_flx(st, lm, False, lmh, llm, undef, "f64")
+    delt = st["TSINST"] - st["TS_INT"]
+    np.testing.assert_allclose(o["FLX"], st["FLX_INT"] + st["DFDTS"] * delt, rtol=1e-15)
+    np.testing.assert_allclose(o["FLXA"], st["FLXA_INT"] + st["DFDTSNA"] * delt, rtol=1e-15)
+    np.testing.assert_allclose(o["FLC"], st["FLC_INT"] + st["DFDTSC"] * delt, rtol=1e-15)
+    np.testing.assert_allclose(o["FLAU"], st["FLAU_INT"] + st["DFDTSCNA"] * delt, rtol=1e-15)
+    np.testing.assert_array_equal(o["FLXD"], st["FLXD_INT"]); np.testing.assert_array_equal(o["FLAD"], st["FLAD_INT"])
+    np.testing.assert_allclose(o["OLR"], -(st["FLX_INT"][0] + st["DFDTS"][0] * delt), rtol=1e-15)
+    np.testing.assert_allclose(o["SFCEM"], st["SFCEM_INT"] - st["DFDTS"][lm] * delt, rtol=1e-15)
+    np.testing.assert_array_equal(o["DSFDTS"], -st["DFDTS"][lm]); np.testing.assert_array_equal(o["DSFDTS0"], o["DSFDTS"])
+    np.testing.assert_allclose(o["LWS"], st["FLX_INT"][lm] + st["SFCEM_INT"], rtol=1e-15)
+    np.testing.assert_allclose(o["FLNSA"], st["FLA_INT"][lm] + st["DFDTSCNA"][lm] * delt, rtol=1e-15)
+    np.testing.assert_array_equal(o["TSREFF"], st["TSINST"])
+    f = st["FCLD"]
+    cld = 1 - (1 - f[:lmh - 1].max(0)) * (1 - f[lmh - 1:llm - 1].max(0)) * (1 - f[llm - 1:].max(0))
+    np.testing.assert_allclose(o["CLDTT"], cld, rtol=1e-15)
+    clear = cld <= 0.05
+    assert clear[:2].all() and not clear.all()
+    np.testing.assert_array_equal(o["OLCC5"][~clear], undef); np.testing.assert_array_equal(o["OLCC5"][clear], o["OLC"][clear])
+    np.testing.assert_array_equal(o["LCSC5"][~clear], undef); np.testing.assert_array_equal(o["LCSC5"][clear], o["LCS"][clear])
+    # RRTMG: no no-aerosol flavours (IRR:3927-3990)
+    st2 = {k: (None if k in G.LWU_IN_NA else v) for k, v in st.items()}
+    r = clib.lw_update_flx(st2, lm, True, lmh, llm, undef, "f64")
+    for k in ("FLXA", "FLA", "FLXAU", "FLAU", "FLXAD", "FLAD", "OLRA", "OLA", "LWSA", "LAS", "FLNSNA", "FLNSA"):
+        assert np.all(r[k] == undef), k
+    for k in ("FLX", "FLC", "FLXU", "FLCU", "FLXD", "FLCD", "OLR", "OLC", "SFCEM", "LWS", "LCS", "FLNS", "FLNSC", "CLDTT"):
+        np.testing.assert_array_equal(r[k], o[k], err_msg=k)
+    # no temperature change since the last full calculation: exports == internals
+    st3 = dict(st); st3["TSINST"] = st["TS_INT"]
+    z = clib.lw_update_flx(st3, lm, False, lmh, llm, undef, "f64")
+    np.testing.assert_array_equal(z["FLX"], st["FLX_INT"]); np.testing.assert_array_equal(z["SFCEM"], st["SFCEM_INT"])
+
+
+def test_sw_prep_post_update_and_tendencies(cols):
+    fs = synth.geos_sw_fields(cols)
+    rr, aer = clib.swd_prep(fs, G.swd_consts(), 3, 1, "f64")
+    for k in ("play", "plev", "tlay", "h2ovmr", "o3vmr", "ch4vmr", "cldf", "ciwp", "clwp", "rei", "rel", "tauaer_sw", "ssaaer_sw",
+              "asmaer_sw"):
+        np.testing.assert_allclose(rr[k], np.asarray(cols[k], dtype=np.float64), rtol=3e-7, atol=1e-30, err_msg=k)
+    np.testing.assert_array_equal(rr["tlev"][0], fs["TS"])       # SW uses TS, not T2M, at the surface (SOL:6175)
+    np.testing.assert_allclose(rr["zm"], cols["zm"], rtol=2e-4)
+    # in-place normalisation (SOL:6116-6125): tau stays, ssa and g are divided out; zero optical depth -> all three zero
+    np.testing.assert_allclose(aer["SSAA"], np.where(fs["TAUA"] > 0, fs["SSAA"] / np.where(fs["TAUA"] > 0, fs["TAUA"], 1), 0), rtol=1e-14)
+    fz = dict(fs); fz["TAUA"] = fs["TAUA"] * 0
+    rz, az = clib.swd_prep(fz, G.swd_consts(), 3, 1, "f64")
+    assert az["SSAA"].max() == 0 and az["ASYA"].max() == 0 and rz["ssaaer_sw"].max() == 0
+    assert np.all(clib.swd_prep(fs, G.swd_consts(), 3, 0, "f64")[0]["rel"] >= 10.0)      # liqflg 0: 10..30 in the SW driver
+
+    rng = np.random.default_rng(2)
+    lm, n = 11, 6
+    fl = {k: rng.uniform(0, 1, (lm + 1, n)) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
+    cot = {k: rng.uniform(0, 5, n) for k in ("cotdtp", "cotdhp", "cotdmp", "cotdlp", "cotntp", "cotnhp", "cotnmp", "cotnlp")}
+    cot["cotdtp"][0] = 0; cot["cotnlp"][1] = 0
+    cc = rng.integers(0, 113, (4, n)).astype(np.int32)
+    o = clib.swd_post(fl, cc, cot, True, 1e15, "f64")
+    np.testing.assert_array_equal(o["FSW"], (fl["swdflx"] - fl["swuflx"])[::-1])
+    np.testing.assert_array_equal(o["FSCU"], fl["swuflxc"][::-1])
+    np.testing.assert_allclose(o["CLDHS"], 1 - cc[1] / 112.0, rtol=1e-15)
+    assert o["COTTP"][0] == 1e15 and o["COTLP"][1] == 1e15
+    np.testing.assert_allclose(o["COTMP"], cot["cotnmp"] / cot["cotdmp"], rtol=1e-15)
+
+    st = {k: rng.uniform(0, 1, (lm + 1, n)) for k in G.SWU_IN[1:9]}
+    st["SLR"] = rng.uniform(0, 1300, n); st["SLR"][0] = 0
+    st["FSWBANDN"] = rng.uniform(0, 1, (14, n)); st["FSWBANDNAN"] = rng.uniform(0, 1, (14, n))
+    u = clib.sw_update_export(st, lm, 14, "f64")
+    np.testing.assert_allclose(u["FSW"], st["FSWN"] * st["SLR"], rtol=1e-15)
+    np.testing.assert_allclose(u["FSCDNA"], (st["FSCNAN"] + st["FSCUNAN"]) * st["SLR"], rtol=1e-15)
+    np.testing.assert_allclose(u["FSWBANDNA"], st["FSWBANDNAN"] * st["SLR"], rtol=1e-15)
+    np.testing.assert_allclose(u["OSR"], (1 - st["FSWN"][0]) * st["SLR"], rtol=1e-15)
+    np.testing.assert_allclose(u["RSCSNA"], st["FSCNAN"][lm] * st["SLR"], rtol=1e-15)
+    assert np.all(u["FSW"][:, 0] == 0)
+
+    rt = {k: rng.uniform(-300, 300, (lm + 1, n)) for k in G.RT_IN[1:8]}
+    rt["PLE"] = np.cumsum(rng.uniform(100, 9000, (lm + 1, n)), axis=0)
+    rt["DSFDTS"] = rng.uniform(4, 6, n); rt["SFCEM"] = rng.uniform(300, 450, n); rt["TRD"] = rng.uniform(270, 300, n)
+    g, cp = G.MAPL["GRAV"], G.MAPL["CP"]
+    t = clib.rad_tendencies(rt, lm, g, cp, "f64")
+    np.testing.assert_allclose(t["DTDT"], ((rt["FLW"][:-1] - rt["FLW"][1:]) + (rt["FSW"][:-1] - rt["FSW"][1:])) * (g / cp), rtol=1e-14)
+    dmi = g / (cp * (rt["PLE"][1:] - rt["PLE"][:-1]))
+    np.testing.assert_allclose(t["RADLW"], (rt["FLW"][:-1] - rt["FLW"][1:]) * dmi, rtol=1e-14)
+    np.testing.assert_allclose(t["RADSWCNA"], (rt["FSCNA"][:-1] - rt["FSCNA"][1:]) * dmi, rtol=1e-14)
+    np.testing.assert_allclose(t["ALW"], rt["SFCEM"] - rt["DSFDTS"] * rt["TRD"], rtol=1e-15)
+    np.testing.assert_array_equal(t["BLW"], rt["DSFDTS"])
+    np.testing.assert_allclose(t["RADSRF"], rt["FSW"][lm] + rt["FLW"][lm], rtol=1e-15)
