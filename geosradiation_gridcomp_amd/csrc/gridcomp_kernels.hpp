@@ -38,6 +38,7 @@ template <typename R> struct LwdArgs {
 // interface temperature of model level k (1..LM+1), IRR:3248-3256
 template <typename R> GR_DEV R lwd_tlev(const LwdArgs<R> &A, int k, int ij)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int n = A.ncol, lm = A.lm;
     if (k == lm + 1) return A.t2m[ij];
     if (k == 1) k = 2;
@@ -52,6 +53,7 @@ template <typename R> GR_DEV R clampr(R x, R lo, R hi) { x = x > lo ? x : lo; re
 // effective-radius limits RRTMG assumes (IRR:3272-3291, SOL:6144-6170)
 template <typename R> GR_DEV void rrtmg_reff_limits(int iceflg, int liqflg, R &reice, R &reliq)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     if (liqflg == 0) reliq = clampr<R>(reliq, (R)5.0, (R)10.0);
     else if (liqflg == 1) reliq = clampr<R>(reliq, (R)2.5, (R)60.0);
     if (iceflg == 0) reice = clampr<R>(reice, (R)10.0, (R)30.0);
@@ -64,6 +66,7 @@ template <typename R> GR_DEV void rrtmg_reff_limits(int iceflg, int liqflg, R &r
 // one thread per (column, RRTMG layer K = 1..LM); blockIdx.y = K - 1, and K = LM additionally writes the top level
 template <typename R> __global__ void __launch_bounds__(256) k_lwd_prep(LwdArgs<R> A)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= A.ncol) return;
     const int n = A.ncol, lm = A.lm, K = blockIdx.y + 1, LV = lm - K + 1;
@@ -122,6 +125,7 @@ template <typename R> __global__ void __launch_bounds__(256) k_lwd_prep(LwdArgs<
 // layer mid-point heights, a running sum up the column (IRR:3344-3356): one thread per column
 template <typename R> __global__ void __launch_bounds__(256) k_lwd_zm(LwdArgs<R> A)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= A.ncol) return;
     const int n = A.ncol, lm = A.lm;
@@ -150,6 +154,7 @@ template <typename R> struct LwdPost {
 // one thread per (column, GEOS level K = 0..LM) (IRR:3487-3533, :3601-3615, :3560-3565)
 template <typename R> __global__ void __launch_bounds__(256) k_lwd_post(LwdPost<R> P)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= P.ncol) return;
     const int n = P.ncol, lm = P.lm, K = blockIdx.y, LV = lm - K + 1;
@@ -201,6 +206,7 @@ template <typename R> struct LwUpd {
 // one thread per (column, level K = 0..LM); the 2-D exports are written by the K = 0 / K = LM threads
 template <typename R> __global__ void __launch_bounds__(256) k_lw_update_flx(LwUpd<R> U)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= U.ncol) return;
     const int n = U.ncol, lm = U.lm, K = blockIdx.y;
@@ -279,6 +285,7 @@ template <typename R> struct SwdArgs {
 
 template <typename R> GR_DEV R swd_tlev(const SwdArgs<R> &A, int k, int ij)      // TLEV(1..LM+1), SOL:6172-6176
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int n = A.ncol, lm = A.lm;
     if (k == lm + 1) return A.ts[ij];
     if (k == 1) k = 2;
@@ -290,6 +297,7 @@ template <typename R> GR_DEV R swd_tlev(const SwdArgs<R> &A, int k, int ij)     
 
 template <typename R> __global__ void __launch_bounds__(256) k_swd_prep(SwdArgs<R> A)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= A.ncol) return;
     const int n = A.ncol, lm = A.lm, K = blockIdx.y + 1, LV = lm - K + 1;
@@ -343,6 +351,7 @@ template <typename R> __global__ void __launch_bounds__(256) k_swd_prep(SwdArgs<
 // ZL_R (SOL:6200-6207): note the level index differs from LW (levels are 1-based here)
 template <typename R> __global__ void __launch_bounds__(256) k_swd_zm(SwdArgs<R> A)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= A.ncol) return;
     const int n = A.ncol, lm = A.lm;
@@ -369,6 +378,7 @@ template <typename R> struct SwdPost {
 
 template <typename R> __global__ void __launch_bounds__(256) k_swd_post(SwdPost<R> P)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= P.ncol) return;
     const int n = P.ncol, lm = P.lm, L = blockIdx.y;      // model level index 0..LM of the un-flipped arrays
@@ -410,6 +420,7 @@ template <typename R> struct SwUpd {
 // blockIdx.y = level 0..LM, then the bands
 template <typename R> __global__ void __launch_bounds__(256) k_sw_update_export(SwUpd<R> U)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= U.ncol) return;
     const int n = U.ncol, lm = U.lm;
@@ -472,6 +483,7 @@ template <typename R> struct RadTend {
 
 template <typename R> __global__ void __launch_bounds__(256) k_rad_tendencies(RadTend<R> P)
 {
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
     const int ij = blockIdx.x * blockDim.x + threadIdx.x;
     if (ij >= P.ncol) return;
     const int n = P.ncol, lm = P.lm, k = blockIdx.y;      // layer k+1 lies between levels k and k+1

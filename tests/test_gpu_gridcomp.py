@@ -1,0 +1,203 @@
+"""GPU parity tests of the GridComp data path: the HIP kernels behind the C ABI against the plain-C
+restatement oracle/gridcomp_oracle_impl.h.  The kernels perform the reference's statements operation by operation (no FMA
+contraction), so the comparison is bitwise in both precisions."""
+import numpy as np
+import pytest
+
+from geosradiation_gridcomp_amd import gridcomp as G
+from geosradiation_gridcomp_amd import synth
+from geosradiation_gridcomp_amd.api import GeosradError
+
+pytestmark = pytest.mark.gpu
+PREC = {4: "f32", 8: "f64"}
+
+
+def _dev(arrs, dt):
+    """numpy dict -> (torch tensors on cuda:0, name -> device address); None stays absent"""
+    import torch
+    t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=dt)).cuda() for k, v in arrs.items() if isinstance(v, np.ndarray)}
+    return t, {k: v.data_ptr() for k, v in t.items()}
+
+
+def _zeros(shapes, dt):
+    import torch
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    t = {k: torch.full(s, -7.0, dtype=tdt, device="cuda") for k, s in shapes.items()}
+    return t, {k: v.data_ptr() for k, v in t.items()}
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_lw_driver_equals_oracle_prep_gpu_solver_oracle_post(gpu_ctx, rk):
+    from oracle import clib
+    ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
+    ncol, lm = 300, 72          # two 256-column blocks, the second ragged
+    inp = synth.make_columns(ncol, lm, start=900, cloudy_frac=0.6, aerosol=True)
+    f = synth.geos_lw_fields(inp)
+    consts = G.lwd_consts()
+    ctx.set_inhomogeneity(1)
+    tin, ptr = _dev(f, dt)
+    shapes = {k: ((lm + 1, ncol) if k in G.LWD_OUT_3D else ((ncol, 16) if k in ("OLRB", "DOLRB") else (ncol,))) for k in G.LWD_OUT}
+    tout, pout = _zeros(shapes, dt)
+    ptr.update(pout)
+    bo = np.zeros(16, dtype=np.int32); bo[[5, 9]] = 1
+    ctx.lw_driver_rrtmg_dev(_stream(), ncol, lm, 16, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"], band_output=bo)
+    ctx.check(_stream())
+    # the same three steps with the oracle either side of the GPU solver
+    rr = clib.lwd_prep(f, consts, 3, 1, prec)
+    inp2 = dict(rr); inp2.update(dyofyr=inp["dyofyr"], cloudLM=inp["cloudLM"], cloudMH=inp["cloudMH"])
+    h = ctx.rrtmg_lw_columns(inp2, dudTs=True, band_output=bo)
+    o = clib.lwd_post(h, h["clearCounts"], f["EMIS"], f["TS"], prec)
+    ctx.set_inhomogeneity(0)
+    for k in G.LWD_OUT[:16]:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
+    got = tout["OLRB"].cpu().numpy()
+    np.testing.assert_array_equal(got[:, [5, 9]], h["olrb"][:, [5, 9]])
+    assert (o["CLDTTLW"] > 0).any() and (o["CLDTTLW"] == 0).any()
+    # GEOS conventions: upward negative, surface emission positive, OLR = -FLX_INT at the top
+    assert (o["FLXU_INT"] < 0).all() and (o["SFCEM_INT"] > 0).all() and (o["FLX_INT"][0] < 0).all()
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_lw_driver_without_aerosols_and_exports_not_associated(gpu_ctx, rk):
+    from oracle import clib
+    ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
+    ncol, lm = 64, 72
+    inp = synth.make_columns(ncol, lm, start=40, cloudy_frac=0.0, aerosol=False)
+    f = synth.geos_lw_fields(inp)
+    f["TAUA"] = None; f["SSAA"] = None
+    f["CO2_3D"] = f["T"] * 0 + 4.1e-4
+    consts = G.lwd_consts()
+    tin, ptr = _dev(f, dt)
+    want = ["FLX_INT", "SFCEM_INT", "DFDTS"]
+    tout, pout = _zeros({"FLX_INT": (lm + 1, ncol), "SFCEM_INT": (ncol,), "DFDTS": (lm + 1, ncol)}, dt)
+    ptr.update(pout)
+    ctx.lw_driver_rrtmg_dev(_stream(), ncol, lm, 0, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"])
+    ctx.check(_stream())
+    rr = clib.lwd_prep(f, consts, 3, 1, prec)
+    inp2 = dict(rr); inp2.update(dyofyr=inp["dyofyr"], cloudLM=inp["cloudLM"], cloudMH=inp["cloudMH"])
+    h = ctx.rrtmg_lw_columns(inp2, dudTs=True)
+    o = clib.lwd_post(h, h["clearCounts"], f["EMIS"], f["TS"], prec, want=want)
+    for k in want:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
+    # a missing required field is refused
+    bad = dict(ptr); bad.pop("Q")
+    with pytest.raises(GeosradError):
+        ctx.lw_driver_rrtmg_dev(_stream(), ncol, lm, 0, bad, consts, 3, 1, 180, f["LCLDLM"], f["LCLDMH"])
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_sw_driver_equals_oracle_prep_gpu_solver_oracle_post(gpu_ctx, rk):
+    from oracle import clib
+    ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
+    ncol, lm = 300, 72
+    inp = synth.make_columns(ncol, lm, start=5000, cloudy_frac=0.6, aerosol=True)
+    f = synth.geos_sw_fields(inp)
+    consts = G.swd_consts()
+    ctx.set_inhomogeneity(1)
+    tin, ptr = _dev(f, dt)
+    shapes = {k: (ncol,) for k in G.SWD_OUT}
+    shapes.update({k: (lm + 1, ncol) for k in ("FSW", "FSC", "FSWU", "FSCU")}); shapes["FSWBAND"] = (14, ncol)
+    tout, pout = _zeros(shapes, dt)
+    ptr.update(pout)
+    ctx.sw_driver_rrtmg_dev(_stream(), ncol, lm, 14, ptr, consts, 3, 1, 1361.0, 1.0, 0, int(inp["dyofyr"]), True, f["LCLDLM"], f["LCLDMH"], 1)
+    ctx.check(_stream())
+    rr, aer = clib.swd_prep(f, consts, 3, 1, prec)
+    inp2 = dict(rr)
+    for k in ("coszen", "alat", "asdir", "asdif", "aldir", "aldif", "dyofyr", "cloudLM", "cloudMH"):
+        inp2[k] = inp[k]
+    h = ctx.rrtmg_sw_columns(inp2, scon=1361.0, adjes=1.0, isolvar=0, iaer=10, normFlx=1)
+    o = clib.swd_post(h, h["clearCounts"], h, True, consts[G.SWD_CONST.index("UNDEF")], prec)
+    ctx.set_inhomogeneity(0)
+    for k in o:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
+    for k, hk in (("NIRR", "nirr"), ("NIRF", "nirf"), ("PARR", "parr"), ("PARF", "parf"), ("UVRR", "uvrr"), ("UVRF", "uvrf"), ("FSWBAND", "fswband")):
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), h[hk], err_msg=k)
+    # the aerosol triplet was normalised in place like the reference does (SOL:6116-6125)
+    for k in ("TAUA", "SSAA", "ASYA"):
+        np.testing.assert_array_equal(tin[k].cpu().numpy(), aer[k], err_msg=k)
+    assert (o["COTLP"] == consts[-1]).any() and (o["COTLP"] != consts[-1]).any()
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_update_flx_export_and_tendencies_match_the_oracle(gpu_ctx, rk):
+    from oracle import clib
+    ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
+    rng = np.random.default_rng(31)
+    lm, n, lmh, llm = 72, 777, 30, 47
+    st = {k: rng.uniform(-400, 400, (lm + 1, n)) for k in G.LWU_IN if k not in ("TSINST", "TS_INT", "SFCEM_INT", "FCLD")}
+    st["TSINST"] = rng.uniform(270, 300, n); st["TS_INT"] = st["TSINST"] + rng.uniform(-3, 3, n); st["SFCEM_INT"] = rng.uniform(300, 450, n)
+    st["FCLD"] = rng.uniform(0, 1, (lm, n)) * (rng.uniform(0, 1, (lm, n)) < 0.02)
+    undef = G.MAPL["UNDEF"]
+    for rrtmg in (False, True):
+        s2 = {k: v for k, v in st.items() if not (rrtmg and k in G.LWU_IN_NA)}
+        want = G.LWU_OUT if not rrtmg else [k for k in G.LWU_OUT if k not in ("FLXD", "LWS", "OLC")]      # some exports not associated
+        tin, ptr = _dev(s2, dt)
+        tout, pout = _zeros({k: ((lm + 1, n) if k in G.LWU_OUT_3D else (n,)) for k in want}, dt)
+        ptr.update(pout)
+        ctx.lw_update_flx_dev(_stream(), n, lm, rrtmg, lmh, llm, undef, ptr)
+        ctx.check(_stream())
+        o = clib.lw_update_flx(s2, lm, rrtmg, lmh, llm, undef, prec, want=want)
+        assert set(o) == set(want)
+        for k in want:
+            np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=f"{k} rrtmg={rrtmg}")
+    # UPDATE_EXPORT
+    sw = {k: rng.uniform(0, 1, (lm + 1, n)) for k in G.SWU_IN[1:9]}
+    sw["SLR"] = rng.uniform(0, 1300, n); sw["FSWBANDN"] = rng.uniform(0, 1, (14, n)); sw["FSWBANDNAN"] = rng.uniform(0, 1, (14, n))
+    tin, ptr = _dev(sw, dt)
+    shp = lambda k: (lm + 1, n) if k in G.SWU_OUT_3D else ((14, n) if k in G.SWU_OUT_BAND else (n,))
+    want = [k for k in G.SWU_OUT if k not in ("FSC", "OSRNA")]
+    tout, pout = _zeros({k: shp(k) for k in want}, dt)
+    ptr.update(pout)
+    ctx.sw_update_export_dev(_stream(), n, lm, 14, ptr)
+    ctx.check(_stream())
+    o = clib.sw_update_export(sw, lm, 14, prec, want=want)
+    for k in want:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
+    # an export without its internal is refused
+    bad = dict(ptr); bad.pop("FSWUN")
+    with pytest.raises(GeosradError):
+        ctx.sw_update_export_dev(_stream(), n, lm, 14, bad)
+    # heating rates
+    rt = {k: rng.uniform(-300, 300, (lm + 1, n)) for k in G.RT_IN[1:8]}
+    rt["PLE"] = np.cumsum(rng.uniform(100, 3000, (lm + 1, n)), axis=0)
+    rt["DSFDTS"] = rng.uniform(4, 6, n); rt["SFCEM"] = rng.uniform(300, 450, n); rt["TRD"] = rng.uniform(270, 300, n)
+    tin, ptr = _dev(rt, dt)
+    tout, pout = _zeros({k: ((lm, n) if k in G.RT_OUT_3D else (n,)) for k in G.RT_OUT}, dt)
+    ptr.update(pout)
+    ctx.rad_tendencies_dev(_stream(), n, lm, G.MAPL["GRAV"], G.MAPL["CP"], ptr)
+    ctx.check(_stream())
+    o = clib.rad_tendencies(rt, lm, G.MAPL["GRAV"], G.MAPL["CP"], prec)
+    for k in G.RT_OUT:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
+
+
+def test_update_flx_full_size_properties(gpu_ctx):
+    """BASELINE configs[3] per-GPU size: no surface-temperature change -> the exports are the internals, bit for bit; the
+    linearisation is exactly linear in the temperature change for a power-of-two step"""
+    import torch
+    ctx = gpu_ctx[4]
+    n, lm = 97_200, 72
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    mk = lambda *s: torch.rand(*s, device="cuda", generator=g) * 800 - 400
+    t = {k: mk(lm + 1, n) for k in G.LWU_IN if k not in ("TSINST", "TS_INT", "SFCEM_INT", "FCLD") and k not in G.LWU_IN_NA}
+    t["TS_INT"] = torch.rand(n, device="cuda", generator=g) * 30 + 270
+    t["TSINST"] = t["TS_INT"].clone(); t["SFCEM_INT"] = mk(n); t["FCLD"] = torch.zeros(lm, n, device="cuda")
+    out = {k: torch.empty(lm + 1, n, device="cuda") for k in ("FLX", "FLCU", "FLXD")}
+    out.update({k: torch.empty(n, device="cuda") for k in ("OLR", "SFCEM", "OLCC5", "CLDTT")})
+    ptr = {k: v.data_ptr() for k, v in {**t, **out}.items()}
+    ctx.lw_update_flx_dev(_stream(), n, lm, True, 30, 47, 1e15, ptr)
+    ctx.check(_stream())
+    assert torch.equal(out["FLX"], t["FLX_INT"]) and torch.equal(out["FLCU"], t["FLCU_INT"]) and torch.equal(out["FLXD"], t["FLXD_INT"])
+    assert torch.equal(out["OLR"], -t["FLX_INT"][0]) and torch.equal(out["SFCEM"], t["SFCEM_INT"])
+    assert torch.equal(out["CLDTT"], torch.zeros(n, device="cuda")) and torch.equal(out["OLCC5"], -t["FLC_INT"][0])
+    t["TSINST"] = t["TS_INT"] + 2.0
+    ptr["TSINST"] = t["TSINST"].data_ptr()
+    ctx.lw_update_flx_dev(_stream(), n, lm, True, 30, 47, 1e15, ptr)
+    ctx.check(_stream())
+    delt = t["TSINST"] - t["TS_INT"]
+    assert torch.equal(out["FLX"], t["FLX_INT"] + t["DFDTS"] * delt)
