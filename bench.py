@@ -144,6 +144,177 @@ def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
             "single_core_columns_per_s": per_core / (lw_s + sw_s)}
 
 
+def _hb_cpu_worker(args):
+    """heartbeat leg of the CPU baseline: the plain-C restatement of Update_Flx + UPDATE_EXPORT + heating rates"""
+    seed, n, lm = args
+    from geosradiation_gridcomp_amd import gridcomp as G
+    from oracle import clib
+    clib.lib()
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    st = {k: rng.uniform(-400, 400, (lm + 1, n)).astype(f32) for k in G.LWU_IN if k not in ("TSINST", "TS_INT", "SFCEM_INT", "FCLD") + tuple(G.LWU_IN_NA)}
+    st["TSINST"] = rng.uniform(270, 300, n).astype(f32); st["TS_INT"] = st["TSINST"] - 1; st["SFCEM_INT"] = rng.uniform(300, 450, n).astype(f32)
+    st["FCLD"] = np.zeros((lm, n), f32)
+    sw = {k: rng.uniform(0, 1, (lm + 1, n)).astype(f32) for k in G.SWU_IN[1:9]}
+    sw["SLR"] = rng.uniform(0, 1300, n).astype(f32)
+    sw["FSWBANDN"] = rng.uniform(0, 1, (14, n)).astype(f32); sw["FSWBANDNAN"] = sw["FSWBANDN"]
+    rt = {k: rng.uniform(-300, 300, (lm + 1, n)).astype(f32) for k in G.RT_IN[1:8]}
+    rt["PLE"] = np.cumsum(rng.uniform(100, 3000, (lm + 1, n)), axis=0).astype(f32)
+    rt["DSFDTS"] = st["SFCEM_INT"]; rt["SFCEM"] = st["SFCEM_INT"]; rt["TRD"] = st["TSINST"]
+    t = time.perf_counter()
+    for _ in range(HB_REPS):
+        clib.lw_update_flx(st, lm, True, 30, 47, 1e15, "f32", want=HB_LW)
+        clib.sw_update_export(sw, lm, 14, "f32", want=HB_SW)
+        clib.rad_tendencies(rt, lm, 9.80665, 1004.683, "f32", want=HB_RT)
+    return time.perf_counter() - t
+
+
+HB_REPS = 16
+# exports the heartbeat benchmark requests (what a typical GEOS history + the parent's couplings ask for every model step)
+HB_LW = ["FLX", "FLC", "FLXU", "FLCU", "FLXD", "FLCD", "OLR", "OLC", "OLCC5", "DSFDTS", "SFCEM", "LWS", "LCS", "LCSC5", "FLNS", "FLNSC",
+         "DSFDTS0", "SFCEM0", "TSREFF", "CLDTT"]
+HB_SW = ["FSW", "FSC", "FSWNA", "FSCNA", "FSWU", "FSCU", "FSWD", "FSCD", "FSWBAND", "RSR", "RSC", "RSRS", "RSCS", "OSR", "OSRCLR"]
+HB_RT = ["DTDT", "RADLW", "RADSW", "RADLWC", "RADSWC", "BLW", "ALW", "RADSRF"]
+
+
+def heartbeat_cpu_baseline(lm, per=8192):
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    with mp.get_context("fork").Pool(cores) as pool:
+        busy = max(pool.map(_hb_cpu_worker, [(i, per, lm) for i in range(cores)]))
+    return {"value": cores * per * HB_REPS / busy, "unit": "columns/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x {HB_REPS} passes over {per} columns x {lm} layers of the same three updates, plain-C restatement "
+                      f"(the GridComps need ESMF/MAPL: unbuildable here); slowest process {busy:.2f} s"}
+
+
+def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
+    """--scheme gridcomp : the RRTMG branches of LW_Driver + SORADCORE on GEOS-native fields (prep / flip + solver + post), i.e. the
+                           default workload entered one level higher
+       --scheme heartbeat: Update_Flx + UPDATE_EXPORT (flux part) + the parent's heating rates: pure streaming,
+                           the one genuinely HBM-bound piece next to the solvers; roofline = algorithmic bytes / time"""
+    import torch
+    import torch.distributed as dist
+    from geosradiation_gridcomp_amd import gridcomp as G
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import Context
+    ncol, lm = a.ncol, a.nlay
+    tdt = torch.float32 if a.real == 4 else torch.float64
+    ctx = Context(a.real, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    to = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev, dtype=tdt)
+    zeros = lambda *s: torch.zeros(*s, device=dev, dtype=tdt)
+    hb_bytes = 0
+    if a.scheme == "gridcomp":
+        inp = synth.make_columns(ncol, lm, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
+        fl, fs = synth.geos_lw_fields(inp), synth.geos_sw_fields(inp)
+        if not aerosol:
+            for k in ("TAUA", "SSAA"):
+                fl[k] = None
+            for k in ("TAUA", "SSAA", "ASYA"):
+                fs[k] = None
+        tl = {k: to(v) for k, v in fl.items() if isinstance(v, np.ndarray)}
+        ts = {k: to(v) for k, v in fs.items() if isinstance(v, np.ndarray)}
+        aer0 = {k: ts[k].clone() for k in ("TAUA", "SSAA", "ASYA") if k in ts}
+        for k in G.LWD_OUT:
+            tl[k] = zeros(lm + 1, ncol) if k in G.LWD_OUT_3D else (zeros(ncol, 16) if k in ("OLRB", "DOLRB") else zeros(ncol))
+        for k in G.SWD_OUT:
+            ts[k] = zeros(lm + 1, ncol) if k in ("FSW", "FSC", "FSWU", "FSCU") else (zeros(14, ncol) if k == "FSWBAND" else zeros(ncol))
+        pl = {k: v.data_ptr() for k, v in tl.items()}; ps = {k: v.data_ptr() for k, v in ts.items()}
+        cl, cs = G.lwd_consts(), G.swd_consts()
+        ctx.set_inhomogeneity(1 if a.cloudy > 0 else 0)
+        doy = int(inp["dyofyr"])
+
+        def step():
+            ctx.lw_driver_rrtmg_dev(stream, ncol, lm, 16 if aerosol else 0, pl, cl, 3, 1, doy, fl["LCLDLM"], fl["LCLDMH"])
+            for k in aer0:                      # the SW driver normalises the aerosol triplet in place: restore the inputs
+                ts[k].copy_(aer0[k])
+            ctx.sw_driver_rrtmg_dev(stream, ncol, lm, 14 if aerosol else 0, ps, cs, 3, 1, 1361.0, 1.0, 0, doy, aerosol, fs["LCLDLM"], fs["LCLDMH"], 1)
+    else:
+        g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+        rnd = lambda lo, hi, *s: (torch.rand(*s, device=dev, generator=g, dtype=torch.float32) * (hi - lo) + lo).to(tdt)
+        lw = {k: rnd(-400, 400, lm + 1, ncol) for k in G.LWU_IN if k not in ("TSINST", "TS_INT", "SFCEM_INT", "FCLD") + tuple(G.LWU_IN_NA)}
+        lw["TS_INT"] = rnd(270, 300, ncol); lw["TSINST"] = lw["TS_INT"] + rnd(-3, 3, ncol); lw["SFCEM_INT"] = rnd(300, 450, ncol)
+        lw["FCLD"] = rnd(0, 1, lm, ncol) * (rnd(0, 1, lm, ncol) < 0.05)
+        sw = {k: rnd(0, 1, lm + 1, ncol) for k in G.SWU_IN[1:9]}
+        sw["SLR"] = rnd(0, 1300, ncol); sw["FSWBANDN"] = rnd(0, 1, 14, ncol); sw["FSWBANDNAN"] = rnd(0, 1, 14, ncol)
+        rt = {"PLE": torch.cumsum(rnd(100, 3000, lm + 1, ncol), 0), "DSFDTS": rnd(4, 6, ncol), "SFCEM": rnd(300, 450, ncol), "TRD": rnd(270, 300, ncol)}
+        nin = sum(v.numel() for v in lw.values()) + sum(v.numel() for k, v in sw.items() if k != "FSWBANDNAN" and k not in ("FSWUNAN", "FSCUNAN"))
+        for k in HB_LW:
+            lw[k] = zeros(lm + 1, ncol) if k in G.LWU_OUT_3D else zeros(ncol)
+        for k in HB_SW:
+            sw[k] = zeros(lm + 1, ncol) if k in G.SWU_OUT_3D else (zeros(14, ncol) if k in G.SWU_OUT_BAND else zeros(ncol))
+        # the parent reads the children's exports
+        rt.update(FLW=lw["FLX"], FSW=sw["FSW"], FLWCLR=lw["FLC"], FSWCLR=sw["FSC"])
+        for k in HB_RT:
+            rt[k] = zeros(lm, ncol) if k in G.RT_OUT_3D else zeros(ncol)
+        nin += rt["PLE"].numel() + 4 * (lm + 1) * ncol + 3 * ncol
+        nout = sum(lw[k].numel() for k in HB_LW) + sum(sw[k].numel() for k in HB_SW) + sum(rt[k].numel() for k in HB_RT)
+        hb_bytes = (nin + nout) * a.real            # every field a requested export needs read once + every export written once
+        p1 = {k: v.data_ptr() for k, v in lw.items()}; p2 = {k: v.data_ptr() for k, v in sw.items()}; p3 = {k: v.data_ptr() for k, v in rt.items()}
+
+        def step():
+            ctx.lw_update_flx_dev(stream, ncol, lm, True, 30, 47, 1e15, p1)
+            ctx.sw_update_export_dev(stream, ncol, lm, 14, p2)
+            ctx.rad_tendencies_dev(stream, ncol, lm, 9.80665, 1004.683, p3)
+
+    for _ in range(a.warmup):
+        step()
+    ctx.check(stream)
+    if a.scheme == "gridcomp":
+        ctx.profile(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # the kernels run on torch's current stream
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        step()
+    ev1.record()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    ctx.check(stream)
+    dev_ms = ev0.elapsed_time(ev1) / a.steps
+    if rank != 0:
+        return
+    value = world * ncol * a.steps / elapsed
+    if a.scheme == "heartbeat":
+        achieved = hb_bytes / (dev_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_lw_update_flx + k_sw_update_export + k_rad_tendencies", "achieved": achieved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_column": hb_bytes / ncol,
+                "avg_launch_ms": dev_ms, "launches": a.steps, "columns_per_launch": ncol,
+                "note": "three streaming launches per step timed together with HIP events on the launch stream; algorithmic bytes = every "
+                        "internal field a requested export needs read once + every export written once"}
+        wl = (f"heartbeat update of {ncol} columns/GPU x {lm} layers: Update_Flx (RRTMG flavour, {len(HB_LW)} exports) + UPDATE_EXPORT flux part "
+              f"({len(HB_SW)} exports) + parent heating rates ({len(HB_RT)} exports)")
+        kms = {"heartbeat (3 launches)": dev_ms}
+    else:
+        prof = ctx.profile_read()
+        cand = {k: v for k, v in prof.items() if k in ("k_lw_bands", "k_sw_bands") and v[1] > 0}
+        kname = max(cand, key=lambda k: cand[k][0])
+        ms, n = prof[kname]
+        abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(lm, a.real, aerosol)
+        per_launch_s = (ms / max(n, 1)) * 1e-3
+        achieved = abytes * ncol / (n / a.steps) / per_launch_s / 1e9
+        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
+                "note": "same dominant kernel as the default bench; the driver adds prep / flip / post streaming kernels around the solvers"}
+        wl = (f"RRTMG branches of LW_Driver + SORADCORE on GEOS-native fields (model ordering, SI units): {ncol} columns/GPU, {lm} layers, "
+              f"McICA clouds on {100 * a.cloudy:.0f} % of the columns, aerosols {'on' if aerosol else 'off'}")
+        kms = {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0}
+        kms["whole step (device)"] = dev_ms
+    print(json.dumps({
+        "metric": "columns/sec (LW+SW, 72 layers)" if a.scheme == "gridcomp" else "columns/sec", "value": value, "unit": "columns/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if a.real == 4 else "f64", "data": "synthetic",
+        "config": {"workload": wl, "columns_per_gpu": ncol, "layers": lm, "sharding": "independent column batches per GPU, no collective"},
+        "roofline": roof, "kernels_ms_per_step": kms, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +323,7 @@ def main():
     ap.add_argument("--ncol", type=int, default=97_200, help="columns per GPU (default: C360 tile / 8)")
     ap.add_argument("--nlay", type=int, default=72)
     ap.add_argument("--real", type=int, default=4, choices=[4, 8], help="arithmetic type: 4 = the reference's default real")
-    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw", "chou", "irrad", "sorad"])
+    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw", "chou", "irrad", "sorad", "gridcomp", "heartbeat"])
     ap.add_argument("--cloudy", type=float, default=0.6, help="fraction of cloudy columns (0 = clear-sky)")
     ap.add_argument("--no-aerosol", action="store_true")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
@@ -169,8 +340,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     cpu = None
-    if rank == 0 and a.gpus == 1 and not a.no_cpu:
-        cpu = cpu_baseline(a.nlay, a.scheme, a.cloudy, aerosol)     # before any GPU initialisation in this process (fork pool)
+    if rank == 0 and a.gpus == 1 and not a.no_cpu:                 # before any GPU initialisation in this process (fork pool)
+        if a.scheme == "heartbeat":
+            cpu = heartbeat_cpu_baseline(a.nlay)
+        elif a.scheme == "gridcomp":      # the solvers dominate: same baseline as the default line
+            cpu = cpu_baseline(a.nlay, "lwsw", a.cloudy, aerosol)
+        else:
+            cpu = cpu_baseline(a.nlay, a.scheme, a.cloudy, aerosol)
 
     import torch
     import torch.distributed as dist
@@ -182,6 +358,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if a.scheme in ("gridcomp", "heartbeat"):
+        bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- inputs resident in HBM -------------------------------------------------------------------------------
     ncol, nlay = a.ncol, a.nlay

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <cstddef>
+#include <cstdint>
 #include "../../include/geosrad.h"
 #include "lw_device.hpp"
 #include "lw_kernels.hpp"
@@ -886,7 +887,13 @@ template <typename R> struct Ctx : geosrad_ctx {
         static_assert(offsetof(LwUpd<R>, cldtt) - offsetof(LwUpd<R>, flx) == (GEOSRAD_LWU_NOUT - 1) * sizeof(void *), "LwUpd export layout");
         R **o3 = &U.flx;       // the export pointers are laid out in the order of the GEOSRAD_LWU_* output enum
         for (int k = 0; k < GEOSRAD_LWU_NOUT; k++) o3[k] = (R *)out[k];
-        hipLaunchKernelGGL((k_lw_update_flx<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, U);
+        // 16-byte accesses (4 floats / 2 doubles per thread) when the column count and every field address allow
+        constexpr int VW = 16 / (int)sizeof(R);
+        bool wide = ncol % VW == 0;
+        for (int k = 0; k < GEOSRAD_LWU_NIN; k++) wide = wide && ((uintptr_t)in[k] & 15) == 0;
+        for (int k = 0; k < GEOSRAD_LWU_NOUT; k++) wide = wide && ((uintptr_t)out[k] & 15) == 0;
+        if (wide) hipLaunchKernelGGL((k_lw_update_flx<R, VW>), dim3((unsigned)((ncol / VW + 255) / 256), lm + 1), dim3(256), 0, st, U);
+        else hipLaunchKernelGGL((k_lw_update_flx<R, 1>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, U);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -914,7 +921,12 @@ template <typename R> struct Ctx : geosrad_ctx {
                         need(U.osrclr, U.fscn) && need(U.rsrna, U.fswnan) && need(U.rsrsna, U.fswnan) && need(U.osrna, U.fswnan) &&
                         need(U.rscna, U.fscnan) && need(U.rscsna, U.fscnan) && need(U.osrcna, U.fscnan);
         if (!ok) return fail(GEOSRAD_EINVAL, "an export was requested without the internal field it is computed from");
-        hipLaunchKernelGGL((k_sw_update_export<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1 + nbands), dim3(256), 0, st, U);
+        constexpr int VW = 16 / (int)sizeof(R);
+        bool wide = ncol % VW == 0;
+        for (int k = 0; k < GEOSRAD_SWU_NIN; k++) wide = wide && ((uintptr_t)in[k] & 15) == 0;
+        for (int k = 0; k < GEOSRAD_SWU_NOUT; k++) wide = wide && ((uintptr_t)out[k] & 15) == 0;
+        if (wide) hipLaunchKernelGGL((k_sw_update_export<R, VW>), dim3((unsigned)((ncol / VW + 255) / 256), lm + 1 + nbands), dim3(256), 0, st, U);
+        else hipLaunchKernelGGL((k_sw_update_export<R, 1>), dim3((unsigned)((ncol + 255) / 256), lm + 1 + nbands), dim3(256), 0, st, U);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -938,9 +950,12 @@ template <typename R> struct Ctx : geosrad_ctx {
                         need(P.radswcna, P.fscna) && need(P.blw, P.dsfdts) && need(P.alw, P.sfcem, P.dsfdts, P.trd) &&
                         need(P.radsrf, P.fsw, P.flw);
         if (!ok) return fail(GEOSRAD_EINVAL, "an export was requested without the field it is computed from");
-        if (!P.ple) P.ple = P.flw ? P.flw : P.fsw;      // never dereferenced for a result (no 3-D rate requested), but k_rad_tendencies forms dmi
-        if (!P.ple) return fail(GEOSRAD_EINVAL, "nothing to do");
-        hipLaunchKernelGGL((k_rad_tendencies<R>), dim3((unsigned)((ncol + 255) / 256), lm), dim3(256), 0, st, P);
+        constexpr int VW = 16 / (int)sizeof(R);
+        bool wide = ncol % VW == 0;
+        for (int k = 0; k < GEOSRAD_RT_NIN; k++) wide = wide && ((uintptr_t)in[k] & 15) == 0;
+        for (int k = 0; k < GEOSRAD_RT_NOUT; k++) wide = wide && ((uintptr_t)out[k] & 15) == 0;
+        if (wide) hipLaunchKernelGGL((k_rad_tendencies<R, VW>), dim3((unsigned)((ncol / VW + 255) / 256), lm), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((k_rad_tendencies<R, 1>), dim3((unsigned)((ncol + 255) / 256), lm), dim3(256), 0, st, P);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }

@@ -203,70 +203,103 @@ template <typename R> struct LwUpd {
         *sfcem0, *tsreff, *cldtt;
 };
 
-// one thread per (column, level K = 0..LM); the 2-D exports are written by the K = 0 / K = LM threads
-template <typename R> __global__ void __launch_bounds__(256) k_lw_update_flx(LwUpd<R> U)
+// V consecutive columns per thread (V = 4 floats / 2 doubles = one 16-byte access when the column count and the field
+// addresses allow, else V = 1): these kernels do nothing but stream, and wide accesses are what keeps enough bytes in flight
+template <typename R, int V> GR_DEV void ldv(const R *__restrict__ p, size_t o, R (&x)[V])
+{
+    if constexpr (V == 1) x[0] = p[o];
+    else if constexpr (sizeof(R) == 4) { const float4 t = *reinterpret_cast<const float4 *>(p + o); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+    else { const double2 t = *reinterpret_cast<const double2 *>(p + o); x[0] = t.x; x[1] = t.y; }
+}
+template <typename R, int V> GR_DEV void stv(R *__restrict__ p, size_t o, const R (&x)[V])
+{
+    if constexpr (V == 1) p[o] = x[0];
+    else if constexpr (sizeof(R) == 4) { float4 t; t.x = x[0]; t.y = x[1]; t.z = x[2]; t.w = x[3]; *reinterpret_cast<float4 *>(p + o) = t; }
+    else { double2 t; t.x = x[0]; t.y = x[1]; *reinterpret_cast<double2 *>(p + o) = t; }
+}
+#define VFOR for (int v = 0; v < V; v++)
+// out = expr, V columns at a time; `expr` may use the per-column arrays declared before it, indexed [v]
+#define VSET(out, off, expr) do { if (out) { R r_[V]; VFOR r_[v] = (expr); stv<R, V>(out, off, r_); } } while (0)
+
+// one thread per (V columns, level K = 0..LM); the 2-D exports are written by the K = 0 / K = LM threads
+template <typename R, int V> __global__ void __launch_bounds__(256) k_lw_update_flx(LwUpd<R> U)
 {
 #pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ij = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (ij >= U.ncol) return;
     const int n = U.ncol, lm = U.lm, K = blockIdx.y;
     const size_t o = (size_t)K * n + ij;
-    const R delt = U.tsinst[ij] - U.ts_int[ij];      // surface temperature change since the last full calculation
     const bool rr = U.rrtmg != 0;
-    const R d = U.dfdts[o], dc = U.dfdtsc[o];
-    const R dna = rr ? (R)0 : U.dfdtsna[o], dcna = rr ? (R)0 : U.dfdtscna[o];
+    const R undef = U.undef;
+    R delt[V], tsi[V], d[V], dc[V], dna[V], dcna[V], a[V], b[V];
+    ldv<R, V>(U.tsinst, ij, tsi); ldv<R, V>(U.ts_int, ij, a);
+    VFOR delt[v] = tsi[v] - a[v];                    // surface temperature change since the last full calculation
+    ldv<R, V>(U.dfdts, o, d); ldv<R, V>(U.dfdtsc, o, dc);
+    VFOR { dna[v] = 0; dcna[v] = 0; }
+    if (!rr) { ldv<R, V>(U.dfdtsna, o, dna); ldv<R, V>(U.dfdtscna, o, dcna); }
+    const bool edge = K == 0 || K == lm;
+    R fx[V], fc[V], fxa[V], fca[V];
+    VFOR { fx[v] = 0; fc[v] = 0; fxa[v] = 0; fca[v] = 0; }
+    if (U.flx || edge) ldv<R, V>(U.flx_int, o, fx);
+    if (U.flc || edge) ldv<R, V>(U.flc_int, o, fc);
+    if (!rr && (U.flxa || edge)) ldv<R, V>(U.flxa_int, o, fxa);
+    if (!rr && (U.fla || edge)) ldv<R, V>(U.fla_int, o, fca);
     // net downward, negated upward (linearised), downward (not linearised)
-    if (U.flx) U.flx[o] = U.flx_int[o] + d * delt;
-    if (U.flc) U.flc[o] = U.flc_int[o] + dc * delt;
-    if (U.flxu) U.flxu[o] = U.flxu_int[o] + d * delt;
-    if (U.flcu) U.flcu[o] = U.flcu_int[o] + dc * delt;
-    if (U.flxd) U.flxd[o] = U.flxd_int[o];
-    if (U.flcd) U.flcd[o] = U.flcd_int[o];
-    if (U.flxa) U.flxa[o] = rr ? U.undef : U.flxa_int[o] + dna * delt;
-    if (U.fla) U.fla[o] = rr ? U.undef : U.fla_int[o] + dcna * delt;
-    if (U.flxau) U.flxau[o] = rr ? U.undef : U.flxau_int[o] + dna * delt;
-    if (U.flau) U.flau[o] = rr ? U.undef : U.flau_int[o] + dcna * delt;
-    if (U.flxad) U.flxad[o] = rr ? U.undef : U.flxad_int[o];
-    if (U.flad) U.flad[o] = rr ? U.undef : U.flad_int[o];
-    if (K != 0 && K != lm) return;
+    VSET(U.flx, o, fx[v] + d[v] * delt[v]);
+    VSET(U.flc, o, fc[v] + dc[v] * delt[v]);
+    if (U.flxu) { ldv<R, V>(U.flxu_int, o, a); VSET(U.flxu, o, a[v] + d[v] * delt[v]); }
+    if (U.flcu) { ldv<R, V>(U.flcu_int, o, a); VSET(U.flcu, o, a[v] + dc[v] * delt[v]); }
+    if (U.flxd) { ldv<R, V>(U.flxd_int, o, a); VSET(U.flxd, o, a[v]); }
+    if (U.flcd) { ldv<R, V>(U.flcd_int, o, a); VSET(U.flcd, o, a[v]); }
+    VSET(U.flxa, o, rr ? undef : fxa[v] + dna[v] * delt[v]);
+    VSET(U.fla, o, rr ? undef : fca[v] + dcna[v] * delt[v]);
+    if (U.flxau) { if (!rr) ldv<R, V>(U.flxau_int, o, a); VSET(U.flxau, o, rr ? undef : a[v] + dna[v] * delt[v]); }
+    if (U.flau) { if (!rr) ldv<R, V>(U.flau_int, o, a); VSET(U.flau, o, rr ? undef : a[v] + dcna[v] * delt[v]); }
+    if (U.flxad) { if (!rr) ldv<R, V>(U.flxad_int, o, a); VSET(U.flxad, o, rr ? undef : a[v]); }
+    if (U.flad) { if (!rr) ldv<R, V>(U.flad_int, o, a); VSET(U.flad, o, rr ? undef : a[v]); }
+    if (!edge) return;
     // 2-D total cloud fraction, max overlap within / random between the super-layers (IRR:3831-3846)
-    R cldtt = 0;
-    const bool need_cld = U.cldtt || U.olcc5 || U.lcsc5;
-    if (need_cld) {
-        R a = 0, b = 0, c = 0;
-        for (int k = 1; k <= U.lev_mid_high - 1; k++) { const R f = U.fcld[(size_t)(k - 1) * n + ij]; a = a > f ? a : f; }
-        for (int k = U.lev_mid_high; k <= U.lev_low_mid - 1; k++) { const R f = U.fcld[(size_t)(k - 1) * n + ij]; b = b > f ? b : f; }
-        for (int k = U.lev_low_mid; k <= lm; k++) { const R f = U.fcld[(size_t)(k - 1) * n + ij]; c = c > f ? c : f; }
-        R x = ((R)1 - a);
-        x = x * ((R)1 - b);
-        cldtt = (R)1.0 - x * ((R)1 - c);
+    R cldtt[V];
+    VFOR cldtt[v] = 0;
+    if (U.cldtt || U.olcc5 || U.lcsc5) {
+        R m1[V], m2[V], m3[V];
+        VFOR { m1[v] = 0; m2[v] = 0; m3[v] = 0; }
+        for (int k = 1; k <= U.lev_mid_high - 1; k++) { ldv<R, V>(U.fcld, (size_t)(k - 1) * n + ij, b); VFOR m1[v] = m1[v] > b[v] ? m1[v] : b[v]; }
+        for (int k = U.lev_mid_high; k <= U.lev_low_mid - 1; k++) { ldv<R, V>(U.fcld, (size_t)(k - 1) * n + ij, b); VFOR m2[v] = m2[v] > b[v] ? m2[v] : b[v]; }
+        for (int k = U.lev_low_mid; k <= lm; k++) { ldv<R, V>(U.fcld, (size_t)(k - 1) * n + ij, b); VFOR m3[v] = m3[v] > b[v] ? m3[v] : b[v]; }
+        VFOR {
+            R x = ((R)1 - m1[v]);
+            x = x * ((R)1 - m2[v]);
+            cldtt[v] = (R)1.0 - x * ((R)1 - m3[v]);
+        }
     }
     if (K == 0) {
         // TOA: outgoing longwave radiation (IRR:3879-3893)
-        if (U.olr) U.olr[ij] = -(U.flx_int[o] + d * delt);
-        if (U.olc) U.olc[ij] = -(U.flc_int[o] + dc * delt);
-        if (U.olra) U.olra[ij] = rr ? U.undef : -(U.flxa_int[o] + dna * delt);
-        if (U.ola) U.ola[ij] = rr ? U.undef : -(U.fla_int[o] + dcna * delt);
-        if (U.olcc5) U.olcc5[ij] = cldtt <= (R)0.05 ? -(U.flc_int[o] + dc * delt) : U.undef;
-        if (U.cldtt) U.cldtt[ij] = cldtt;
+        VSET(U.olr, ij, -(fx[v] + d[v] * delt[v]));
+        VSET(U.olc, ij, -(fc[v] + dc[v] * delt[v]));
+        VSET(U.olra, ij, rr ? undef : -(fxa[v] + dna[v] * delt[v]));
+        VSET(U.ola, ij, rr ? undef : -(fca[v] + dcna[v] * delt[v]));
+        VSET(U.olcc5, ij, cldtt[v] <= (R)0.05 ? -(fc[v] + dc[v] * delt[v]) : undef);
+        VSET(U.cldtt, ij, cldtt[v]);
     }
     if (K == lm) {
         // surface (IRR:3895-3925, :3991-3999)
-        const R se = U.sfcem_int[ij];
-        if (U.dsfdts) U.dsfdts[ij] = -d;
-        if (U.sfcem) U.sfcem[ij] = se - d * delt;
-        if (U.lws) U.lws[ij] = U.flx_int[o] + se;
-        if (U.lcs) U.lcs[ij] = U.flc_int[o] + se;
-        if (U.lwsa) U.lwsa[ij] = rr ? U.undef : U.flxa_int[o] + se;
-        if (U.las) U.las[ij] = rr ? U.undef : U.fla_int[o] + se;
-        if (U.lcsc5) U.lcsc5[ij] = cldtt <= (R)0.05 ? U.flc_int[o] + se : U.undef;
-        if (U.flns) U.flns[ij] = U.flx_int[o] + d * delt;
-        if (U.flnsc) U.flnsc[ij] = U.flc_int[o] + dc * delt;
-        if (U.flnsna) U.flnsna[ij] = rr ? U.undef : U.flxa_int[o] + dna * delt;
-        if (U.flnsa) U.flnsa[ij] = rr ? U.undef : U.fla_int[o] + dcna * delt;
-        if (U.dsfdts0) U.dsfdts0[ij] = -d;
-        if (U.sfcem0) U.sfcem0[ij] = se - d * delt;
-        if (U.tsreff) U.tsreff[ij] = U.tsinst[ij];
+        R se[V];
+        ldv<R, V>(U.sfcem_int, ij, se);
+        VSET(U.dsfdts, ij, -d[v]);
+        VSET(U.sfcem, ij, se[v] - d[v] * delt[v]);
+        VSET(U.lws, ij, fx[v] + se[v]);
+        VSET(U.lcs, ij, fc[v] + se[v]);
+        VSET(U.lwsa, ij, rr ? undef : fxa[v] + se[v]);
+        VSET(U.las, ij, rr ? undef : fca[v] + se[v]);
+        VSET(U.lcsc5, ij, cldtt[v] <= (R)0.05 ? fc[v] + se[v] : undef);
+        VSET(U.flns, ij, fx[v] + d[v] * delt[v]);
+        VSET(U.flnsc, ij, fc[v] + dc[v] * delt[v]);
+        VSET(U.flnsna, ij, rr ? undef : fxa[v] + dna[v] * delt[v]);
+        VSET(U.flnsa, ij, rr ? undef : fca[v] + dcna[v] * delt[v]);
+        VSET(U.dsfdts0, ij, -d[v]);
+        VSET(U.sfcem0, ij, se[v] - d[v] * delt[v]);
+        VSET(U.tsreff, ij, tsi[v]);
     }
 }
 
@@ -417,55 +450,61 @@ template <typename R> struct SwUpd {
     R *rsr, *rsc, *rsrna, *rscna, *rsrs, *rscs, *rsrsna, *rscsna, *osr, *osrclr, *osrna, *osrcna;
 };
 
-// blockIdx.y = level 0..LM, then the bands
-template <typename R> __global__ void __launch_bounds__(256) k_sw_update_export(SwUpd<R> U)
+// blockIdx.y = level 0..LM, then the bands; V columns per thread
+template <typename R, int V> __global__ void __launch_bounds__(256) k_sw_update_export(SwUpd<R> U)
 {
 #pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ij = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (ij >= U.ncol) return;
     const int n = U.ncol, lm = U.lm;
-    const R slr = U.slr[ij];
+    R slr[V], a[V];
+    ldv<R, V>(U.slr, ij, slr);
     if ((int)blockIdx.y > lm) {
         const size_t o = (size_t)(blockIdx.y - lm - 1) * n + ij;
-        if (U.fswband) U.fswband[o] = U.fswbandn[o] * slr;
-        if (U.fswbandna) U.fswbandna[o] = U.fswbandnan[o] * slr;
+        if (U.fswband) { ldv<R, V>(U.fswbandn, o, a); VSET(U.fswband, o, a[v] * slr[v]); }
+        if (U.fswbandna) { ldv<R, V>(U.fswbandnan, o, a); VSET(U.fswbandna, o, a[v] * slr[v]); }
         return;
     }
     const int L = blockIdx.y;
     const size_t o = (size_t)L * n + ij;
     const bool edge = L == 0 || L == lm;
-    R w = 0, c = 0, wna = 0, cna = 0;
-    if (U.fsw || U.fswd || (edge && (U.rsr || U.rsrs || U.osr))) w = U.fswn[o];
-    if (U.fsc || U.fscd || (edge && (U.rsc || U.rscs || U.osrclr))) c = U.fscn[o];
-    if (U.fswna || U.fswdna || (edge && (U.rsrna || U.rsrsna || U.osrna))) wna = U.fswnan[o];
-    if (U.fscna || U.fscdna || (edge && (U.rscna || U.rscsna || U.osrcna))) cna = U.fscnan[o];
-    if (U.fsw) U.fsw[o] = w * slr;
-    if (U.fsc) U.fsc[o] = c * slr;
-    if (U.fswna) U.fswna[o] = wna * slr;
-    if (U.fscna) U.fscna[o] = cna * slr;
-    if (U.fswu) U.fswu[o] = U.fswun[o] * slr;
-    if (U.fscu) U.fscu[o] = U.fscun[o] * slr;
-    if (U.fswuna) U.fswuna[o] = U.fswunan[o] * slr;
-    if (U.fscuna) U.fscuna[o] = U.fscunan[o] * slr;
-    if (U.fswd) U.fswd[o] = (w + U.fswun[o]) * slr;
-    if (U.fscd) U.fscd[o] = (c + U.fscun[o]) * slr;
-    if (U.fswdna) U.fswdna[o] = (wna + U.fswunan[o]) * slr;
-    if (U.fscdna) U.fscdna[o] = (cna + U.fscunan[o]) * slr;
+    R w[V], c[V], wna[V], cna[V], wu[V], cu[V], wuna[V], cuna[V];
+    VFOR { w[v] = 0; c[v] = 0; wna[v] = 0; cna[v] = 0; wu[v] = 0; cu[v] = 0; wuna[v] = 0; cuna[v] = 0; }
+    if (U.fsw || U.fswd || (edge && (U.rsr || U.rsrs || U.osr))) ldv<R, V>(U.fswn, o, w);
+    if (U.fsc || U.fscd || (edge && (U.rsc || U.rscs || U.osrclr))) ldv<R, V>(U.fscn, o, c);
+    if (U.fswna || U.fswdna || (edge && (U.rsrna || U.rsrsna || U.osrna))) ldv<R, V>(U.fswnan, o, wna);
+    if (U.fscna || U.fscdna || (edge && (U.rscna || U.rscsna || U.osrcna))) ldv<R, V>(U.fscnan, o, cna);
+    if (U.fswu || U.fswd) ldv<R, V>(U.fswun, o, wu);
+    if (U.fscu || U.fscd) ldv<R, V>(U.fscun, o, cu);
+    if (U.fswuna || U.fswdna) ldv<R, V>(U.fswunan, o, wuna);
+    if (U.fscuna || U.fscdna) ldv<R, V>(U.fscunan, o, cuna);
+    VSET(U.fsw, o, w[v] * slr[v]);
+    VSET(U.fsc, o, c[v] * slr[v]);
+    VSET(U.fswna, o, wna[v] * slr[v]);
+    VSET(U.fscna, o, cna[v] * slr[v]);
+    VSET(U.fswu, o, wu[v] * slr[v]);
+    VSET(U.fscu, o, cu[v] * slr[v]);
+    VSET(U.fswuna, o, wuna[v] * slr[v]);
+    VSET(U.fscuna, o, cuna[v] * slr[v]);
+    VSET(U.fswd, o, (w[v] + wu[v]) * slr[v]);
+    VSET(U.fscd, o, (c[v] + cu[v]) * slr[v]);
+    VSET(U.fswdna, o, (wna[v] + wuna[v]) * slr[v]);
+    VSET(U.fscdna, o, (cna[v] + cuna[v]) * slr[v]);
     if (L == 0) {
-        if (U.rsr) U.rsr[ij] = w * slr;
-        if (U.rsc) U.rsc[ij] = c * slr;
-        if (U.rsrna) U.rsrna[ij] = wna * slr;
-        if (U.rscna) U.rscna[ij] = cna * slr;
-        if (U.osr) U.osr[ij] = ((R)1. - w) * slr;
-        if (U.osrclr) U.osrclr[ij] = ((R)1. - c) * slr;
-        if (U.osrna) U.osrna[ij] = ((R)1. - wna) * slr;
-        if (U.osrcna) U.osrcna[ij] = ((R)1. - cna) * slr;
+        VSET(U.rsr, ij, w[v] * slr[v]);
+        VSET(U.rsc, ij, c[v] * slr[v]);
+        VSET(U.rsrna, ij, wna[v] * slr[v]);
+        VSET(U.rscna, ij, cna[v] * slr[v]);
+        VSET(U.osr, ij, ((R)1. - w[v]) * slr[v]);
+        VSET(U.osrclr, ij, ((R)1. - c[v]) * slr[v]);
+        VSET(U.osrna, ij, ((R)1. - wna[v]) * slr[v]);
+        VSET(U.osrcna, ij, ((R)1. - cna[v]) * slr[v]);
     }
     if (L == lm) {
-        if (U.rsrs) U.rsrs[ij] = w * slr;
-        if (U.rscs) U.rscs[ij] = c * slr;
-        if (U.rsrsna) U.rsrsna[ij] = wna * slr;
-        if (U.rscsna) U.rscsna[ij] = cna * slr;
+        VSET(U.rsrs, ij, w[v] * slr[v]);
+        VSET(U.rscs, ij, c[v] * slr[v]);
+        VSET(U.rsrsna, ij, wna[v] * slr[v]);
+        VSET(U.rscsna, ij, cna[v] * slr[v]);
     }
 }
 
@@ -481,27 +520,39 @@ template <typename R> struct RadTend {
     R *blw, *alw, *radsrf;
 };
 
-template <typename R> __global__ void __launch_bounds__(256) k_rad_tendencies(RadTend<R> P)
+template <typename R, int V> __global__ void __launch_bounds__(256) k_rad_tendencies(RadTend<R> P)
 {
 #pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ij = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (ij >= P.ncol) return;
     const int n = P.ncol, lm = P.lm, k = blockIdx.y;      // layer k+1 lies between levels k and k+1
     const size_t t = (size_t)k * n + ij, b = (size_t)(k + 1) * n + ij;
-    if (P.dtdt) P.dtdt[t] = ((P.flw[t] - P.flw[b]) + (P.fsw[t] - P.fsw[b])) * (P.grav / P.cp);
-    const R dmi = P.grav / (P.cp * (P.ple[b] - P.ple[t]));
-    if (P.radlw) P.radlw[t] = (P.flw[t] - P.flw[b]) * dmi;
-    if (P.radsw) P.radsw[t] = (P.fsw[t] - P.fsw[b]) * dmi;
-    if (P.radlwc) P.radlwc[t] = (P.flwclr[t] - P.flwclr[b]) * dmi;
-    if (P.radswc) P.radswc[t] = (P.fswclr[t] - P.fswclr[b]) * dmi;
-    if (P.radswna) P.radswna[t] = (P.fswna[t] - P.fswna[b]) * dmi;
-    if (P.radlwcna) P.radlwcna[t] = (P.fla[t] - P.fla[b]) * dmi;
-    if (P.radswcna) P.radswcna[t] = (P.fscna[t] - P.fscna[b]) * dmi;
-    if (k == lm - 1) {
-        if (P.blw) P.blw[ij] = P.dsfdts[ij];
-        if (P.alw) P.alw[ij] = P.sfcem[ij] - P.dsfdts[ij] * P.trd[ij];
-        if (P.radsrf) P.radsrf[ij] = P.fsw[b] + P.flw[b];
+    const R gcp = P.grav / P.cp;
+    R lt[V], lb[V], st[V], sb[V], x[V], y[V], dmi[V];
+    VFOR { lt[v] = 0; lb[v] = 0; st[v] = 0; sb[v] = 0; dmi[v] = 0; }
+    const bool last = k == lm - 1;
+    if (P.dtdt || P.radlw || (last && P.radsrf)) { ldv<R, V>(P.flw, t, lt); ldv<R, V>(P.flw, b, lb); }
+    if (P.dtdt || P.radsw || (last && P.radsrf)) { ldv<R, V>(P.fsw, t, st); ldv<R, V>(P.fsw, b, sb); }
+    VSET(P.dtdt, t, ((lt[v] - lb[v]) + (st[v] - sb[v])) * gcp);
+    if (P.radlw || P.radsw || P.radlwc || P.radswc || P.radswna || P.radlwcna || P.radswcna) {
+        ldv<R, V>(P.ple, t, x); ldv<R, V>(P.ple, b, y);
+        VFOR dmi[v] = P.grav / (P.cp * (y[v] - x[v]));
+    }
+    VSET(P.radlw, t, (lt[v] - lb[v]) * dmi[v]);
+    VSET(P.radsw, t, (st[v] - sb[v]) * dmi[v]);
+    if (P.radlwc) { ldv<R, V>(P.flwclr, t, x); ldv<R, V>(P.flwclr, b, y); VSET(P.radlwc, t, (x[v] - y[v]) * dmi[v]); }
+    if (P.radswc) { ldv<R, V>(P.fswclr, t, x); ldv<R, V>(P.fswclr, b, y); VSET(P.radswc, t, (x[v] - y[v]) * dmi[v]); }
+    if (P.radswna) { ldv<R, V>(P.fswna, t, x); ldv<R, V>(P.fswna, b, y); VSET(P.radswna, t, (x[v] - y[v]) * dmi[v]); }
+    if (P.radlwcna) { ldv<R, V>(P.fla, t, x); ldv<R, V>(P.fla, b, y); VSET(P.radlwcna, t, (x[v] - y[v]) * dmi[v]); }
+    if (P.radswcna) { ldv<R, V>(P.fscna, t, x); ldv<R, V>(P.fscna, b, y); VSET(P.radswcna, t, (x[v] - y[v]) * dmi[v]); }
+    if (last) {
+        if (P.blw) { ldv<R, V>(P.dsfdts, ij, x); VSET(P.blw, ij, x[v]); }
+        if (P.alw) { R se[V], tr[V]; ldv<R, V>(P.dsfdts, ij, x); ldv<R, V>(P.sfcem, ij, se); ldv<R, V>(P.trd, ij, tr); VSET(P.alw, ij, se[v] - x[v] * tr[v]); }
+        VSET(P.radsrf, ij, sb[v] + lb[v]);
     }
 }
+
+#undef VFOR
+#undef VSET
 
 }  // namespace geosrad

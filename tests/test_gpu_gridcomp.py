@@ -123,12 +123,13 @@ def test_sw_driver_equals_oracle_prep_gpu_solver_oracle_post(gpu_ctx, rk):
     assert (o["COTLP"] == consts[-1]).any() and (o["COTLP"] != consts[-1]).any()
 
 
+@pytest.mark.parametrize("n", [776, 777])       # 16-byte accesses (4 / 2 columns per thread) and the scalar fall-back
 @pytest.mark.parametrize("rk", [4, 8])
-def test_update_flx_export_and_tendencies_match_the_oracle(gpu_ctx, rk):
+def test_update_flx_export_and_tendencies_match_the_oracle(gpu_ctx, rk, n):
     from oracle import clib
     ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
     rng = np.random.default_rng(31)
-    lm, n, lmh, llm = 72, 777, 30, 47
+    lm, lmh, llm = 72, 30, 47
     st = {k: rng.uniform(-400, 400, (lm + 1, n)) for k in G.LWU_IN if k not in ("TSINST", "TS_INT", "SFCEM_INT", "FCLD")}
     st["TSINST"] = rng.uniform(270, 300, n); st["TS_INT"] = st["TSINST"] + rng.uniform(-3, 3, n); st["SFCEM_INT"] = rng.uniform(300, 450, n)
     st["FCLD"] = rng.uniform(0, 1, (lm, n)) * (rng.uniform(0, 1, (lm, n)) < 0.02)
