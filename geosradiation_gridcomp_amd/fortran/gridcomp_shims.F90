@@ -1,0 +1,207 @@
+! gridcomp_shims.F90 -- Fortran view of the GridComp data-path entry points of include/geosrad.h (SURVEY section 8f rows 1-2): what
+! GEOS_IrradGridComp's LW_Driver / Update_Flx, GEOS_SolarGridComp's SORADCORE / UPDATE_EXPORT and the parent's RUN call once their
+! fields live in device memory.  Field lists are passed as arrays of C pointers indexed by the LWD_* / SWD_* / LWU_* / SWU_* / RT_*
+! parameters below (1-based mirrors of the GEOSRAD_* enums); c_null_ptr = "not associated".  The small hip* interface block is all a
+! GridComp needs to keep its INTERNAL state on the device between the full calculation and the heartbeat updates.
+module geosrad_gridcomp
+   use iso_c_binding
+   use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
+   implicit none
+   private
+   public :: lw_driver_rrtmg, sw_driver_rrtmg, lw_update_flx, sw_update_export, rad_tendencies
+   public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
+
+   ! ---- GEOSRAD_LWD_* ----
+   integer, parameter, public :: LWD_PLE = 1, LWD_PL = 2, LWD_T = 3, LWD_Q = 4, LWD_O3 = 5, LWD_CH4 = 6, LWD_N2O = 7, LWD_CO2_3D = 8, &
+      LWD_CFC11 = 9, LWD_CFC12 = 10, LWD_HCFC22 = 11, LWD_FCLD = 12, LWD_CWC_LIQ = 13, LWD_CWC_ICE = 14, LWD_REFF_LIQ = 15, &
+      LWD_REFF_ICE = 16, LWD_TAUA = 17, LWD_SSAA = 18, LWD_TS = 19, LWD_EMIS = 20, LWD_LATS = 21, LWD_T2M = 22, LWD_NIN = 22
+   integer, parameter, public :: LWD_C_CO2_FIXED = 1, LWD_C_O2 = 2, LWD_C_CCL4 = 3, LWD_C_AIRMW = 4, LWD_C_H2OMW = 5, LWD_C_O3MW = 6, &
+      LWD_C_RGAS = 7, LWD_C_GRAV = 8, LWD_NCONST = 8
+   integer, parameter, public :: LWD_FLXU_INT = 1, LWD_FLXD_INT = 2, LWD_FLCU_INT = 3, LWD_FLCD_INT = 4, LWD_DFDTS = 5, LWD_DFDTSC = 6, &
+      LWD_DFDTSNA = 7, LWD_DFDTSCNA = 8, LWD_FLX_INT = 9, LWD_FLC_INT = 10, LWD_SFCEM_INT = 11, LWD_TS_INT = 12, LWD_CLDTTLW = 13, &
+      LWD_CLDHILW = 14, LWD_CLDMDLW = 15, LWD_CLDLOLW = 16, LWD_OLRB = 17, LWD_DOLRB = 18, LWD_NOUT = 18
+   ! ---- GEOSRAD_SWD_* ----
+   integer, parameter, public :: SWD_PLE = 1, SWD_PL = 2, SWD_T = 3, SWD_Q = 4, SWD_O3 = 5, SWD_CH4 = 6, SWD_CL = 7, SWD_TS = 8, &
+      SWD_QQ_ICE = 9, SWD_QQ_LIQ = 10, SWD_RR_ICE = 11, SWD_RR_LIQ = 12, SWD_TAUA = 13, SWD_SSAA = 14, SWD_ASYA = 15, SWD_ZT = 16, &
+      SWD_ALAT = 17, SWD_ALBVR = 18, SWD_ALBVF = 19, SWD_ALBNR = 20, SWD_ALBNF = 21, SWD_NIN = 21
+   integer, parameter, public :: SWD_C_CO2 = 1, SWD_C_O2 = 2, SWD_C_AIRMW = 3, SWD_C_H2OMW = 4, SWD_C_O3MW = 5, SWD_C_RGAS = 6, &
+      SWD_C_GRAV = 7, SWD_C_UNDEF = 8, SWD_NCONST = 8
+   integer, parameter, public :: SWD_FSW = 1, SWD_FSC = 2, SWD_FSWU = 3, SWD_FSCU = 4, SWD_NIRR = 5, SWD_NIRF = 6, SWD_PARR = 7, &
+      SWD_PARF = 8, SWD_UVRR = 9, SWD_UVRF = 10, SWD_FSWBAND = 11, SWD_CLDTS = 12, SWD_CLDHS = 13, SWD_CLDMS = 14, SWD_CLDLS = 15, &
+      SWD_COTTP = 16, SWD_COTHP = 17, SWD_COTMP = 18, SWD_COTLP = 19, SWD_NOUT = 19
+   ! ---- GEOSRAD_LWU_* ----
+   integer, parameter, public :: LWU_TSINST = 1, LWU_TS_INT = 2, LWU_SFCEM_INT = 3, LWU_FCLD = 4, LWU_FLX_INT = 5, LWU_FLXA_INT = 6, &
+      LWU_FLC_INT = 7, LWU_FLA_INT = 8, LWU_FLXU_INT = 9, LWU_FLXAU_INT = 10, LWU_FLCU_INT = 11, LWU_FLAU_INT = 12, LWU_FLXD_INT = 13, &
+      LWU_FLXAD_INT = 14, LWU_FLCD_INT = 15, LWU_FLAD_INT = 16, LWU_DFDTS = 17, LWU_DFDTSNA = 18, LWU_DFDTSC = 19, LWU_DFDTSCNA = 20, &
+      LWU_NIN = 20
+   integer, parameter, public :: LWU_FLX = 1, LWU_FLXA = 2, LWU_FLC = 3, LWU_FLA = 4, LWU_FLXU = 5, LWU_FLXAU = 6, LWU_FLCU = 7, &
+      LWU_FLAU = 8, LWU_FLXD = 9, LWU_FLXAD = 10, LWU_FLCD = 11, LWU_FLAD = 12, LWU_OLR = 13, LWU_OLRA = 14, LWU_OLC = 15, LWU_OLA = 16, &
+      LWU_OLCC5 = 17, LWU_DSFDTS = 18, LWU_SFCEM = 19, LWU_LWS = 20, LWU_LWSA = 21, LWU_LCS = 22, LWU_LAS = 23, LWU_LCSC5 = 24, &
+      LWU_FLNS = 25, LWU_FLNSNA = 26, LWU_FLNSC = 27, LWU_FLNSA = 28, LWU_DSFDTS0 = 29, LWU_SFCEM0 = 30, LWU_TSREFF = 31, &
+      LWU_CLDTT = 32, LWU_NOUT = 32
+   ! ---- GEOSRAD_SWU_* ----
+   integer, parameter, public :: SWU_SLR = 1, SWU_FSWN = 2, SWU_FSCN = 3, SWU_FSWNAN = 4, SWU_FSCNAN = 5, SWU_FSWUN = 6, SWU_FSCUN = 7, &
+      SWU_FSWUNAN = 8, SWU_FSCUNAN = 9, SWU_FSWBANDN = 10, SWU_FSWBANDNAN = 11, SWU_NIN = 11
+   integer, parameter, public :: SWU_FSW = 1, SWU_FSC = 2, SWU_FSWNA = 3, SWU_FSCNA = 4, SWU_FSWU = 5, SWU_FSCU = 6, SWU_FSWUNA = 7, &
+      SWU_FSCUNA = 8, SWU_FSWD = 9, SWU_FSCD = 10, SWU_FSWDNA = 11, SWU_FSCDNA = 12, SWU_FSWBAND = 13, SWU_FSWBANDNA = 14, SWU_RSR = 15, &
+      SWU_RSC = 16, SWU_RSRNA = 17, SWU_RSCNA = 18, SWU_RSRS = 19, SWU_RSCS = 20, SWU_RSRSNA = 21, SWU_RSCSNA = 22, SWU_OSR = 23, &
+      SWU_OSRCLR = 24, SWU_OSRNA = 25, SWU_OSRCNA = 26, SWU_NOUT = 26
+   ! ---- GEOSRAD_RT_* ----
+   integer, parameter, public :: RT_PLE = 1, RT_FLW = 2, RT_FSW = 3, RT_FLWCLR = 4, RT_FSWCLR = 5, RT_FSWNA = 6, RT_FLA = 7, RT_FSCNA = 8, &
+      RT_DSFDTS = 9, RT_SFCEM = 10, RT_TRD = 11, RT_NIN = 11
+   integer, parameter, public :: RT_DTDT = 1, RT_RADLW = 2, RT_RADSW = 3, RT_RADLWC = 4, RT_RADSWC = 5, RT_RADSWNA = 6, RT_RADLWCNA = 7, &
+      RT_RADSWCNA = 8, RT_BLW = 9, RT_ALW = 10, RT_RADSRF = 11, RT_NOUT = 11
+
+   interface
+      integer(c_int) function geosrad_lw_driver_rrtmg_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflglw, liqflglw, doy, lcldlm, &
+            lcldmh, band_output, fout) bind(C, name='geosrad_lw_driver_rrtmg_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm, nb_aer, iceflglw, liqflglw, doy, lcldlm, lcldmh
+         type(c_ptr), intent(in) :: fin(*), fout(*)
+         real(c_double), intent(in) :: consts(*)
+         integer(c_int), intent(in) :: band_output(*)
+      end function
+      integer(c_int) function geosrad_sw_driver_rrtmg_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflgsw, liqflgsw, sc, dist, isolvar, &
+            dyofyr, include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, fout) bind(C, name='geosrad_sw_driver_rrtmg_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream, bndsolvar, indsolvar
+         integer(c_int), value :: ncol, lm, nb_aer, iceflgsw, liqflgsw, isolvar, dyofyr, include_aerosols, lcldlm, lcldmh, normflx
+         real(c_double), value :: sc, dist
+         type(c_ptr), intent(in) :: fin(*), fout(*)
+         real(c_double), intent(in) :: consts(*)
+      end function
+      integer(c_int) function geosrad_lw_update_flx_dev(ctx, stream, ncol, lm, rrtmg, lev_mid_high, lev_low_mid, undef, fin, fout) &
+            bind(C, name='geosrad_lw_update_flx_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm, rrtmg, lev_mid_high, lev_low_mid
+         real(c_double), value :: undef
+         type(c_ptr), intent(in) :: fin(*), fout(*)
+      end function
+      integer(c_int) function geosrad_sw_update_export_dev(ctx, stream, ncol, lm, nbands, fin, fout) bind(C, name='geosrad_sw_update_export_dev')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm, nbands
+         type(c_ptr), intent(in) :: fin(*), fout(*)
+      end function
+      integer(c_int) function geosrad_rad_tendencies_dev(ctx, stream, ncol, lm, grav, cp, fin, fout) bind(C, name='geosrad_rad_tendencies_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm
+         real(c_double), value :: grav, cp
+         type(c_ptr), intent(in) :: fin(*), fout(*)
+      end function
+      integer(c_int) function geosrad_check(ctx, stream) bind(C, name='geosrad_check')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx, stream
+      end function
+      ! HIP runtime (libamdhip64): device memory for the GridComp's fields
+      integer(c_int) function hipMalloc(p, bytes) bind(C, name='hipMalloc')
+         import :: c_int, c_ptr, c_size_t
+         type(c_ptr), intent(out) :: p
+         integer(c_size_t), value :: bytes
+      end function
+      integer(c_int) function hipFree(p) bind(C, name='hipFree')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: p
+      end function
+      integer(c_int) function hipMemcpy(dst, src, bytes, kind) bind(C, name='hipMemcpy')
+         import :: c_int, c_ptr, c_size_t
+         type(c_ptr), value :: dst, src
+         integer(c_size_t), value :: bytes
+         integer(c_int), value :: kind
+      end function
+      integer(c_int) function hipDeviceSynchronize() bind(C, name='hipDeviceSynchronize')
+         import :: c_int
+      end function
+   end interface
+
+contains
+
+   function dev_alloc(nreal) result(p)
+      integer, intent(in) :: nreal
+      type(c_ptr) :: p
+      real :: x
+      type(c_ptr) :: h
+      h = geosrad_ctx_handle()          ! selects the device
+      if (hipMalloc(p, int(nreal, c_size_t) * int(storage_size(x) / 8, c_size_t)) /= 0) error stop 'geosrad_gridcomp: hipMalloc failed'
+   end function
+   subroutine dev_free(p)
+      type(c_ptr), intent(inout) :: p
+      if (c_associated(p)) then
+         if (hipFree(p) /= 0) error stop 'geosrad_gridcomp: hipFree failed'
+      end if
+      p = c_null_ptr
+   end subroutine
+   subroutine dev_put(p, a, n)
+      type(c_ptr), intent(in) :: p
+      integer, intent(in) :: n
+      real, intent(in), target :: a(n)
+      if (hipMemcpy(p, c_loc(a), int(n, c_size_t) * int(storage_size(a) / 8, c_size_t), 1_c_int) /= 0) error stop 'geosrad_gridcomp: H2D copy failed'
+   end subroutine
+   subroutine dev_get(a, p, n)
+      integer, intent(in) :: n
+      real, intent(out), target :: a(n)
+      type(c_ptr), intent(in) :: p
+      if (hipMemcpy(c_loc(a), p, int(n, c_size_t) * int(storage_size(a) / 8, c_size_t), 2_c_int) /= 0) error stop 'geosrad_gridcomp: D2H copy failed'
+   end subroutine
+   subroutine dev_sync()
+      if (geosrad_check(geosrad_ctx_handle(), c_null_ptr) /= 0) call geosrad_fail('geosrad_gridcomp')
+      if (hipDeviceSynchronize() /= 0) error stop 'geosrad_gridcomp: device error'
+   end subroutine
+
+   ! RRTMG branch of LW_Driver (GEOS_IrradGridComp.F90:3188-3615); lcldlm / lcldmh in model ordering
+   subroutine lw_driver_rrtmg(ncol, lm, nb_aer, fin, consts, iceflglw, liqflglw, doy, lcldlm, lcldmh, band_output, fout)
+      integer, intent(in) :: ncol, lm, nb_aer, iceflglw, liqflglw, doy, lcldlm, lcldmh
+      type(c_ptr), intent(in) :: fin(LWD_NIN), fout(LWD_NOUT)
+      real(c_double), intent(in) :: consts(LWD_NCONST)
+      logical, intent(in) :: band_output(16)
+      integer(c_int) :: bo(16)
+      bo = merge(1_c_int, 0_c_int, band_output)
+      if (geosrad_lw_driver_rrtmg_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, consts, &
+            int(iceflglw,c_int), int(liqflglw,c_int), int(doy,c_int), int(lcldlm,c_int), int(lcldmh,c_int), bo, fout) /= 0) &
+         call geosrad_fail('LW_Driver (RRTMG)')
+   end subroutine
+
+   ! RRTMG branch of SORADCORE (GEOS_SolarGridComp.F90:6113-6450) on the packed daytime columns
+   subroutine sw_driver_rrtmg(ncol, lm, nb_aer, fin, consts, iceflgsw, liqflgsw, sc, dist, isolvar, dyofyr, include_aerosols, lcldlm, &
+         lcldmh, fout, rc)
+      integer, intent(in) :: ncol, lm, nb_aer, iceflgsw, liqflgsw, isolvar, dyofyr, lcldlm, lcldmh
+      logical, intent(in) :: include_aerosols
+      real, intent(in) :: sc, dist
+      type(c_ptr), intent(in) :: fin(SWD_NIN), fout(SWD_NOUT)
+      real(c_double), intent(in) :: consts(SWD_NCONST)
+      integer, intent(out) :: rc
+      rc = geosrad_sw_driver_rrtmg_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, consts, &
+            int(iceflgsw,c_int), int(liqflgsw,c_int), real(sc,c_double), real(dist,c_double), int(isolvar,c_int), int(dyofyr,c_int), &
+            merge(1_c_int, 0_c_int, include_aerosols), int(lcldlm,c_int), int(lcldmh,c_int), 1_c_int, c_null_ptr, c_null_ptr, fout)
+   end subroutine
+
+   ! Update_Flx (GEOS_IrradGridComp.F90:3796-3999)
+   subroutine lw_update_flx(ncol, lm, use_rrtmg, lev_mid_high, lev_low_mid, undef, fin, fout)
+      integer, intent(in) :: ncol, lm, lev_mid_high, lev_low_mid
+      logical, intent(in) :: use_rrtmg
+      real, intent(in) :: undef
+      type(c_ptr), intent(in) :: fin(LWU_NIN), fout(LWU_NOUT)
+      if (geosrad_lw_update_flx_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), merge(1_c_int, 0_c_int, use_rrtmg), &
+            int(lev_mid_high,c_int), int(lev_low_mid,c_int), real(undef,c_double), fin, fout) /= 0) call geosrad_fail('Update_Flx')
+   end subroutine
+
+   ! flux part of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7540-7579)
+   subroutine sw_update_export(ncol, lm, nbands, fin, fout)
+      integer, intent(in) :: ncol, lm, nbands
+      type(c_ptr), intent(in) :: fin(SWU_NIN), fout(SWU_NOUT)
+      if (geosrad_sw_update_export_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nbands,c_int), fin, fout) /= 0) &
+         call geosrad_fail('UPDATE_EXPORT')
+   end subroutine
+
+   ! heating rates of the parent (GEOS_RadiationGridComp.F90:798-819)
+   subroutine rad_tendencies(ncol, lm, grav, cp, fin, fout)
+      integer, intent(in) :: ncol, lm
+      real, intent(in) :: grav, cp
+      type(c_ptr), intent(in) :: fin(RT_NIN), fout(RT_NOUT)
+      if (geosrad_rad_tendencies_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), real(grav,c_double), real(cp,c_double), &
+            fin, fout) /= 0) call geosrad_fail('GEOS_RadiationGridComp RUN')
+   end subroutine
+end module geosrad_gridcomp

@@ -146,3 +146,56 @@ def test_fortran_chou_caller_matches_oracle(tmp_path, kind):
     tol = 1e-9 if kind == "r8" else 2e-5
     for k, v in sgot.items():
         assert np.abs(v - s[k].astype(np.float64)).max() <= tol, k
+
+
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
+    """gridcomp_driver.F90: LW_Driver's RRTMG branch + one heartbeat Update_Flx called from Fortran on device-resident GEOS fields
+    (module geosrad_gridcomp); same library, same inputs -> the same bits as the Python mirror of the entry points."""
+    import torch
+    from geosradiation_gridcomp_amd import gridcomp as G
+    from geosradiation_gridcomp_amd import synth
+    exe = os.path.join(FDIR, "bin", f"gridcomp_driver_{kind}")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    ncol, lm, nb, ih = 48, 72, 16, 1
+    inp = synth.make_columns(ncol, lm, start=2024, aerosol=True, cloudy_frac=0.6)
+    f = synth.geos_lw_fields(inp)
+    f32 = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in f.items() if isinstance(v, np.ndarray)}
+    consts = G.lwd_consts()
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as fh:
+        np.array([ncol, lm, nb, ih, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"]], dtype=np.int32).tofile(fh)
+        np.array(consts, dtype=np.float64).tofile(fh)
+        for k in G.LWD_IN:
+            if k != "CO2_3D":
+                f32[k].tofile(fh)
+    env = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
+    subprocess.check_call([exe, str(fin), str(fout)], env=env)
+    raw = np.fromfile(fout, dtype=np.float64)
+    n3p = (lm + 1) * ncol
+    parts = np.split(raw, np.cumsum([n3p, n3p, ncol, ncol, n3p, ncol, ncol]))
+    got = dict(zip(["FLX_INT", "DFDTS", "SFCEM_INT", "CLDTTLW", "FLX", "OLR", "FLNS", "SFCEM"], parts))
+    # the same two calls through the Python mirror (inputs rounded to float32 first, as the file holds them)
+    ctx = gpu_ctx[4 if kind == "r4" else 8]
+    dt = ctx.dtype
+    tdt = torch.float32 if kind == "r4" else torch.float64
+    st = torch.cuda.current_stream().cuda_stream
+    t = {k: torch.from_numpy(v.astype(dt)).cuda() for k, v in f32.items()}
+    for k in G.LWD_OUT[:16]:
+        t[k] = torch.zeros((lm + 1, ncol) if k in G.LWD_OUT_3D else (ncol,), dtype=tdt, device="cuda")
+    ptr = {k: v.data_ptr() for k, v in t.items()}
+    ctx.set_inhomogeneity(ih)
+    ctx.lw_driver_rrtmg_dev(st, ncol, lm, nb, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"])
+    u = {k: t[k] for k in ("TS_INT", "SFCEM_INT", "FCLD", "FLX_INT", "FLC_INT", "FLXU_INT", "FLCU_INT", "FLXD_INT", "FLCD_INT", "DFDTS", "DFDTSC")}
+    u["TSINST"] = t["TS"] + 1.0
+    for k in ("FLX", "OLR", "FLNS", "SFCEM"):
+        u[k] = torch.zeros((lm + 1, ncol) if k == "FLX" else (ncol,), dtype=tdt, device="cuda")
+    ctx.lw_update_flx_dev(st, ncol, lm, True, f["LCLDMH"], f["LCLDLM"], 1.0e15, {k: v.data_ptr() for k, v in u.items()})
+    ctx.check(st)
+    ctx.set_inhomogeneity(0)
+    for k in ("FLX_INT", "DFDTS", "SFCEM_INT", "CLDTTLW"):
+        np.testing.assert_array_equal(got[k], t[k].cpu().numpy().astype(np.float64).ravel(), err_msg=k)
+    for k in ("FLX", "OLR", "FLNS", "SFCEM"):
+        np.testing.assert_array_equal(got[k], u[k].cpu().numpy().astype(np.float64).ravel(), err_msg=k)
+    assert (got["OLR"] > 100).all() and (got["SFCEM"] > got["SFCEM_INT"]).all()      # a warmer surface emits more
