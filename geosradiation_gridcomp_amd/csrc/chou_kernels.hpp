@@ -151,7 +151,7 @@ struct ChBand {
     int h2o_s, con_s, co2_s, n2o_s, ch4_s, com_s, f11_s, f12_s, f22_s, ne;
     bool h2otable, conbnd, co2bnd, oznbnd, n2obnd, combnd, f11bnd, f12bnd, b10bnd;
 };
-GR_DEV ChBand ch_band(int ibn)
+__host__ __device__ constexpr ChBand ch_band(int ibn)
 {
     ChBand b{};
     b.h2otable = ibn == 1 || ibn == 2 || ibn == 8; b.conbnd = ibn >= 2 && ibn <= 7; b.co2bnd = ibn == 3; b.oznbnd = ibn == 5;
@@ -172,6 +172,30 @@ GR_DEV ChBand ch_band(int ibn)
     return b;
 }
 
+// LDS planes of K1 reals a band needs: its exponentials (highest slot used) + the absorber paths of its table look-ups
+__host__ __device__ constexpr int ch_nex(int ibn)
+{
+    constexpr int nex[11] = {0, 0, 1, 9, 16, 14, 17, 15, 0, 6, 14};
+    return nex[ibn];
+}
+__host__ __device__ constexpr int ch_planes(int ibn)
+{
+    const ChBand b = ch_band(ibn);
+    const int ntab = (b.h2otable ? 1 : 0) + (b.co2bnd ? 1 : 0) + (b.oznbnd ? 1 : 0);
+    return ch_nex(ibn) + (ntab ? 2 + ntab : 0);
+}
+__host__ __device__ constexpr int ch_planes_max()
+{
+    int m = 0;
+    for (int ibn = 1; ibn <= 10; ibn++) m = ch_planes(ibn) > m ? ch_planes(ibn) : m;
+    return m;
+}
+// LDS bytes of k_chou_bands for np layers
+template <typename R> constexpr size_t chou_bands_lds_bytes(int np)
+{
+    return (size_t)((ch_planes_max() + 3) * (np + 1) + 12 * (np + 2)) * sizeof(R) + (size_t)(np + 1) * sizeof(int);
+}
+
 // running transmittance state of one lane (one k1)
 template <typename R> struct ChState {
     R th2o[6], tcon[3], tco2[6], tn2o[4], tch4[4], tcom[6], tf11, tf12, tf22, x1, x2, x3;
@@ -179,29 +203,33 @@ template <typename R> struct ChState {
 
 // ---------------------------------------------------------------------------------------------------
 // k_chou_bands: one wave per (column, band); blockIdx.x = column, blockIdx.y = band - 1.  Dynamic LDS.
+// The band is a template parameter of the body: which absorbers a band has, where their exponentials sit and how many running
+// products a lane carries are then compile-time facts (dead branches and their registers disappear).
 // ---------------------------------------------------------------------------------------------------
-template <typename R>
-__global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<R> *__restrict__ Tp)
+template <typename R, int IBN>
+GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned char *ch_smem)
 {
-    extern __shared__ __align__(16) unsigned char ch_smem[];
-    const ChouDev<R> &T = *Tp;
-    const int i = blockIdx.x, ibn = blockIdx.y + 1, lane = threadIdx.x;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    constexpr int ibn = IBN;
     const int np = A.np, K1 = np + 1, K2 = np + 2, ld = A.ld;
-    const ChBand B = ch_band(ibn);
+    constexpr ChBand B = ch_band(IBN);
     const bool trace = A.trace != 0, do_aer = A.na > 0;
 
     // ---- LDS carve-up ----------------------------------------------------------------------------------
     R *sp = reinterpret_cast<R *>(ch_smem);
     auto take = [&](int n) { R *q = sp; sp += n; return q; };
-    R *ex = take(17 * K1);                                // ex[(j-1)*K1 + k]
-    R *s_pa = take(K1), *s_dt = take(K1), *s_dw = take(K1), *s_dco2 = take(K1), *s_do3 = take(K1);
-    R *blayer = take(K2), *blevel = take(K2);
+    constexpr bool TAB = B.h2otable || B.co2bnd || B.oznbnd;
+    R *ex = take(ch_nex(IBN) * K1);                       // ex[(j-1)*K1 + k]
+    R *s_pa = TAB ? take(K1) : nullptr, *s_dt = TAB ? take(K1) : nullptr;
+    R *s_dw = B.h2otable ? take(K1) : nullptr, *s_dco2 = B.co2bnd ? take(K1) : nullptr, *s_do3 = B.oznbnd ? take(K1) : nullptr;
+    sp = reinterpret_cast<R *>(ch_smem) + ch_planes_max() * K1;      // the rest sits at band-independent offsets
     R *bu = take(K2), *bd = take(K2), *cu = take(K2), *cd = take(K2), *au = take(K2), *ad = take(K2), *du = take(K2), *dd = take(K2);
     R *enn = take(K1), *tcld = take(K1), *taer = take(K1);
-    R *fup = take(4 * K2);                                // flxu flcu flau flxau  [kind][k]
     R *fdn = take(4 * K2);                                // flxd flcd flad flxad
-    R *tr = take(4 * K2);                                 // transfc transfca trantcr trantca
-    R *dfd = take(K2);
+    // the Planck fluxes of layers and levels are dead once loop 1500 has formed the layer emissions: they share the downward-flux
+    // accumulators' space (which are zeroed after it).  The per-k1 results of loop 2000 (4 upward fluxes, 4 transmittances,
+    // dfdts) are parked in the band's `part` slots in HBM by the lane that reads them back in P5.
+    R *blayer = fdn, *blevel = fdn + K2;
     int *icx = reinterpret_cast<int *>(sp);
 #define EX(k, j) ex[((j) - 1) * K1 + (k)]
 
@@ -211,8 +239,11 @@ __global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<
     for (int k = lane; k <= np; k += 64) {
         const R pa = rec[CF_PA * K1 + k], dt = rec[CF_DT * K1 + k], dh2o = rec[CF_DH2O * K1 + k], dcont = rec[CF_DCONT * K1 + k],
                 dco2 = rec[CF_DCO2 * K1 + k], do3 = rec[CF_DO3 * K1 + k];
-        s_pa[k] = pa; s_dt[k] = dt; s_dw[k] = dh2o; s_dco2[k] = dco2; s_do3[k] = do3;
-        for (int j = 1; j <= 17; j++) EX(k, j) = 0;
+        if constexpr (TAB) { s_pa[k] = pa; s_dt[k] = dt; }
+        if constexpr (B.h2otable) s_dw[k] = dh2o;
+        if constexpr (B.co2bnd) s_dco2[k] = dco2;
+        if constexpr (B.oznbnd) s_do3[k] = do3;
+        for (int j = 1; j <= ch_nex(IBN); j++) EX(k, j) = 0;
         // water vapour line exponentials (h2oexps :1379-1458)
         if (!B.h2otable && !B.b10bnd) {
             R xh = dh2o * gr_pow<R>(pa / (R)500., T.pm[ibn - 1]) * ((R)1. + (T.aw[ibn - 1] + T.bw[ibn - 1] * dt) * dt);
@@ -533,9 +564,9 @@ __global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<
         ad[km] = dn; au[km] = up;
     }
     if (lane == 0) { bu[np + 1] = bs; au[np + 1] = bs; cu[np + 1] = bs; du[np + 1] = bs; }
-    for (int k = lane; k < 4 * K2; k += 64) { fdn[k] = 0; fup[k] = 0; tr[k] = 1; }
-    for (int k = lane; k < K2; k += 64) dfd[k] = 0;
+    for (int k = lane; k < 4 * K2; k += 64) fdn[k] = 0;
     __syncthreads();
+    R *part = A.part + ((size_t)i * CH_NB + (ibn - 1)) * CH_NKIND * K2;
 
     // ---- P4: loop 2000 (:948-1290): lanes = k1, lock-step walk over k2 --------------------------------------------------
     R *flxd = fdn, *flcd = fdn + K2, *flad = fdn + 2 * K2, *flxad = fdn + 3 * K2;
@@ -594,29 +625,35 @@ __global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<
                 if (do_aer) xx = k1 == 0 ? -taant * ad1 : taant * (ad0 - ad1);
                 flad[k2] = flad[k2] + xx;
             }
-            __syncthreads();          // lanes touch distinct k2 per step; the barrier orders the LDS updates between steps
+            // lanes touch distinct k2 within a step; between steps the block's ONE wavefront issues its LDS instructions in
+            // program order and the LDS executes a wave's instructions in order, so a compiler-level barrier is all that is needed
+            // (no s_waitcnt / s_barrier: the next step's loads overlap this step's stores)
+            __builtin_amdgcn_wave_barrier();
         }
-        if (act) {
-            fup[0 * K2 + k1] = axu; fup[1 * K2 + k1] = acu; fup[2 * K2 + k1] = aau; fup[3 * K2 + k1] = axau;
-            tr[0 * K2 + k1] = trant * fclr; tr[1 * K2 + k1] = taant * fclr; tr[2 * K2 + k1] = trant; tr[3 * K2 + k1] = taant;
-            if (k1 > 0) dfd[k1] = -dbs * (trant * fclr);
+        if (act) {      // parked where P5's loop index k == k1 of this same lane picks them up again
+            part[0 * K2 + k1] = axu; part[1 * K2 + k1] = acu; part[2 * K2 + k1] = aau; part[3 * K2 + k1] = axau;
+            part[4 * K2 + k1] = trant * fclr; part[5 * K2 + k1] = taant * fclr; part[6 * K2 + k1] = trant; part[7 * K2 + k1] = taant;
+            part[8 * K2 + k1] = k1 > 0 ? -dbs * (trant * fclr) : (R)0;
         }
     }
     __syncthreads();
 
     // ---- P5: surface emission and reflection (:1292-1315), band partials to HBM ------------------------------------------
-    R *part = A.part + ((size_t)i * CH_NB + (ibn - 1)) * CH_NKIND * K2;
     const bool sfc = !B.b10bnd;
     const R fxd_s = flxd[np + 1], fcd_s = flcd[np + 1], fad_s = flad[np + 1], fxad_s = flxad[np + 1];
     for (int k = lane; k <= np + 1; k += 64) {
-        R xu = fup[0 * K2 + k], cu_ = fup[1 * K2 + k], au_ = fup[2 * K2 + k], xau = fup[3 * K2 + k], df = dfd[k];
+        R xu = 0, cu_ = 0, au_ = 0, xau = 0, df = 0, t0 = 1, t1 = 1, t2 = 1, t3 = 1;      // level np+1: nothing below it
+        if (k <= np) {
+            xu = part[0 * K2 + k]; cu_ = part[1 * K2 + k]; au_ = part[2 * K2 + k]; xau = part[3 * K2 + k];
+            t0 = part[4 * K2 + k]; t1 = part[5 * K2 + k]; t2 = part[6 * K2 + k]; t3 = part[7 * K2 + k]; df = part[8 * K2 + k];
+        }
         if (sfc) {
             if (k == np + 1) { xu = -bs; cu_ = -bs; au_ = -bs; xau = -bs; df = -dbs; }
             if (k >= 1) {
-                au_ = au_ - fad_s * tr[3 * K2 + k] * rflxs;
-                cu_ = cu_ - fcd_s * tr[2 * K2 + k] * rflxs;
-                xu = xu - fxd_s * tr[0 * K2 + k] * rflxs;
-                xau = xau - fxad_s * tr[1 * K2 + k] * rflxs;
+                au_ = au_ - fad_s * t3 * rflxs;
+                cu_ = cu_ - fcd_s * t2 * rflxs;
+                xu = xu - fxd_s * t0 * rflxs;
+                xau = xau - fxad_s * t1 * rflxs;
             }
         }
         part[0 * K2 + k] = xu; part[1 * K2 + k] = cu_; part[2 * K2 + k] = au_; part[3 * K2 + k] = xau;
@@ -625,6 +662,25 @@ __global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<
         if (k == 0) part[9 * K2] = sfc ? -bs : (R)0;     // sfcem contribution of the band
     }
 #undef EX
+}
+
+template <typename R>
+__global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<R> *__restrict__ Tp)
+{
+    extern __shared__ __align__(16) unsigned char ch_smem[];
+    const ChouDev<R> &T = *Tp;
+    switch (blockIdx.y) {
+        case 0: chou_band_body<R, 1>(A, T, ch_smem); break;
+        case 1: chou_band_body<R, 2>(A, T, ch_smem); break;
+        case 2: chou_band_body<R, 3>(A, T, ch_smem); break;
+        case 3: chou_band_body<R, 4>(A, T, ch_smem); break;
+        case 4: chou_band_body<R, 5>(A, T, ch_smem); break;
+        case 5: chou_band_body<R, 6>(A, T, ch_smem); break;
+        case 6: chou_band_body<R, 7>(A, T, ch_smem); break;
+        case 7: chou_band_body<R, 8>(A, T, ch_smem); break;
+        case 8: chou_band_body<R, 9>(A, T, ch_smem); break;
+        default: chou_band_body<R, 10>(A, T, ch_smem); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1410,7 +1410,10 @@ template <typename R> struct Ctx : geosrad_ctx {
             ws_ch_bytes = need;
         }
         const int nband = trace ? 10 : 9;      // irrad.F90:478 (band 10 only with trace gases)
-        const size_t lds = (size_t)(25 * K1 + 23 * K2) * sizeof(R) + (size_t)K1 * sizeof(int);
+#ifndef GEOSRAD_EXP_LDS_PAD
+#define GEOSRAD_EXP_LDS_PAD 0
+#endif
+        const size_t lds = chou_bands_lds_bytes<R>(np) + GEOSRAD_EXP_LDS_PAD;
         if (lds > 64 * 1024) {
             if (hipFuncSetAttribute((const void *)k_chou_bands<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return fail(GEOSRAD_EINVAL, "np too large for the LDS-resident band state");
