@@ -55,40 +55,63 @@ template <> GR_DEV double gr_log10<double>(double x) { return log10(x); }
 // k_chou_prep: lane = column; absorber amounts and scaled quantities of every layer (irrad.F90:381-453), written as the
 // column's record.  Negative inputs raise an error bit (the reference has no input assertions here).
 // ---------------------------------------------------------------------------------------------------
+// The records are column-major ([column][field][level]: k_chou_bands reads a column's fields with lanes = levels), the inputs
+// are level-major with the column index fastest: the transposition goes through an LDS tile of 64 columns x 8 (fp64: 4) levels, so that
+// the inputs are read coalesced (lanes = columns) and the records are written in 32-byte runs (lanes = levels x fields).
 template <typename R>
-__global__ void __launch_bounds__(256) k_chou_prep(ChouArgs<R> A)
+__global__ void __launch_bounds__(64) k_chou_prep(ChouArgs<R> A)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.m) return;
+    constexpr int CHP_KC = 32 / (int)sizeof(R);      // levels per tile: one 32-byte run per (column, field)
+    __shared__ R tile[CF_NFIELD * CHP_KC * 65];
+    const int lane = threadIdx.x, col0 = blockIdx.x * 64, i = col0 + lane;
+    const bool act = i < A.m;
     const int np = A.np, ld = A.ld, K1 = np + 1;
-    R *rec = A.rec + (size_t)i * CF_NFIELD * K1;
+    const int ncolb = (A.m - col0) < 64 ? (A.m - col0) : 64;
 #define AP(a, k) a[(size_t)((k) - 1) * ld + i]
-    for (int k = 0; k <= np; k++) {
-        const int ks = k == 0 ? 1 : k;      // layer 0 copies the top layer's state (:432-453)
-        R dp, pa;
-        if (k == 0) { dp = AP(A.ple, 1) * (R)0.01; dp = dp > (R)0.005 ? dp : (R)0.005; pa = (R)0.5 * dp; }
-        else { pa = (R)0.5 * (AP(A.ple, k + 1) + AP(A.ple, k)) * (R)0.01; dp = (AP(A.ple, k + 1) - AP(A.ple, k)) * (R)0.01; }
-        const R ta = AP(A.ta, ks), wa = AP(A.wa, ks);
-        R dh2o = (R)1.02 * wa * dp, do3 = (R)476. * AP(A.oa, ks) * dp, dco2 = (R)789. * A.co2 * dp;
-        dh2o = dh2o > (R)1.e-10 ? dh2o : (R)1.e-10;
-        do3 = do3 > (R)1.e-6 ? do3 : (R)1.e-6;
-        dco2 = dco2 > (R)1.e-4 ? dco2 : (R)1.e-4;
-        const R xx = pa * (R)0.001618 * wa * wa * dp;
-        rec[CF_PA * K1 + k] = pa; rec[CF_DT * K1 + k] = ta - (R)250.0; rec[CF_DH2O * K1 + k] = dh2o;
-        rec[CF_DCONT * K1 + k] = xx * gr_exp<R>((R)1800. / ta - (R)6.081);
-        rec[CF_DCO2 * K1 + k] = dco2; rec[CF_DO3 * K1 + k] = do3;
-        rec[CF_DN2O * K1 + k] = (R)789. * AP(A.n2o, ks) * dp; rec[CF_DCH4 * K1 + k] = (R)789. * AP(A.ch4, ks) * dp;
-        rec[CF_DF11 * K1 + k] = (R)789. * AP(A.cfc11, ks) * dp; rec[CF_DF12 * K1 + k] = (R)789. * AP(A.cfc12, ks) * dp;
-        rec[CF_DF22 * K1 + k] = (R)789. * AP(A.cfc22, ks) * dp;
-        rec[CF_TA * K1 + k] = ta;
-        rec[CF_DPPA * K1 + k] = k == 0 ? (R)0 : AP(A.ple, k + 1) - AP(A.ple, k);
-        rec[CF_FCLD * K1 + k] = k == 0 ? (R)0 : AP(A.fcld, k);
-        for (int l = 0; l < 4; l++) {
-            rec[(CF_REFF1 + l) * K1 + k] = k == 0 ? (R)0 : A.reff[((size_t)l * np + (k - 1)) * ld + i];
-            rec[(CF_CWC1 + l) * K1 + k] = k == 0 ? (R)0 : A.cwc[((size_t)l * np + (k - 1)) * ld + i];
+#define TL(f, kk) tile[((f) * CHP_KC + (kk)) * 65 + lane]
+    for (int k0 = 0; k0 <= np; k0 += CHP_KC) {
+        const int nk = (np + 1 - k0) < CHP_KC ? (np + 1 - k0) : CHP_KC;
+        if (act) {
+            for (int kk = 0; kk < nk; kk++) {
+                const int k = k0 + kk;
+                const int ks = k == 0 ? 1 : k;      // layer 0 copies the top layer's state (:432-453)
+                R dp, pa;
+                if (k == 0) { dp = AP(A.ple, 1) * (R)0.01; dp = dp > (R)0.005 ? dp : (R)0.005; pa = (R)0.5 * dp; }
+                else { pa = (R)0.5 * (AP(A.ple, k + 1) + AP(A.ple, k)) * (R)0.01; dp = (AP(A.ple, k + 1) - AP(A.ple, k)) * (R)0.01; }
+                const R ta = AP(A.ta, ks), wa = AP(A.wa, ks);
+                R dh2o = (R)1.02 * wa * dp, do3 = (R)476. * AP(A.oa, ks) * dp, dco2 = (R)789. * A.co2 * dp;
+                dh2o = dh2o > (R)1.e-10 ? dh2o : (R)1.e-10;
+                do3 = do3 > (R)1.e-6 ? do3 : (R)1.e-6;
+                dco2 = dco2 > (R)1.e-4 ? dco2 : (R)1.e-4;
+                const R xx = pa * (R)0.001618 * wa * wa * dp;
+                TL(CF_PA, kk) = pa; TL(CF_DT, kk) = ta - (R)250.0; TL(CF_DH2O, kk) = dh2o;
+                TL(CF_DCONT, kk) = xx * gr_exp<R>((R)1800. / ta - (R)6.081);
+                TL(CF_DCO2, kk) = dco2; TL(CF_DO3, kk) = do3;
+                TL(CF_DN2O, kk) = (R)789. * AP(A.n2o, ks) * dp; TL(CF_DCH4, kk) = (R)789. * AP(A.ch4, ks) * dp;
+                TL(CF_DF11, kk) = (R)789. * AP(A.cfc11, ks) * dp; TL(CF_DF12, kk) = (R)789. * AP(A.cfc12, ks) * dp;
+                TL(CF_DF22, kk) = (R)789. * AP(A.cfc22, ks) * dp;
+                TL(CF_TA, kk) = ta;
+                TL(CF_DPPA, kk) = k == 0 ? (R)0 : AP(A.ple, k + 1) - AP(A.ple, k);
+                TL(CF_FCLD, kk) = k == 0 ? (R)0 : AP(A.fcld, k);
+                for (int l = 0; l < 4; l++) {
+                    TL(CF_REFF1 + l, kk) = k == 0 ? (R)0 : A.reff[((size_t)l * np + (k - 1)) * ld + i];
+                    TL(CF_CWC1 + l, kk) = k == 0 ? (R)0 : A.cwc[((size_t)l * np + (k - 1)) * ld + i];
+                }
+            }
         }
+        __syncthreads();
+        // write-out: lane -> (field group, level in tile); 8 consecutive lanes write 8 consecutive levels of one field
+        const int kk = lane % CHP_KC, fg = lane / CHP_KC;
+        if (kk < nk) {
+            for (int c = 0; c < ncolb; c++) {
+                R *rec = A.rec + (size_t)(col0 + c) * CF_NFIELD * K1 + k0 + kk;
+                for (int f = fg; f < CF_NFIELD; f += 64 / CHP_KC) rec[(size_t)f * K1] = tile[(f * CHP_KC + kk) * 65 + c];
+            }
+        }
+        __syncthreads();
     }
 #undef AP
+#undef TL
 }
 
 // planck / plancd (:1341-1376)
