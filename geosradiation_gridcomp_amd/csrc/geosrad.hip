@@ -1572,6 +1572,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             O.flx = Q(SOO_FLX); O.flc = Q(SOO_FLC); O.fdiruv = Q(SOO_FDIRUV); O.fdifuv = Q(SOO_FDIFUV); O.fdirpar = Q(SOO_FDIRPAR);
             O.fdifpar = Q(SOO_FDIFPAR); O.fdirir = Q(SOO_FDIRIR); O.fdifir = Q(SOO_FDIFIR); O.flxu = Q(SOO_FLXU); O.flcu = Q(SOO_FLCU);
             O.flx_sfc_band = Q(SOO_SFCBAND); O.drband = Q(SOO_DRBAND); O.dfband = Q(SOO_DFBAND);
+            hipLaunchKernelGGL(k_sorad_sum<R>, dim3(gx, np + 1), blk, 0, st, A, O);
             hipLaunchKernelGGL(k_sorad_reduce<R>, dim3(gx), blk, 0, st, A, (const SoradDev<R> *)d_O, O);
         }
         HIPCHK(hipGetLastError());

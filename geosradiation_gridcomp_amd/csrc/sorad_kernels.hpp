@@ -291,22 +291,23 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
             so_deledd<R>(tautof, ssatof, asytof, dsm, rst, tst, dum);
         }
         LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
-        P(30, k) = 0; P(31, k) = 0; P(32, k) = 0; P(33, k) = 0;
     }
-    P(30, np + 1) = 0; P(31, np + 1) = 0; P(32, np + 1) = 0; P(33, np + 1) = 0;
 
     // ---- CLDFLX (:689-872): composites from the top over the high and middle groups ---------------------------------------
     const int nh = cc1 > 0 ? 2 : 1, nm = cc2 > 0 ? 2 : 1, ns = cc3 > 0 ? 2 : 1;       // portions of non-zero weight
     for (int ih = 1; ih <= nh; ih++) {
         R tda = LY(2, ih, 0), tta = LY(1, ih, 0), rsa = LY(3, ih, 0);
-        TDA(0, ih, 1) = tda; TTA(0, ih, 1) = tta; RSA(0, ih, 1) = rsa; TDA(0, ih, 2) = tda; TTA(0, ih, 2) = tta; RSA(0, ih, 2) = rsa;
+        // (ih, 2) copies feed the cloudy middle portion only
+        TDA(0, ih, 1) = tda; TTA(0, ih, 1) = tta; RSA(0, ih, 1) = rsa;
+        if (nm == 2) { TDA(0, ih, 2) = tda; TTA(0, ih, 2) = tta; RSA(0, ih, 2) = rsa; }
         for (int k = 1; k <= ict - 1; k++) {
             const R rr = LY(0, ih, k), tt = LY(1, ih, k), td = LY(2, ih, k), rs = LY(3, ih, k), ts = LY(4, ih, k);
             const R denm = ts / ((R)1. - rsa * rs);
             const R ntta = tda * tt + (tda * rsa * rr + tta - tda) * denm;
             const R nrsa = rs + ts * rsa * denm;
             tda = tda * td; tta = ntta; rsa = nrsa;
-            TDA(k, ih, 1) = tda; TTA(k, ih, 1) = tta; RSA(k, ih, 1) = rsa; TDA(k, ih, 2) = tda; TTA(k, ih, 2) = tta; RSA(k, ih, 2) = rsa;
+            TDA(k, ih, 1) = tda; TTA(k, ih, 1) = tta; RSA(k, ih, 1) = rsa;
+            if (nm == 2) { TDA(k, ih, 2) = tda; TTA(k, ih, 2) = tta; RSA(k, ih, 2) = rsa; }
         }
         for (int im = 1; im <= nm; im++) {
             R a = TDA(ict - 1, ih, im), b = TTA(ict - 1, ih, im), c = RSA(ict - 1, ih, im);
@@ -323,13 +324,15 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
     // composites from the surface over the low and middle groups
     for (int is = 1; is <= ns; is++) {
         R rra = LY(0, is, np + 1), rxa = LY(3, is, np + 1);
-        RRA(np + 1, 1, is) = rra; RXA(np + 1, 1, is) = rxa; RRA(np + 1, 2, is) = rra; RXA(np + 1, 2, is) = rxa;
+        RRA(np + 1, 1, is) = rra; RXA(np + 1, 1, is) = rxa;
+        if (nm == 2) { RRA(np + 1, 2, is) = rra; RXA(np + 1, 2, is) = rxa; }
         for (int k = np; k >= icb; k--) {
             const R rr = LY(0, is, k), tt = LY(1, is, k), td = LY(2, is, k), rs = LY(3, is, k), ts = LY(4, is, k);
             const R denm = ts / ((R)1. - rs * rxa);
             const R nrra = rr + (td * rra + (tt - td) * rxa) * denm;
             rxa = rs + ts * rxa * denm; rra = nrra;
-            RRA(k, 1, is) = rra; RXA(k, 1, is) = rxa; RRA(k, 2, is) = rra; RXA(k, 2, is) = rxa;
+            RRA(k, 1, is) = rra; RXA(k, 1, is) = rxa;
+            if (nm == 2) { RRA(k, 2, is) = rra; RXA(k, 2, is) = rxa; }
         }
         for (int im = 1; im <= nm; im++) {
             R a = RRA(icb, im, is), b = RXA(icb, im, is);
@@ -380,9 +383,9 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
                     fdndif = (xx4 * rsa + yy) * denm;
                     const R fupdif = (xx4 + yy * rxa) * denm;
                     const R flxdn = fdndir + fdndif - fupdif;
-                    if (ih == 1 && im == 1 && is == 1) { P(33, k) = fupdif; P(31, k) = flxdn; }
-                    P(32, k) = P(32, k) + fupdif * ct;
-                    P(30, k) = P(30, k) + flxdn * ct;
+                    // the first sky situation (all-clear portions) starts the weighted sums: 0 + x * ct, as the reference's zeroed arrays give
+                    if (ih == 1 && im == 1 && is == 1) { P(33, k) = fupdif; P(31, k) = flxdn; P(32, k) = (R)0 + fupdif * ct; P(30, k) = (R)0 + flxdn * ct; }
+                    else { P(32, k) = P(32, k) + fupdif * ct; P(30, k) = P(30, k) + flxdn * ct; }
                 }
                 fsdir = fsdir + fdndir * ct;
                 fsdif = fsdif + fdndif * ct;
@@ -401,6 +404,27 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_sorad_sum: per (column, level) -- flux integration over the 35 passes in pass order (Eq. 6.1)
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_sum(SoradArgs<R> A, SoradOut<R> O)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y + 1;
+    if (i >= A.m) return;
+    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
+    R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 5
+    for (int p = 0; p < SO_NPASS; p++) {
+        const R hk = A.hk[p];
+        const R *q = A.scr + (((size_t)p * 34 + 30) * K2 + k) * m + i;
+        s0 = s0 + q[0] * hk; s1 = s1 + q[(size_t)K2 * m] * hk; s2 = s2 + q[(size_t)2 * K2 * m] * hk; s3 = s3 + q[(size_t)3 * K2 * m] * hk;
+    }
+    const size_t o = (size_t)(k - 1) * ld + i;
+    O.flx[o] = s0; O.flc[o] = s1; O.flxu[o] = s2; O.flcu[o] = s3;
+    (void)np;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_sorad_reduce: per column -- flux integration over the passes (Eq. 6.1), O2 / CO2 reductions (:1425-1552), surface rescaling
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
@@ -412,14 +436,7 @@ __global__ void __launch_bounds__(256) k_sorad_reduce(SoradArgs<R> A, const Sora
     const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
 #define OUT2(a, k) a[(size_t)((k) - 1) * ld + i]
 #define SCR(pass, q, k) A.scr[(((size_t)(pass) * 34 + (q)) * K2 + (k)) * m + i]
-    for (int k = 1; k <= np + 1; k++) {
-        R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (int p = 0; p < SO_NPASS; p++) {
-            const R hk = A.hk[p];
-            s0 = s0 + SCR(p, 30, k) * hk; s1 = s1 + SCR(p, 31, k) * hk; s2 = s2 + SCR(p, 32, k) * hk; s3 = s3 + SCR(p, 33, k) * hk;
-        }
-        OUT2(O.flx, k) = s0; OUT2(O.flc, k) = s1; OUT2(O.flxu, k) = s2; OUT2(O.flcu, k) = s3;
-    }
+    // (the level fluxes were summed over the passes by k_sorad_sum)
     // surface band fluxes and direct / diffuse partition
     R fdiruv = 0, fdifuv = 0, fdirpar = 0, fdifpar = 0, fdirir = 0, fdifir = 0, band[8], drb[8], dfb[8];
     for (int b = 0; b < 8; b++) { band[b] = 0; drb[b] = 0; dfb[b] = 0; }
