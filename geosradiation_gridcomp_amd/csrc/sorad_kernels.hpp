@@ -242,6 +242,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
 #define RSA(k, a, b) P(18 + 2 * ((a) - 1) + (b) - 1, k)
 #define RRA(k, a, b) P(22 + 2 * ((a) - 1) + (b) - 1, k)
 #define RXA(k, a, b) P(26 + 2 * ((a) - 1) + (b) - 1, k)
+    // The sweeps below are first-order recurrences over the levels: each step loads a layer's five properties and stores the new
+    // composites.  gfx9 tracks loads and stores with one in-order counter, so a load issued after a store cannot be consumed before
+    // that store is acknowledged: every sweep therefore requests the NEXT level's properties before it stores the current results.
+    struct L5 { R rr, tt, td, rs, ts; };
+    auto ld5 = [&](int j, int k) { L5 l; l.rr = LY(0, j, k); l.tt = LY(1, j, k); l.td = LY(2, j, k); l.rs = LY(3, j, k); l.ts = LY(4, j, k); return l; };
     // boundary "layers": surface (np+1) and the layer above the model top (0)  (:365-387, 914-936)
     {
         const R rb = uv ? A.rsuvbm[i] : A.rsirbm[i], rd = uv ? A.rsuvdf[i] : A.rsirdf[i];
@@ -300,8 +305,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         // (ih, 2) copies feed the cloudy middle portion only
         TDA(0, ih, 1) = tda; TTA(0, ih, 1) = tta; RSA(0, ih, 1) = rsa;
         if (nm == 2) { TDA(0, ih, 2) = tda; TTA(0, ih, 2) = tta; RSA(0, ih, 2) = rsa; }
+        L5 nx = ld5(ih, 1);
         for (int k = 1; k <= ict - 1; k++) {
-            const R rr = LY(0, ih, k), tt = LY(1, ih, k), td = LY(2, ih, k), rs = LY(3, ih, k), ts = LY(4, ih, k);
+            const L5 c = nx;
+            if (k + 1 <= ict - 1) nx = ld5(ih, k + 1);
+            const R rr = c.rr, tt = c.tt, td = c.td, rs = c.rs, ts = c.ts;
             const R denm = ts / ((R)1. - rsa * rs);
             const R ntta = tda * tt + (tda * rsa * rr + tta - tda) * denm;
             const R nrsa = rs + ts * rsa * denm;
@@ -311,8 +319,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         }
         for (int im = 1; im <= nm; im++) {
             R a = TDA(ict - 1, ih, im), b = TTA(ict - 1, ih, im), c = RSA(ict - 1, ih, im);
+            L5 nx = ld5(im, ict);
             for (int k = ict; k <= icb - 1; k++) {
-                const R rr = LY(0, im, k), tt = LY(1, im, k), td = LY(2, im, k), rs = LY(3, im, k), ts = LY(4, im, k);
+                const L5 l = nx;
+                if (k + 1 <= icb - 1) nx = ld5(im, k + 1);
+                const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
                 const R denm = ts / ((R)1. - c * rs);
                 const R nb = a * tt + (a * c * rr + b - a) * denm;
                 const R nc = rs + ts * c * denm;
@@ -326,8 +337,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         R rra = LY(0, is, np + 1), rxa = LY(3, is, np + 1);
         RRA(np + 1, 1, is) = rra; RXA(np + 1, 1, is) = rxa;
         if (nm == 2) { RRA(np + 1, 2, is) = rra; RXA(np + 1, 2, is) = rxa; }
+        L5 nx = ld5(is, np);
         for (int k = np; k >= icb; k--) {
-            const R rr = LY(0, is, k), tt = LY(1, is, k), td = LY(2, is, k), rs = LY(3, is, k), ts = LY(4, is, k);
+            const L5 l = nx;
+            if (k - 1 >= icb) nx = ld5(is, k - 1);
+            const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
             const R denm = ts / ((R)1. - rs * rxa);
             const R nrra = rr + (td * rra + (tt - td) * rxa) * denm;
             rxa = rs + ts * rxa * denm; rra = nrra;
@@ -336,8 +350,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         }
         for (int im = 1; im <= nm; im++) {
             R a = RRA(icb, im, is), b = RXA(icb, im, is);
+            L5 nx = ld5(im, icb - 1);
             for (int k = icb - 1; k >= ict; k--) {
-                const R rr = LY(0, im, k), tt = LY(1, im, k), td = LY(2, im, k), rs = LY(3, im, k), ts = LY(4, im, k);
+                const L5 l = nx;
+                if (k - 1 >= ict) nx = ld5(im, k - 1);
+                const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
                 const R denm = ts / ((R)1. - rs * b);
                 const R na = rr + (td * a + (tt - td) * b) * denm;
                 b = rs + ts * b * denm; a = na;
@@ -355,8 +372,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
                 const R ct = is == 1 ? cm * ((R)1.0 - cc3) : cm * cc3;
                 {   // add one layer at a time, going down through the low group
                     R a = TDA(icb - 1, ih, im), b = TTA(icb - 1, ih, im), c = RSA(icb - 1, ih, im);
+                    L5 nx = ld5(is, icb);
                     for (int k = icb; k <= np; k++) {
-                        const R rr = LY(0, is, k), tt = LY(1, is, k), td = LY(2, is, k), rs = LY(3, is, k), ts = LY(4, is, k);
+                        const L5 l = nx;
+                        if (k + 1 <= np) nx = ld5(is, k + 1);
+                        const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
                         const R denm = ts / ((R)1. - c * rs);
                         const R nb = a * tt + (a * rr * c + b - a) * denm;
                         const R nc = rs + ts * c * denm;
@@ -366,8 +386,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
                 }
                 {   // going up through the high group
                     R a = RRA(ict, im, is), b = RXA(ict, im, is);
+                    L5 nx = ld5(ih, ict - 1);
                     for (int k = ict - 1; k >= 0; k--) {
-                        const R rr = LY(0, ih, k), tt = LY(1, ih, k), td = LY(2, ih, k), rs = LY(3, ih, k), ts = LY(4, ih, k);
+                        const L5 l = nx;
+                        if (k - 1 >= 0) nx = ld5(ih, k - 1);
+                        const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
                         const R denm = ts / ((R)1. - rs * b);
                         const R na = rr + (td * a + (tt - td) * b) * denm;
                         b = rs + ts * b * denm; a = na;
@@ -375,8 +398,16 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
                     }
                 }
                 R fdndir = 0, fdndif = 0;
+                const bool first = ih == 1 && im == 1 && is == 1;
+                auto ldf = [&](int k) { L5 l; l.rr = TDA(k - 1, ih, im); l.tt = TTA(k - 1, ih, im); l.td = RSA(k - 1, ih, im); l.rs = RRA(k, im, is); l.ts = RXA(k, im, is); return l; };
+                L5 nx = ldf(1);
+                R a32 = 0, a30 = 0;
+                if (!first) { a32 = P(32, 1); a30 = P(30, 1); }
                 for (int k = 1; k <= np + 1; k++) {      // Eqs. (6.15), (6.16)
-                    const R tda = TDA(k - 1, ih, im), tta = TTA(k - 1, ih, im), rsa = RSA(k - 1, ih, im), rra = RRA(k, im, is), rxa = RXA(k, im, is);
+                    const L5 l = nx;
+                    const R p32 = a32, p30 = a30;
+                    if (k + 1 <= np + 1) { nx = ldf(k + 1); if (!first) { a32 = P(32, k + 1); a30 = P(30, k + 1); } }
+                    const R tda = l.rr, tta = l.tt, rsa = l.td, rra = l.rs, rxa = l.ts;
                     const R denm = (R)1. / ((R)1. - rsa * rxa);
                     fdndir = tda;
                     const R xx4 = tda * rra, yy = tta - tda;
@@ -384,8 +415,8 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
                     const R fupdif = (xx4 + yy * rxa) * denm;
                     const R flxdn = fdndir + fdndif - fupdif;
                     // the first sky situation (all-clear portions) starts the weighted sums: 0 + x * ct, as the reference's zeroed arrays give
-                    if (ih == 1 && im == 1 && is == 1) { P(33, k) = fupdif; P(31, k) = flxdn; P(32, k) = (R)0 + fupdif * ct; P(30, k) = (R)0 + flxdn * ct; }
-                    else { P(32, k) = P(32, k) + fupdif * ct; P(30, k) = P(30, k) + flxdn * ct; }
+                    if (first) { P(33, k) = fupdif; P(31, k) = flxdn; P(32, k) = (R)0 + fupdif * ct; P(30, k) = (R)0 + flxdn * ct; }
+                    else { P(32, k) = p32 + fupdif * ct; P(30, k) = p30 + flxdn * ct; }
                 }
                 fsdir = fsdir + fdndir * ct;
                 fsdif = fsdif + fdndif * ct;
