@@ -251,16 +251,26 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
     {
         const R rb = uv ? A.rsuvbm[i] : A.rsirbm[i], rd = uv ? A.rsuvdf[i] : A.rsirdf[i];
         const R td0 = uv ? gr_exp<R>(-(wvtoa * T.wk_uv[ib - 1] + o3toa * T.zk_uv[ib - 1]) / cz) : gr_exp<R>(-wvtoa * T.xk_ir[ik - 1] / cz);
+        // the cloudy-portion planes (j = 2) of a group are only read when the group has cloud
         for (int j = 1; j <= 2; j++) {
-            LY(0, j, np + 1) = rb; LY(3, j, np + 1) = rd; LY(2, j, np + 1) = 0; LY(1, j, np + 1) = 0; LY(4, j, np + 1) = 0;
-            LY(0, j, 0) = 0; LY(3, j, 0) = 0; LY(1, j, 0) = 1; LY(4, j, 0) = 1; LY(2, j, 0) = td0;
+            if (j == 1 || cc3 > 0) { LY(0, j, np + 1) = rb; LY(3, j, np + 1) = rd; LY(2, j, np + 1) = 0; LY(1, j, np + 1) = 0; LY(4, j, np + 1) = 0; }
+            if (j == 1 || cc1 > 0) { LY(0, j, 0) = 0; LY(3, j, 0) = 0; LY(1, j, 0) = 1; LY(4, j, 0) = 1; LY(2, j, 0) = td0; }
         }
     }
     // ---- layers: clear and cloudy portion (:436-520, 996-1068) ---------------------------------------------------------
-    for (int k = 1; k <= np; k++) {
-        const R dp = A.lay[((size_t)0 * K2 + k) * m + i], wh = A.lay[((size_t)1 * K2 + k) * m + i], oh = A.lay[((size_t)2 * K2 + k) * m + i];
+    struct In6 { R dp, wh, oh, ta, sa, as; };
+    auto ldin = [&](int k) {
+        In6 v;
+        v.dp = A.lay[((size_t)0 * K2 + k) * m + i]; v.wh = A.lay[((size_t)1 * K2 + k) * m + i]; v.oh = A.lay[((size_t)2 * K2 + k) * m + i];
         const size_t ja = ((size_t)(iv - 1) * np + (k - 1)) * ld + i;
-        const R ta_ = A.taua[ja], sa_ = A.ssaa[ja], as_ = A.asya[ja];
+        v.ta = A.taua[ja]; v.sa = A.ssaa[ja]; v.as = A.asya[ja];
+        return v;
+    };
+    In6 nin = ldin(1);
+    for (int k = 1; k <= np; k++) {
+        const In6 cin = nin;
+        if (k + 1 <= np) nin = ldin(k + 1);      // before this level's stores (see the note on the in-order memory counter below)
+        const R dp = cin.dp, wh = cin.wh, oh = cin.oh, ta_ = cin.ta, sa_ = cin.sa, as_ = cin.as;
         R taurs, tausto, ssatau;
         if (uv) {
             taurs = T.ry_uv[ib - 1] * dp;
@@ -294,8 +304,8 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
             const R asytof = (uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf)) / (ssatof * tautof);
             so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
             so_deledd<R>(tautof, ssatof, asytof, dsm, rst, tst, dum);
+            LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
         }
-        LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
     }
 
     // ---- CLDFLX (:689-872): composites from the top over the high and middle groups ---------------------------------------
