@@ -335,7 +335,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     ChouDev<R> *d_C = nullptr;
     bool have_chou = false;
     char *d_ws_ch = nullptr; size_t ws_ch_bytes = 0;
-    char *d_ws_drv = nullptr; size_t ws_drv_bytes = 0;      // RRTMG-side arrays of the GridComp drivers
+    char *d_ws_drvs[2] = {nullptr, nullptr}; size_t ws_drvs_bytes[2] = {0, 0};      // RRTMG-side arrays of the LW / SW GridComp drivers (separate: the two may run on two streams)
     // McICA segment plans (jump-ahead constants), cached per (mode, nsubcol, nlay, inhomogeneous?)
     struct PlanEntry { McSegDev *d_seg; int nseg; KissJump jsub, jhalf; };
     std::map<std::tuple<int, int, int, int>, PlanEntry> plans;
@@ -360,7 +360,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_ws_so) (void)hipFree(d_ws_so);
         if (d_C) (void)hipFree(d_C);
         if (d_ws_ch) (void)hipFree(d_ws_ch);
-        if (d_ws_drv) (void)hipFree(d_ws_drv);
+        for (char *q : d_ws_drvs) if (q) (void)hipFree(q);
         if (d_S) (void)hipFree(d_S);
         if (d_ws_sw) (void)hipFree(d_ws_sw);
         if (d_err) (void)hipFree(d_err);
@@ -538,7 +538,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         return sync_T();
     }
 
-    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + ws_drv_bytes + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
+    size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + ws_drvs_bytes[0] + ws_drvs_bytes[1] + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
     struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
@@ -707,12 +707,12 @@ template <typename R> struct Ctx : geosrad_ctx {
     }
 
     // ---- GridComp drivers (gridcomp_kernels.hpp) ---------------------------------------------------------------------------
-    int drv_reserve(size_t need)
+    int drv_reserve(int which, size_t need)
     {
-        if (need <= ws_drv_bytes) return GEOSRAD_OK;
-        if (d_ws_drv) { HIPCHK(hipFree(d_ws_drv)); d_ws_drv = nullptr; ws_drv_bytes = 0; }
-        if (hipMalloc((void **)&d_ws_drv, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the driver workspace failed");
-        ws_drv_bytes = need;
+        if (need <= ws_drvs_bytes[which]) return GEOSRAD_OK;
+        if (d_ws_drvs[which]) { HIPCHK(hipFree(d_ws_drvs[which])); d_ws_drvs[which] = nullptr; ws_drvs_bytes[which] = 0; }
+        if (hipMalloc((void **)&d_ws_drvs[which], need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the driver workspace failed");
+        ws_drvs_bytes[which] = need;
         return GEOSRAD_OK;
     }
 
@@ -733,8 +733,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         const size_t o_tsfc = take(n), o_alat = take(n), o_emis = take(n * 16), o_aer = take(cl * 16);
         for (auto &o : o_flux) o = take(cv);
         const size_t o_olrb = take(n * 16), o_dolrb = take(n * 16), o_cc = take(n * 4);
-        int rc = drv_reserve(off);
+        int rc = drv_reserve(0, off);
         if (rc) return rc;
+        char *const d_ws_drv = d_ws_drvs[0];
         auto P = [&](size_t o) { return (R *)(d_ws_drv + o); };
         LwdArgs<R> A{};
         A.ncol = ncol; A.lm = lm; A.nb = in[GEOSRAD_LWD_TAUA] ? nb : 0; A.iceflg = iceflg; A.liqflg = liqflg;
@@ -813,8 +814,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (auto &o : o_sc) o = take(n);
         for (auto &o : o_cot) o = take(n);
         const size_t o_band = take(n * 14), o_cc = take(n * 4);
-        int rc = drv_reserve(off);
+        int rc = drv_reserve(1, off);
         if (rc) return rc;
+        char *const d_ws_drv = d_ws_drvs[1];
         auto P = [&](size_t o) { return (R *)(d_ws_drv + o); };
         auto I = [&](int k) { return (const R *)in[k]; };
         SwdArgs<R> A{};
