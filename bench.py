@@ -480,6 +480,13 @@ def main():
             abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(nlay, a.real, aerosol)
         per_launch_s = (ms / max(n, 1)) * 1e-3
         achieved = abytes * (ncol / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
+        # separate rocprofv3 --pmc runs): only quoted for the exact configuration those passes were collected on
+        traffic = None
+        if a.scheme == "lwsw" and (ncol, nlay, a.cloudy, aerosol, a.real) == (97_200, 72, 0.6, True, 4):
+            traffic = {"k_sw_bands": 64.7e9, "k_lw_bands": 29.9e9}.get(kname)      # profiles/r01_v5_lwsw_pmc_traffic.md (both instantiations)
+        elif a.scheme == "chou" and (ncol, nlay, a.cloudy, aerosol, a.real) == (20_000, 72, 0.6, True, 4):
+            traffic = {"k_sorad_pass": 32.9e9, "k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
                    "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
                    "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]
@@ -498,7 +505,7 @@ def main():
                        "cloudy_fraction": a.cloudy, "aerosol": aerosol, "hip_streams": 2 if side is not None else 1,
                        "sharding": "independent column batches per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
                          "columns_per_launch": ncol / launches_per_step,
                          "note": "fused k-distribution + two-stream sweep is FP32/latency bound (~170 FLOP per algorithmic byte, "
