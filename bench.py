@@ -219,7 +219,10 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
         for k in G.LWD_OUT:
             tl[k] = zeros(lm + 1, ncol) if k in G.LWD_OUT_3D else (zeros(ncol, 16) if k in ("OLRB", "DOLRB") else zeros(ncol))
         for k in G.SWD_OUT:
-            ts[k] = zeros(lm + 1, ncol) if k in ("FSW", "FSC", "FSWU", "FSCU") else (zeros(14, ncol) if k == "FSWBAND" else zeros(ncol))
+            if k.endswith("NA") and not a.na_pass:
+                continue
+            ts[k] = (zeros(lm + 1, ncol) if k in ("FSW", "FSC", "FSWU", "FSCU", "FSWNA", "FSCNA", "FSWUNA", "FSCUNA")
+                     else (zeros(14, ncol) if k.startswith("FSWBAND") else zeros(ncol)))
         pl = {k: v.data_ptr() for k, v in tl.items()}; ps = {k: v.data_ptr() for k, v in ts.items()}
         cl, cs = G.lwd_consts(), G.swd_consts()
         ctx.set_inhomogeneity(1 if a.cloudy > 0 else 0)
@@ -335,6 +338,7 @@ def main():
     ap.add_argument("--no-aerosol", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="lwsw: RRTMG_LW and RRTMG_SW on ONE stream (default: two HIP streams - the two solvers are independent)")
+    ap.add_argument("--na-pass", action="store_true", help="gridcomp: also request the no-aerosol flavour of the SW fluxes (FSWNA ...)")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     a = ap.parse_args()

@@ -335,6 +335,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     ChouDev<R> *d_C = nullptr;
     bool have_chou = false;
     char *d_ws_ch = nullptr; size_t ws_ch_bytes = 0;
+    void *const *sw_na_out = nullptr;      // set by sw_driver_dev around its sw_dev call: outputs of the additional no-aerosol pass
     char *d_ws_drvs[2] = {nullptr, nullptr}; size_t ws_drvs_bytes[2] = {0, 0};      // RRTMG-side arrays of the LW / SW GridComp drivers (separate: the two may run on two streams)
     // McICA segment plans (jump-ahead constants), cached per (mode, nsubcol, nlay, inhomogeneous?)
     struct PlanEntry { McSegDev *d_seg; int nseg; KissJump jsub, jhalf; };
@@ -806,7 +807,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         const size_t n = (size_t)ncol, cl = n * lm, cv = n * (lm + 1);
         size_t off = 0;
         auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
-        size_t o_lay[13], o_lev[2], o_aer[3], o_flux[4], o_sc[6], o_cot[8];
+        const bool want_na = out[GEOSRAD_SWD_FSWNA] || out[GEOSRAD_SWD_FSCNA] || out[GEOSRAD_SWD_FSWUNA] || out[GEOSRAD_SWD_FSCUNA] ||
+                             out[GEOSRAD_SWD_FSWBANDNA];
+        size_t o_lay[13], o_lev[2], o_aer[3], o_flux[4], o_sc[6], o_cot[8], o_nflux[4], o_nsc[14];
         for (auto &o : o_lay) o = take(cl);
         for (auto &o : o_lev) o = take(cv);
         for (auto &o : o_aer) o = take(cl * 14);
@@ -814,6 +817,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (auto &o : o_sc) o = take(n);
         for (auto &o : o_cot) o = take(n);
         const size_t o_band = take(n * 14), o_cc = take(n * 4);
+        for (auto &o : o_nflux) o = want_na ? take(cv) : 0;
+        for (auto &o : o_nsc) o = want_na ? take(n) : 0;
+        const size_t o_nband = want_na ? take(n * 14) : 0;
         int rc = drv_reserve(1, off);
         if (rc) return rc;
         char *const d_ws_drv = d_ws_drvs[1];
@@ -850,8 +856,17 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (int k = 0; k < 8; k++) sout[SO_COT0 + k] = P(o_cot[k]);      // cotd t/h/m/l then cotn t/h/m/l
         int32_t *cc = (int32_t *)(d_ws_drv + o_cc);
         // IAER = 10 always (SOL:6235; without aerosols the arrays are zero); super-layer indices flipped in the call (SOL:6341)
+        void *nout[SO_NOUT] = {};
+        if (want_na) {
+            for (int k = 0; k < 4; k++) nout[SO_UFLX + k] = P(o_nflux[k]);
+            for (int k = 0; k < 6; k++) nout[SO_NIRR + k] = P(o_nsc[k]);
+            for (int k = 0; k < 8; k++) nout[SO_COT0 + k] = P(o_nsc[6 + k]);
+            nout[SO_FSWBAND] = out[GEOSRAD_SWD_FSWBANDNA] ? out[GEOSRAD_SWD_FSWBANDNA] : (void *)P(o_nband);
+            sw_na_out = nout;
+        }
         rc = sw_dev(st, ncol, lm, sc, dist, isolvar, sin, iceflg, liqflg, dyofyr, 10, lm - lcldlm + 1, lm - lcldmh + 1,
                     normflx, cc, sout, 0, bndsolvar, indsolvar, nullptr);
+        sw_na_out = nullptr;
         if (rc) return rc;
         SwdPost<R> Q{};
         Q.ncol = ncol; Q.lm = lm; Q.ngpt = NG_SW; Q.aerosols = include_aerosols; Q.undef = (R)consts[GEOSRAD_SWD_C_UNDEF];
@@ -861,6 +876,14 @@ template <typename R> struct Ctx : geosrad_ctx {
         Q.cldts = (R *)out[GEOSRAD_SWD_CLDTS]; Q.cldhs = (R *)out[GEOSRAD_SWD_CLDHS]; Q.cldms = (R *)out[GEOSRAD_SWD_CLDMS];
         Q.cldls = (R *)out[GEOSRAD_SWD_CLDLS];
         hipLaunchKernelGGL((k_swd_post<R>), dim3(gx, lm + 1), blk, 0, st, Q);
+        if (want_na) {      // un-flip of the no-aerosol fluxes (the FS*NAN internals, SOL:4152-4159)
+            SwdPost<R> N{};
+            N.ncol = ncol; N.lm = lm; N.ngpt = NG_SW; N.aerosols = 0; N.undef = Q.undef;
+            N.swuflx = P(o_nflux[0]); N.swdflx = P(o_nflux[1]); N.swuflxc = P(o_nflux[2]); N.swdflxc = P(o_nflux[3]); N.clearCounts = cc;
+            N.fsw = (R *)out[GEOSRAD_SWD_FSWNA]; N.fsc = (R *)out[GEOSRAD_SWD_FSCNA]; N.fswu = (R *)out[GEOSRAD_SWD_FSWUNA];
+            N.fscu = (R *)out[GEOSRAD_SWD_FSCUNA];
+            hipLaunchKernelGGL((k_swd_post<R>), dim3(gx, lm + 1), blk, 0, st, N);
+        }
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -1292,6 +1315,23 @@ template <typename R> struct Ctx : geosrad_ctx {
             for (int k = 0; k < 8; k++) O.cot[k] = Q(SO_COT0 + k);
             O.drband = Q(SO_DRBAND); O.dfband = Q(SO_DFBAND);
             span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx), blk, 0, st, A, O); span_end(st);
+            if (sw_na_out && !dbg) {
+                // the GridComp's "no-aerosol" diagnostics (GEOS_SolarGridComp.F90:3249-3259 calls the whole of SORADCORE a second
+                // time): same columns, same clouds (McICA is seeded by the pressures), same gas optical depths - only the band
+                // sweeps and the reduction are repeated, without the aerosol terms; validation, setcoef and McICA are shared
+                A.iaer = 0; A.do_drfband = 0;
+                span_begin(8, st);
+                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+                span_end(st);
+                SwOut<R> N{};
+                auto QN = [&](int k) { return (R *)sw_na_out[k] + c0; };
+                N.swuflx = QN(SO_UFLX); N.swdflx = QN(SO_DFLX); N.swuflxc = QN(SO_UFLXC); N.swdflxc = QN(SO_DFLXC);
+                N.nirr = QN(SO_NIRR); N.nirf = QN(SO_NIRF); N.parr = QN(SO_PARR); N.parf = QN(SO_PARF); N.uvrr = QN(SO_UVRR); N.uvrf = QN(SO_UVRF);
+                N.fswband = QN(SO_FSWBAND);
+                for (int k = 0; k < 8; k++) N.cot[k] = QN(SO_COT0 + k);
+                span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx), blk, 0, st, A, N); span_end(st);
+            }
         }
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;

@@ -28,7 +28,8 @@ module geosrad_gridcomp
       SWD_C_GRAV = 7, SWD_C_UNDEF = 8, SWD_NCONST = 8
    integer, parameter, public :: SWD_FSW = 1, SWD_FSC = 2, SWD_FSWU = 3, SWD_FSCU = 4, SWD_NIRR = 5, SWD_NIRF = 6, SWD_PARR = 7, &
       SWD_PARF = 8, SWD_UVRR = 9, SWD_UVRF = 10, SWD_FSWBAND = 11, SWD_CLDTS = 12, SWD_CLDHS = 13, SWD_CLDMS = 14, SWD_CLDLS = 15, &
-      SWD_COTTP = 16, SWD_COTHP = 17, SWD_COTMP = 18, SWD_COTLP = 19, SWD_NOUT = 19
+      SWD_COTTP = 16, SWD_COTHP = 17, SWD_COTMP = 18, SWD_COTLP = 19, SWD_FSWNA = 20, SWD_FSCNA = 21, SWD_FSWUNA = 22, SWD_FSCUNA = 23, &
+      SWD_FSWBANDNA = 24, SWD_NOUT = 24
    ! ---- GEOSRAD_LWU_* ----
    integer, parameter, public :: LWU_TSINST = 1, LWU_TS_INT = 2, LWU_SFCEM_INT = 3, LWU_FCLD = 4, LWU_FLX_INT = 5, LWU_FLXA_INT = 6, &
       LWU_FLC_INT = 7, LWU_FLA_INT = 8, LWU_FLXU_INT = 9, LWU_FLXAU_INT = 10, LWU_FLCU_INT = 11, LWU_FLAU_INT = 12, LWU_FLXD_INT = 13, &

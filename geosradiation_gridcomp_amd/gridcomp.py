@@ -17,7 +17,7 @@ SWD_IN = ["PLE", "PL", "T", "Q", "O3", "CH4", "CL", "TS", "QQ_ICE", "QQ_LIQ", "R
           "ALBVR", "ALBVF", "ALBNR", "ALBNF"]
 SWD_CONST = ["CO2", "O2", "AIRMW", "H2OMW", "O3MW", "RGAS", "GRAV", "UNDEF"]
 SWD_OUT = ["FSW", "FSC", "FSWU", "FSCU", "NIRR", "NIRF", "PARR", "PARF", "UVRR", "UVRF", "FSWBAND", "CLDTS", "CLDHS", "CLDMS", "CLDLS",
-           "COTTP", "COTHP", "COTMP", "COTLP"]
+           "COTTP", "COTHP", "COTMP", "COTLP", "FSWNA", "FSCNA", "FSWUNA", "FSCUNA", "FSWBANDNA"]
 
 LWU_IN = ["TSINST", "TS_INT", "SFCEM_INT", "FCLD", "FLX_INT", "FLXA_INT", "FLC_INT", "FLA_INT", "FLXU_INT", "FLXAU_INT", "FLCU_INT",
           "FLAU_INT", "FLXD_INT", "FLXAD_INT", "FLCD_INT", "FLAD_INT", "DFDTS", "DFDTSNA", "DFDTSC", "DFDTSCNA"]

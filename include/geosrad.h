@@ -290,7 +290,12 @@ enum { GEOSRAD_SWD_C_CO2, GEOSRAD_SWD_C_O2, GEOSRAD_SWD_C_AIRMW, GEOSRAD_SWD_C_H
 enum { GEOSRAD_SWD_FSW /*(ncol,LM+1) model ordering*/, GEOSRAD_SWD_FSC, GEOSRAD_SWD_FSWU, GEOSRAD_SWD_FSCU, GEOSRAD_SWD_NIRR,
        GEOSRAD_SWD_NIRF, GEOSRAD_SWD_PARR, GEOSRAD_SWD_PARF, GEOSRAD_SWD_UVRR, GEOSRAD_SWD_UVRF, GEOSRAD_SWD_FSWBAND /*(ncol,14)*/,
        GEOSRAD_SWD_CLDTS, GEOSRAD_SWD_CLDHS, GEOSRAD_SWD_CLDMS, GEOSRAD_SWD_CLDLS, GEOSRAD_SWD_COTTP, GEOSRAD_SWD_COTHP,
-       GEOSRAD_SWD_COTMP, GEOSRAD_SWD_COTLP, GEOSRAD_SWD_NOUT };
+       GEOSRAD_SWD_COTMP, GEOSRAD_SWD_COTLP,
+       /* the no-aerosol flavour (FSWNAN ... of the GridComp, which calls the whole of SORADCORE a second time for them,
+        * GEOS_SolarGridComp.F90:3249-3259): requested by a non-NULL pointer; validation, setcoef and McICA are shared with the
+        * with-aerosol pass, only the band sweeps are repeated */
+       GEOSRAD_SWD_FSWNA, GEOSRAD_SWD_FSCNA, GEOSRAD_SWD_FSWUNA, GEOSRAD_SWD_FSCUNA, GEOSRAD_SWD_FSWBANDNA /*(ncol,14)*/,
+       GEOSRAD_SWD_NOUT };
 int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nb_aer, const void *const *in,
                                 const double *consts, int iceflgsw, int liqflgsw, double sc, double dist, int isolvar, int dyofyr,
                                 int include_aerosols, int lcldlm, int lcldmh, int normflx, const void *bndsolvar,

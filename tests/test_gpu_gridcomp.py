@@ -100,7 +100,7 @@ def test_sw_driver_equals_oracle_prep_gpu_solver_oracle_post(gpu_ctx, rk):
     consts = G.swd_consts()
     ctx.set_inhomogeneity(1)
     tin, ptr = _dev(f, dt)
-    shapes = {k: (ncol,) for k in G.SWD_OUT}
+    shapes = {k: (ncol,) for k in G.SWD_OUT if not k.endswith("NA")}        # (the no-aerosol flavour has a test of its own)
     shapes.update({k: (lm + 1, ncol) for k in ("FSW", "FSC", "FSWU", "FSCU")}); shapes["FSWBAND"] = (14, ncol)
     tout, pout = _zeros(shapes, dt)
     ptr.update(pout)
@@ -202,3 +202,34 @@ def test_update_flx_full_size_properties(gpu_ctx):
     ctx.check(_stream())
     delt = t["TSINST"] - t["TS_INT"]
     assert torch.equal(out["FLX"], t["FLX_INT"] + t["DFDTS"] * delt)
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_sw_driver_no_aerosol_flavour_shares_the_cloud_generator(gpu_ctx, rk):
+    """FSWNA ... requested from the with-aerosol call (band sweeps repeated without aerosol terms; validation, setcoef, McICA shared)
+    == a separate call of the driver without aerosols, which is what the GridComp does (GEOS_SolarGridComp.F90:3249-3259)"""
+    ctx = gpu_ctx[rk]; dt = ctx.dtype
+    ncol, lm = 200, 72
+    inp = synth.make_columns(ncol, lm, start=777, cloudy_frac=0.6, aerosol=True)
+    f = synth.geos_sw_fields(inp)
+    consts = G.swd_consts()
+    ctx.set_inhomogeneity(1)
+    shapes = {k: (lm + 1, ncol) for k in ("FSW", "FSC", "FSWU", "FSCU", "FSWNA", "FSCNA", "FSWUNA", "FSCUNA")}
+    shapes["FSWBAND"] = (14, ncol); shapes["FSWBANDNA"] = (14, ncol)
+    tin, ptr = _dev(f, dt)
+    tout, pout = _zeros(shapes, dt)
+    ptr.update(pout)
+    args = (3, 1, 1361.0, 1.0, 0, int(inp["dyofyr"]))
+    ctx.sw_driver_rrtmg_dev(_stream(), ncol, lm, 14, ptr, consts, *args, True, f["LCLDLM"], f["LCLDMH"], 1)
+    ctx.check(_stream())
+    f0 = dict(f); f0["TAUA"] = None; f0["SSAA"] = None; f0["ASYA"] = None
+    tin0, ptr0 = _dev(f0, dt)
+    tout0, pout0 = _zeros({k: shapes[k] for k in ("FSW", "FSC", "FSWU", "FSCU", "FSWBAND")}, dt)
+    ptr0.update(pout0)
+    ctx.sw_driver_rrtmg_dev(_stream(), ncol, lm, 0, ptr0, consts, *args, False, f["LCLDLM"], f["LCLDMH"], 1)
+    ctx.check(_stream())
+    ctx.set_inhomogeneity(0)
+    for a, b in (("FSWNA", "FSW"), ("FSCNA", "FSC"), ("FSWUNA", "FSWU"), ("FSCUNA", "FSCU"), ("FSWBANDNA", "FSWBAND")):
+        np.testing.assert_array_equal(tout[a].cpu().numpy(), tout0[b].cpu().numpy(), err_msg=a)
+    # and the aerosols do matter in the regular flavour
+    assert np.abs(tout["FSC"].cpu().numpy() - tout["FSCNA"].cpu().numpy()).max() > 1e-3
