@@ -1314,7 +1314,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             O.fswband = Q(SO_FSWBAND);
             for (int k = 0; k < 8; k++) O.cot[k] = Q(SO_COT0 + k);
             O.drband = Q(SO_DRBAND); O.dfband = Q(SO_DFBAND);
-            span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx), blk, 0, st, A, O); span_end(st);
+            span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, O); span_end(st);
             if (sw_na_out && !dbg) {
                 // the GridComp's "no-aerosol" diagnostics (GEOS_SolarGridComp.F90:3249-3259 calls the whole of SORADCORE a second
                 // time): same columns, same clouds (McICA is seeded by the pressures), same gas optical depths - only the band
@@ -1330,7 +1330,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 N.nirr = QN(SO_NIRR); N.nirf = QN(SO_NIRF); N.parr = QN(SO_PARR); N.parf = QN(SO_PARF); N.uvrr = QN(SO_UVRR); N.uvrf = QN(SO_UVRF);
                 N.fswband = QN(SO_FSWBAND);
                 for (int k = 0; k < 8; k++) N.cot[k] = QN(SO_COT0 + k);
-                span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx), blk, 0, st, A, N); span_end(st);
+                span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, N); span_end(st);
             }
         }
         HIPCHK(hipGetLastError());

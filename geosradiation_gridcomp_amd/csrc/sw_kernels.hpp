@@ -797,8 +797,9 @@ __global__ void __launch_bounds__(256) k_sw_bands(SwArgs<R> A, SwDev<R> T, SwSol
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_sw_reduce: one thread per column (SW/rrtmg_sw_rad.F90:1515-1798): band sums in fixed order, surface
-// broadband / band diagnostics (spcvmc :624-671), clear == total for cloud-free columns, normFlx.
+// k_sw_reduce: one thread per (column, level) for the flux profiles, blockIdx.y = nlay + 1 for the per-column part
+// (SW/rrtmg_sw_rad.F90:1515-1798): band sums in fixed order, surface broadband / band diagnostics (spcvmc :624-671),
+// clear == total for cloud-free columns, normFlx.
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_sw_reduce(SwArgs<R> A, SwOut<R> O)
@@ -814,7 +815,8 @@ __global__ void __launch_bounds__(256) k_sw_reduce(SwArgs<R> A, SwOut<R> O)
     for (int b = 0; b < NB_SW; b++) top += A.part[(size_t)(ccol ? 3 : 1) * qs + ((size_t)b * (nlay + 1) + nlay) * n + col];
     R scale = 1;
     if (A.normFlx == 1) scale = top > (R)1e-7 ? top : (R)1e-7;
-    for (int lev = 0; lev <= nlay; lev++) {
+    if ((int)blockIdx.y <= nlay) {
+        const int lev = blockIdx.y;
         R s[4] = {0, 0, 0, 0};
         for (int b = 0; b < NB_SW; b++) {
             const size_t o = ((size_t)b * (nlay + 1) + lev) * n + col;
@@ -825,6 +827,7 @@ __global__ void __launch_bounds__(256) k_sw_reduce(SwArgs<R> A, SwOut<R> O)
         const size_t i = (size_t)lev * ld + pc;
         if (A.normFlx == 1) { O.swuflxc[i] = s[0] / scale; O.swdflxc[i] = s[1] / scale; O.swuflx[i] = s[2] / scale; O.swdflx[i] = s[3] / scale; }
         else { O.swuflxc[i] = s[0]; O.swdflxc[i] = s[1]; O.swuflx[i] = s[2]; O.swdflx[i] = s[3]; }
+        return;
     }
     R znirr = 0, znirf = 0, zparr = 0, zparf = 0, zuvrr = 0, zuvrf = 0;
     for (int ibm = 1; ibm <= NB_SW; ibm++) {
