@@ -40,6 +40,15 @@ GR_DEV double nf_sub(double a, double b) {
 
 struct Kiss { uint32_t s1, s2, s3, s4; };
 
+// one step of a 16-bit multiply-with-carry generator, a * (s & 65535) + (s >> 16): V_MAD_U32_U16 multiplies the LOW halves of its
+// first two operands, so the mask costs nothing (the compiler's own choice is v_and + v_mad_u32_u24)
+GR_DEV uint32_t mwc16(uint32_t s, uint32_t a)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(s), "s"(a), "v"(s >> 16));
+    return r;
+}
+
 // rng_kiss (cloud_subcol_gen.F90:570-575)
 template <typename R> GR_DEV R kiss_next(Kiss &k)
 {
@@ -47,8 +56,8 @@ template <typename R> GR_DEV R kiss_next(Kiss &k)
     uint32_t x = k.s2;
     x ^= x << 13; x ^= x >> 17; x ^= x << 5;
     k.s2 = x;
-    k.s3 = 18000u * (k.s3 & 65535u) + (k.s3 >> 16);
-    k.s4 = 30903u * (k.s4 & 65535u) + (k.s4 >> 16);
+    k.s3 = mwc16(k.s3, 18000u);
+    k.s4 = mwc16(k.s4, 30903u);
     const int32_t kiss = (int32_t)(k.s1 + k.s2 + (k.s3 << 16) + k.s4);
     return nf_add(nf_mul((R)kiss, (R)2.328306e-10), (R)0.5);
 }
