@@ -233,3 +233,50 @@ def test_sw_driver_no_aerosol_flavour_shares_the_cloud_generator(gpu_ctx, rk):
         np.testing.assert_array_equal(tout[a].cpu().numpy(), tout0[b].cpu().numpy(), err_msg=a)
     # and the aerosols do matter in the regular flavour
     assert np.abs(tout["FSC"].cpu().numpy() - tout["FSCNA"].cpu().numpy()).max() > 1e-3
+
+
+def test_lw_driver_137_layers_single_column_and_chunked_batches(gpu_ctx):
+    """edge sizes: BASELINE configs[4] layer count, one column, and a batch the solver splits into several chunks -- every column
+    must come out the same whatever the batching (bitwise)"""
+    from oracle import clib
+    ctx = gpu_ctx[8]; dt = ctx.dtype
+    consts = G.lwd_consts()
+
+    def run(inp, ncol, lm):
+        f = synth.geos_lw_fields(inp)
+        tin, ptr = _dev(f, dt)
+        tout, pout = _zeros({"FLX_INT": (lm + 1, ncol), "FLC_INT": (lm + 1, ncol), "DFDTS": (lm + 1, ncol), "SFCEM_INT": (ncol,),
+                             "CLDTTLW": (ncol,)}, dt)
+        ptr.update(pout)
+        ctx.lw_driver_rrtmg_dev(_stream(), ncol, lm, 16, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"])
+        ctx.check(_stream())
+        return f, {k: v.cpu().numpy() for k, v in tout.items()}
+
+    ctx.set_inhomogeneity(2)
+    inp = synth.make_columns(70, 137, start=31, cloudy_frac=0.5, aerosol=True)
+    f, full = run(inp, 70, 137)
+    rr = clib.lwd_prep(f, consts, 3, 1, "f64")
+    inp2 = dict(rr); inp2.update(dyofyr=inp["dyofyr"], cloudLM=inp["cloudLM"], cloudMH=inp["cloudMH"])
+    h = ctx.rrtmg_lw_columns(inp2, dudTs=True)
+    o = clib.lwd_post(h, h["clearCounts"], f["EMIS"], f["TS"], "f64", want=list(full))
+    for k in full:
+        np.testing.assert_array_equal(full[k], o[k], err_msg=k)
+    # one column (the first of the batch)
+    one = conftest_sub(inp, 1)
+    _, single = run(one, 1, 137)
+    for k in full:
+        np.testing.assert_array_equal(single[k][..., 0], full[k][..., 0], err_msg=k)
+    # several chunks
+    ctx.set_chunk(64)             # 64 + 6
+    try:
+        _, chunked = run(inp, 70, 137)
+    finally:
+        ctx.set_chunk(131072)
+        ctx.set_inhomogeneity(0)
+    for k in full:
+        np.testing.assert_array_equal(chunked[k], full[k], err_msg=k)
+
+
+def conftest_sub(inp, n):
+    from tests.conftest import sub_columns
+    return sub_columns(inp, n)
