@@ -1261,27 +1261,38 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
     if (dudTs) { PART(4, 0, dusum); if (CLD && ccol) PART(5, 0, ducsum); }
 
     // ---- upward sweep, surface -> top (:336-379) -----------------------------------------------------
+    // highest layer in which a column of this wave keeps a gas-only pair of its own (wave-uniform; no memory access): above it the
+    // parked total pairs serve both streams.  All pairs of a layer are requested together, without control flow between them.
+    int wtop = -1;
+    if (CLD) {
+        for (int l = nlay - 1; l >= 0; l--)
+            if (__ballot(ccol && diverge && ltop == l) != 0) { wtop = l; break; }
+    }
     for (int lay = 0; lay < nlay; lay++) {
         usum = 0; ucsum = 0; dusum = 0; ducsum = 0;
-        const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
+        R2 sv[NG], sg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) sv[g] = ldg(s1_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
+        if (CLD && lay <= wtop) {
+            // (lanes that have no pair of their own here read what happens to be there and do not use it)
+#pragma unroll
+            for (int g = 0; g < NG; g++) sg[g] = ldg(s2_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; g++) sg[g] = sv[g];
+        }
+        const bool own = CLD && ccol && diverge && lay <= ltop;      // above ltop the layer is clear for every g-point: gas == total
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const uint32_t scell = SCELL(lay, g);
-            const R2 sv = ldg(s1_b, scell * (uint32_t)sizeof(R2));
-            rad[g] = rad[g] + (sv.y - rad[g]) * sv.x;
-            dlu[g] = dlu[g] - dlu[g] * sv.x;
+            rad[g] = rad[g] + (sv[g].y - rad[g]) * sv[g].x;
+            dlu[g] = dlu[g] - dlu[g] * sv[g].x;
             usum = usum + sumfac * rad[g];
             dusum = dusum + sumfac * dlu[g];
-            if (CLD && ccol) {
-                if (diverge) {
-                    // above ltop the layer is clear for every g-point: gas == total
-                    const R2 sg = (lay <= ltop) ? ldg(s2_b, scell * (uint32_t)sizeof(R2)) : sv;
-                    radc[g] = radc[g] + (sg.y - radc[g]) * sg.x;
-                    dclu[g] = dclu[g] - dclu[g] * sg.x;
-                } else {
-                    radc[g] = rad[g];
-                    dclu[g] = dlu[g];
-                }
+            if (CLD) {
+                const R gx = own ? sg[g].x : sv[g].x, gy = own ? sg[g].y : sv[g].y;
+                const R rc = radc[g] + (gy - radc[g]) * gx, dc = dclu[g] - dclu[g] * gx;
+                radc[g] = diverge ? rc : rad[g];
+                dclu[g] = diverge ? dc : dlu[g];
                 ucsum = ucsum + sumfac * radc[g];
                 ducsum = ducsum + sumfac * dclu[g];
             }
