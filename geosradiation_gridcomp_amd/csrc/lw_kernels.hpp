@@ -1171,14 +1171,34 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
             __builtin_amdgcn_sched_barrier(0);   // keep one g-group's table rows in flight at a time
         }
         } else {
+        // general (cloudy-column) body.  Control flow around memory operations is wave-uniform only (ballots): a per-lane branch
+        // with a load inside makes the loads of a group wait for one another.  Lanes the test does not concern load / store
+        // along and select afterwards (their values are never used: unwritten cloud cells, gas-only pairs above their own cloud top).
+        const bool wlc = CLD && __ballot(laycld) != 0;       // some column of the wave has cloud in this layer
+        const bool wdv = CLD && __ballot(diverge) != 0;      // some column of the wave keeps gas-only pairs from here down
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
+            R tcv[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) tcv[j] = 0;
+            if (wlc) {
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    if (q * W + j < NG) tcv[j] = ldg(taucmc_b, (cell0 + (uint32_t)(q * W + j) * (uint32_t)n) * (uint32_t)sizeof(R));
+#pragma unroll
+                for (int j = 0; j < W; j++) tcv[j] = laycld ? tcv[j] : (R)0;
+            }
             R tau[W], pf[W];
             BAND::template eval<R, W>(T, L, P, q * W, tau, pf);
+            int itg[W];
+            R2 eg[W];
+            R ttb[W];
+            bool anyc = false;
 #pragma unroll
             for (int j = 0; j < W; j++) {
                 const int g = q * W + j;
-                if (g >= NG) continue;   // padding of the last group
+                ttb[j] = 0;
+                if (g >= NG) { itg[j] = 0; eg[j].x = 0; eg[j].y = 0; continue; }   // padding of the last group
                 if (DBG) {
                     const size_t o = ((size_t)pc * NG_LW + (G0 + g)) * nlay + lay;   // Fortran (nlay,140,ncol)
                     A.dbg_taug[o] = tau[j] + ta;
@@ -1187,43 +1207,43 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
                 R odepth = secdiff * (tau[j] + ta);
                 if (odepth < 0) odepth = 0;
                 const R tblind = odepth / (bpade + odepth);
-                const int itgas = (int)(tblint * tblind + (R)0.5);
-                const R2 e = lut_at(itgas);
-                const R agas = (R)1. - e.x, tfacgas = e.y;
+                itg[j] = (int)(tblint * tblind + (R)0.5);
+                eg[j] = lut_at(itg[j]);
+                anyc = anyc || tcv[j] > 0;
+            }
+            const bool wcl = wlc && __ballot(anyc) != 0;         // some cell of the group is cloudy in some column of the wave
+            if (wcl) {
+#pragma unroll
+                for (int j = 0; j < W; j++) ttb[j] = ldg(T.tau_tbl, (uint32_t)itg[j] * (uint32_t)sizeof(R));
+            }
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                if (g >= NG) continue;
+                const R agas = (R)1. - eg[j].x, tfacgas = eg[j].y;
                 const R bbdgas = pf[j] * (blay + tfacgas * dplankdn);
                 const R bbugas = pf[j] * (blay + tfacgas * dplankup);
-                const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
                 const uint32_t scell = SCELL(lay, g);
-                R atot = agas, bbutot = bbugas;
-                const R radprev = rad[g];
-                bool cldcell = false;
-                if (CLD && laycld) {
-                    const R tc = ldg(taucmc_b, cell * (uint32_t)sizeof(R));
-                    if (tc > 0) {
-                        cldcell = true;
-                        // cloud added to the DISCRETISED gas tau (:264-268)
-                        const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
-                        const R tb2 = odtot / (bpade + odtot);
-                        const int ittot = (int)(tblint * tb2 + (R)0.5);
-                        const R2 e2 = lut_at(ittot);
-                        atot = (R)1. - e2.x;
-                        const R bbdtot = pf[j] * (blay + e2.y * dplankdn);
-                        bbutot = pf[j] * (blay + e2.y * dplankup);
-                        rad[g] = radprev + (bbdtot - radprev) * atot;
-                    }
+                R atot = agas, bbutot = bbugas, bbd = bbdgas;
+                if (wcl) {
+                    // cloud added to the DISCRETISED gas tau (:264-268); evaluated for the whole wave, kept for the cloudy cells
+                    const bool cld = tcv[j] > 0;
+                    const R odtot = ttb[j] + secdiff * tcv[j];
+                    const R tb2 = odtot / (bpade + odtot);
+                    const int ittot = (int)(tblint * tb2 + (R)0.5);
+                    const R2 e2 = lut_at(cld ? ittot : itg[j]);
+                    const R ac = (R)1. - e2.x;
+                    const R bbdtot = pf[j] * (blay + e2.y * dplankdn), bbut = pf[j] * (blay + e2.y * dplankup);
+                    atot = cld ? ac : agas; bbutot = cld ? bbut : bbugas; bbd = cld ? bbdtot : bbdgas;
                 }
-                if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
+                rad[g] = rad[g] + (bbd - rad[g]) * atot;
                 R2 sv; sv.x = atot; sv.y = bbutot;
                 stg(s1_b, scell * (uint32_t)sizeof(R2), sv);
                 dsum = dsum + sumfac * rad[g];
-                if (CLD && ccol) {
-                    if (diverge) {
-                        radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
-                        R2 sg; sg.x = agas; sg.y = bbugas;
-                        stg(s2_b, scell * (uint32_t)sizeof(R2), sg);
-                    } else {
-                        radc[g] = rad[g];
-                    }
+                if (CLD) {
+                    const R rc = radc[g] + (bbdgas - radc[g]) * agas;
+                    radc[g] = diverge ? rc : rad[g];
+                    if (wdv) { R2 sg; sg.x = agas; sg.y = bbugas; stg(s2_b, scell * (uint32_t)sizeof(R2), sg); }
                     dcsum = dcsum + sumfac * radc[g];
                 }
                 if (lay == 0) {
