@@ -683,6 +683,86 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
         const uint32_t cellu = ((uint32_t)(lay + 1) * (uint32_t)NG) * (uint32_t)n + ucol;    // layer above: holds this level's tdbt/ztdn/prdnd
         R cu = 0, cd = 0, fu = 0, fd = 0;
         uint32_t cnext = 0;
+        if constexpr (CLD) {
+        // cloudy columns: four g-points at a time - all clear-sky values of the chunk are requested together, two wave-uniform tests
+        // (ballots) decide whether the chunk's total-sky values are requested at all, and only then does the arithmetic start.
+        // A per-lane branch around each conditional load made every load of a layer wait for the one before it.  Lanes a test
+        // does not concern load along and select the clear-sky value afterwards.
+        constexpr int GC = 4;
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += GC) {
+            R ref[GC], refd[GC], tra[GC], trad[GC], dbt[GC], tbc[GC], ztc[GC], prc[GC];
+            R refT[GC], refdT[GC], traT[GC], tradT[GC], dbtT[GC], tbT[GC], ztT[GC], prT[GC];
+            bool ldv[GC];
+            bool anycm = false, anydv = false;
+#pragma unroll
+            for (int j = 0; j < GC; j++) {
+                const int g = g0 + j;
+                if (g >= NG) continue;
+                const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
+                const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
+                ref[j] = ldg(CELL(0), c4); refd[j] = ldg(CELL(1), c4); tra[j] = ldg(CELL(2), c4); trad[j] = ldg(CELL(3), c4); dbt[j] = ldg(CELL(4), c4);
+                if (jk > 0) { tbc[j] = ldg(CELL(5), u4); ztc[j] = ldg(CELL(6), u4); prc[j] = ldg(CELL(7), u4); }
+                else { tbc[j] = 1; ztc[j] = 1; prc[j] = 0; }
+            }
+#pragma unroll
+            for (int j = 0; j < GC; j++) {
+                const int g = g0 + j;
+                ldv[j] = false;
+                if (g >= NG) continue;
+                ldv[j] = ccol && jk > 0 && __builtin_signbit(tbc[j]);
+                tbc[j] = __builtin_signbit(tbc[j]) ? -tbc[j] : tbc[j];
+                anydv = anydv || ldv[j];
+                anycm = anycm || (ccol && ((cmask >> g) & 1u));
+            }
+            const bool wcm = __ballot(anycm) != 0, wdv = __ballot(anydv) != 0;
+#pragma unroll
+            for (int j = 0; j < GC; j++) {
+                const int g = g0 + j;
+                refT[j] = ref[j]; refdT[j] = refd[j]; traT[j] = tra[j]; tradT[j] = trad[j]; dbtT[j] = dbt[j];
+                tbT[j] = tbc[j]; ztT[j] = ztc[j]; prT[j] = prc[j];
+                if (g >= NG) continue;
+                const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
+                const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
+                if (wcm) { refT[j] = ldg(CELL(8), c4); refdT[j] = ldg(CELL(9), c4); traT[j] = ldg(CELL(10), c4); tradT[j] = ldg(CELL(11), c4); dbtT[j] = ldg(CELL(12), c4); }
+                if (wdv) { tbT[j] = ldg(CELL(13), u4); ztT[j] = ldg(CELL(14), u4); prT[j] = ldg(CELL(15), u4); }
+            }
+#pragma unroll
+            for (int j = 0; j < GC; j++) {
+                const int g = g0 + j;
+                if (g >= NG) continue;
+                const R zi = zinc[g] * prmu0;
+                {
+                    const R zrj = f_rcp<R>((R)1. - prupd[g] * refd[j]);
+                    const R pu = ref[j] + (trad[j] * ((tra[j] - dbt[j]) * prupd[g] + dbt[j] * prup[g])) * zrj;
+                    const R pd = refd[j] + trad[j] * trad[j] * prupd[g] * zrj;
+                    prup[g] = pu; prupd[g] = pd;
+                    const R zr = f_rcp<R>((R)1. - prc[j] * pd);
+                    cu = cu + zi * ((tbc[j] * pu + (ztc[j] - tbc[j]) * pd) * zr);
+                    cd = cd + zi * (tbc[j] + (ztc[j] - tbc[j] + tbc[j] * pu * prc[j]) * zr);
+                }
+                {
+                    const bool cm = ccol && ((cmask >> g) & 1u);
+                    const R r0 = cm ? refT[j] : ref[j], r1 = cm ? refdT[j] : refd[j], r2 = cm ? traT[j] : tra[j], r3 = cm ? tradT[j] : trad[j],
+                            r4 = cm ? dbtT[j] : dbt[j];
+                    const R zrj = f_rcp<R>((R)1. - prupdT[g] * r1);
+                    const R pu = r0 + (r3 * ((r2 - r4) * prupdT[g] + r4 * prupT[g])) * zrj;
+                    const R pd = r1 + r3 * r3 * prupdT[g] * zrj;
+                    prupT[g] = pu; prupdT[g] = pd;
+                    // above the sub-column's highest cloud: the clear-sky values
+                    const bool dv = ldv[j];
+                    const bool cl = dv && __builtin_signbit(tbT[j]);          // the layer above is cloudy in this sub-column
+                    if (cl) cnext |= 1u << g;
+                    const R tbr = dv ? tbT[j] : tbc[j];
+                    const R tb = cl ? -tbr : tbr, zt = dv ? ztT[j] : ztc[j], pr = dv ? prT[j] : prc[j];
+                    const R zr = f_rcp<R>((R)1. - pr * pd);
+                    fu = fu + zi * ((tb * pu + (zt - tb) * pd) * zr);
+                    fd = fd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one chunk's values in flight at a time
+        }
+        } else {
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
@@ -721,6 +801,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 fu = fu + zi * ((tb * pu + (zt - tb) * pd) * zr);
                 fd = fd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
             }
+        }
         }
         PART(0, lay + 1, cu); PART(1, lay + 1, cd);
         if (CLD && ccol) { PART(2, lay + 1, fu); PART(3, lay + 1, fd); }
@@ -767,7 +848,7 @@ __host__ __device__ constexpr int sw_band_ng(int jb)
 }
 
 template <typename R, bool CLD, bool DBG>
-__global__ void __launch_bounds__(256) k_sw_bands(SwArgs<R> A, SwDev<R> T, SwSolar<R> SV)
+__global__ void __launch_bounds__(256, (sizeof(R) == 4 ? 2 : 1)) k_sw_bands(SwArgs<R> A, SwDev<R> T, SwSolar<R> SV)
 {
     const int nclear = *A.nclear;
     // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
