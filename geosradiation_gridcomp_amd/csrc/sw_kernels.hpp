@@ -562,10 +562,34 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
         }
         const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
         const bool laycld = CLD && ccol && ldg(A.laycloudy, (uint32_t)lay * (uint32_t)n + ucol) != 0;
+        const bool wlc = CLD && __ballot(laycld) != 0;      // some column of the wave has cloud in this layer (wave-uniform)
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
+            // cloud optics of the group's cells: requested together behind wave-uniform tests and selected afterwards (a per-lane
+            // branch around each load made the loads wait for one another); lanes without cloud here read cells nobody wrote
+            R tcv[W], ocv[W], gcv[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) { tcv[j] = 0; ocv[j] = 0; gcv[j] = 0; }
+            if (wlc) {
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    if (q * W + j < NG) tcv[j] = ldg(tcb, (cell0 + (uint32_t)(q * W + j) * (uint32_t)n) * (uint32_t)sizeof(R));
+            }
             R tg[W], tr[W];
             sw_eval<R, B, W>(T, L, P, q * W, tg, tr);
+            if (wlc) {
+                bool anyc = false;
+#pragma unroll
+                for (int j = 0; j < W; j++) { tcv[j] = laycld ? tcv[j] : (R)0; anyc = anyc || tcv[j] > 0; }
+                if (__ballot(anyc) != 0) {
+#pragma unroll
+                    for (int j = 0; j < W; j++)
+                        if (q * W + j < NG) {
+                            const uint32_t o4 = (cell0 + (uint32_t)(q * W + j) * (uint32_t)n) * (uint32_t)sizeof(R);
+                            ocv[j] = ldg(ocb, o4); gcv[j] = ldg(gcb, o4);
+                        }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < W; j++) {
                 const int g = q * W + j;
@@ -604,7 +628,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 const R tdbt_clear = tdbt[g];
                 bool cellcld = false;
                 R tc = 0;
-                if (CLD && ccol && laycld) { tc = ldg(tcb, cb4); cellcld = tc > 0; }
+                if (CLD) { tc = tcv[j]; cellcld = tc > 0; }
                 // Above the highest cloudy cell of a sub-column the total-sky downward state IS the clear-sky one (same recurrences,
                 // same inputs): nothing is computed or parked for it there; the sign bit of the parked clear-sky T_dir^cum tells
                 // sweep B from which level on the total sky has values of its own.
@@ -615,7 +639,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                     dmask |= 1u << g;
                     // total sky: cloudy cells get the (already delta-scaled) cloud optics added (:512-536, 541, 547-559)
                     if (cellcld) {
-                        const R oc = ldg(ocb, cb4), gc = ldg(gcb, cb4);
+                        const R oc = ocv[j], gc = gcv[j];
                         R g2 = ztauo * zomco * zgco + tc * oc * gc;
                         R o2 = ztauo * zomco + tc * oc;
                         const R t2 = ztauo + tc;
