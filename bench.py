@@ -488,7 +488,7 @@ def main():
         # separate rocprofv3 --pmc runs): only quoted for the exact configuration those passes were collected on
         traffic = None
         if a.scheme == "lwsw" and (ncol, nlay, a.cloudy, aerosol, a.real) == (97_200, 72, 0.6, True, 4):
-            traffic = {"k_sw_bands": 64.7e9, "k_lw_bands": 29.9e9}.get(kname)      # profiles/r01_v5_lwsw_pmc_traffic.md (both instantiations)
+            traffic = {"k_sw_bands": 66.6e9, "k_lw_bands": 30.1e9}.get(kname)      # profiles/r01_v9_lwsw_pmc_traffic.md (both instantiations)
         elif a.scheme == "chou" and (ncol, nlay, a.cloudy, aerosol, a.real) == (20_000, 72, 0.6, True, 4):
             traffic = {"k_sorad_pass": 32.9e9, "k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
