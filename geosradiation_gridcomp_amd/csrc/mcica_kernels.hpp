@@ -372,27 +372,45 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
         const R thr = nf_sub((R)1., cf);
         const R sigma = cf > (R)0.99 ? (R)0.5 : (cf > (R)0.9 ? (R)0.71 : (R)1.0);
         const bool in_hi = il >= hi0 && il <= hi1, in_mid = il >= mi0 && il <= mi1, in_lo = il >= lo0 && il <= lo1;
+        // the draws of the segment's sub-columns first; then, if any sub-column of any column of the wave is cloudy here, the
+        // condensate scaling factors of all of them together (four table values each) - not one look-up per cloudy sub-column
+        // inside a per-lane branch, where each would wait for the one before
+        bool cldy[MC_S];
+        R zcws[MC_S];
+        bool anyc = false;
 #pragma unroll
         for (int s = 0; s < MC_S; s++) {
+            cldy[s] = false; zcws[s] = 1;
             if (s >= ns) continue;
             // cloud presence with exponential overlap (:406-414)
             R cdf1 = kiss_next<R>(k1[s]);
             const R cdf2 = kiss_next<R>(k1[s]);
             if (il > 0 && cdf2 < al) cdf1 = cprev[s];
             cprev[s] = cdf1;
-            const bool cloudy = cdf1 >= thr;
-            R ci = 0, cl = 0;
+            cldy[s] = cdf1 >= thr;
+            anyc = anyc || cldy[s];
             if (inhomo) {
                 // condensate with exponential overlap + inhomogeneity (:416-466); the stream is consumed for every layer
                 const R c2 = kiss_next<R>(k2[s]);
                 R cdf3 = kiss_next<R>(k2[s]);
                 if (il > 0 && c2 < rc) cdf3 = c3prev[s];
                 c3prev[s] = cdf3;
-                if (cloudy) {
-                    const R zcw = zcw_lookup<R>(T.xcw, cdf3, sigma);
-                    ci = nf_mul(ciw, zcw); cl = nf_mul(clw, zcw);
-                }
-            } else if (cloudy) { ci = ciw; cl = clw; }      // homogeneous condensate (:438-443)
+            }
+        }
+        if (inhomo && __ballot(anyc) != 0) {
+#pragma unroll
+            for (int s = 0; s < MC_S; s++)
+                if (s < ns) zcws[s] = zcw_lookup<R>(T.xcw, c3prev[s], sigma);
+        }
+#pragma unroll
+        for (int s = 0; s < MC_S; s++) {
+            if (s >= ns) continue;
+            const bool cloudy = cldy[s];
+            R ci = 0, cl = 0;
+            if (cloudy) {
+                if (inhomo) { ci = nf_mul(ciw, zcws[s]); cl = nf_mul(clw, zcws[s]); }
+                else { ci = ciw; cl = clw; }      // homogeneous condensate (:438-443)
+            }
             bool c = false;
             if (cloudy) {
                 const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
