@@ -170,18 +170,16 @@ __global__ void __launch_bounds__(256) k_overlap(int ncol, int ld, int nlay, int
     }
 }
 
-// LW cloud optical depth of one McICA cell (LW/rrtmg_lw_cldprmc.F90:84-360); returns tau, raises error
-// bits where the reference would `error stop`.
+// LW cloud absorption coefficients of one (layer, band): tau = ciwp * kice + clwp * kliq (LW/rrtmg_lw_cldprmc.F90:84-360).  They
+// depend on the effective radii only, so they are looked up once per layer for all sub-columns of the segment; error bits where the
+// reference would `error stop` (it does so in cloudy cells only: the caller raises them only if a cell of the layer is cloudy).
 template <typename R>
-GR_DEV R lw_cloud_tau(const LwDev<R> &T, int iceflag, int ib, R ciwp, R clwp, R reice, R reliq, uint32_t &err)
+GR_DEV void lw_cloud_coef(const LwDev<R> &T, int iceflag, int ib, R reice, R reliq, R &kice, R &kliq, uint32_t &err)
 {
-    R tau = 0;
-    // ---- ice ----
-    if (iceflag == 0) {
-        if (ciwp > 0) tau = ciwp * (T.absice0[0] + T.absice0[1] / reice);
-    } else if (iceflag == 1) {
-        if (ciwp > 0) { const int i1 = T.ice1b[ib - 1]; tau = ciwp * (T.absice1[(i1 - 1) * 2] + T.absice1[(i1 - 1) * 2 + 1] / reice); }
-    } else {
+    kice = 0; kliq = 0;
+    if (iceflag == 0) kice = T.absice0[0] + T.absice0[1] / reice;
+    else if (iceflag == 1) { const int i1 = T.ice1b[ib - 1]; kice = T.absice1[(i1 - 1) * 2] + T.absice1[(i1 - 1) * 2 + 1] / reice; }
+    else {
         R factor; int nmax; const R *tab;
         if (iceflag == 2) { factor = (reice - (R)2.) / (R)3.; nmax = 43; tab = T.absice2; }
         else if (iceflag == 3) { factor = (reice - (R)2.) / (R)3.; nmax = 46; tab = T.absice3; }
@@ -190,24 +188,18 @@ GR_DEV R lw_cloud_tau(const LwDev<R> &T, int iceflag, int ib, R ciwp, R clwp, R 
         if (index >= nmax) { if (index == nmax) index = nmax - 1; else { err |= 1u << ERR_ICE_RADIUS_HI; index = nmax - 1; } }
         else if (index <= 0) { if (index == 0) index = 1; else { err |= 1u << ERR_ICE_RADIUS_LO; index = 1; } }
         const R fint = factor - (R)index;
-        if (ciwp > 0) {
-            const R *p = tab + (size_t)(ib - 1) * nmax + (index - 1);
-            tau = ciwp * (p[0] + fint * (p[1] - p[0]));
-        }
+        const R *p = tab + (size_t)(ib - 1) * nmax + (index - 1);
+        kice = p[0] + fint * (p[1] - p[0]);
     }
-    // ---- liquid (liqflag == 1, Hu & Stamnes) ----
     {
         const R factor = reliq - (R)1.5;
         int index = (int)factor;
         if (index >= 58) { if (index == 58) index = 57; else { err |= 1u << ERR_LIQ_RADIUS_HI; index = 57; } }
         else if (index <= 0) { if (index == 0) index = 1; else { err |= 1u << ERR_LIQ_RADIUS_LO; index = 1; } }
         const R fint = factor - (R)index;
-        if (clwp > 0) {
-            const R *p = T.absliq1 + (size_t)(ib - 1) * 58 + (index - 1);
-            tau = tau + clwp * (p[0] + fint * (p[1] - p[0]));
-        }
+        const R *p = T.absliq1 + (size_t)(ib - 1) * 58 + (index - 1);
+        kliq = p[0] + fint * (p[1] - p[0]);
     }
-    return tau;
 }
 
 // cldprmc_sw for one cloudy cell (SW/rrtmg_sw_cldprmc.F90:131-411): un-scaled tau (taormc) and the delta-scaled
@@ -397,11 +389,15 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
                 c3prev[s] = cdf3;
             }
         }
-        if (inhomo && __ballot(anyc) != 0) {
+        const bool wany = __ballot(anyc) != 0;
+        if (inhomo && wany) {
 #pragma unroll
             for (int s = 0; s < MC_S; s++)
                 if (s < ns) zcws[s] = zcw_lookup<R>(T.xcw, c3prev[s], sigma);
         }
+        R kice = 0, kliq = 0;
+        uint32_t kerr = 0;
+        if (MODE == 0 && wany) lw_cloud_coef<R>(T, M.iceflg, ib, rei, rel, kice, kliq, kerr);
 #pragma unroll
         for (int s = 0; s < MC_S; s++) {
             if (s >= ns) continue;
@@ -429,7 +425,11 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
             if (MODE == 0) {
                 if (cf > 0) {
                     R tau = 0;
-                    if (c) tau = lw_cloud_tau<R>(T, M.iceflg, ib, ci, cl, rei, rel, err);
+                    if (c) {
+                        if (ci > 0) tau = ci * kice;
+                        if (cl > 0) tau = tau + cl * kliq;
+                        err |= kerr;
+                    }
                     M.taucmc[tb0 + (size_t)s * n + (size_t)il * tbs] = tau;
                     if (tau > 0) M.laycloudy[w] = 1;
                 }
