@@ -202,62 +202,74 @@ GR_DEV void lw_cloud_coef(const LwDev<R> &T, int iceflag, int ib, R reice, R rel
     }
 }
 
-// cldprmc_sw for one cloudy cell (SW/rrtmg_sw_cldprmc.F90:131-411): un-scaled tau (taormc) and the delta-scaled
-// tau / single-scattering albedo / asymmetry of the combined liquid + ice cloud.  jb = 16..29.
+// cldprmc_sw (SW/rrtmg_sw_cldprmc.F90:131-411) in two steps: the extinction / single-scattering / asymmetry / forward-scattering
+// coefficients of ice and liquid depend on the effective radii only (one look-up per (layer, band) for all sub-columns of the
+// segment); the cell then combines them with its water paths: un-scaled tau (taormc) and the delta-scaled tau / single-scattering
+// albedo / asymmetry of the liquid + ice cloud.  jb = 16..29.
+template <typename R> struct SwCldCoef { R extcoice, ssacoice, gice, forwice, extcoliq, ssacoliq, gliq, forwliq; };
+
 template <typename R>
-GR_DEV void sw_cloud_optics(const SwDev<R> &S, int iceflag, int jb, R ciwp, R clwp, R radice, R radliq, R &taor, R &tauc, R &ssac,
-                            R &asmc)
+GR_DEV SwCldCoef<R> sw_cloud_coef(const SwDev<R> &S, int iceflag, int jb, R radice, R radliq)
 {
-    const R epsg = (R)1.e-06, cldmin = (R)1.e-20;
+    const R epsg = (R)1.e-06;
     const int ib = jb - 16;      // 0-based column of the (n,16:29) tables
-    R extcoice = 0, ssacoice = 0, gice = 0, forwice = 0, extcoliq = 0, ssacoliq = 0, gliq = 0, forwliq = 0;
+    SwCldCoef<R> c;
 #define LIN_T(tab, nmax) ((tab)[(size_t)ib * (nmax) + index - 1] + fint * ((tab)[(size_t)ib * (nmax) + index] - (tab)[(size_t)ib * (nmax) + index - 1]))
-    if (ciwp != 0) {
-        if (iceflag == 1) {
-            const int ic = S.icxa[jb - 15] - 1;
-            extcoice = S.abari[ic] + S.bbari[ic] / radice;
-            ssacoice = (R)1. - S.cbari[ic] - S.dbari[ic] * radice;
-            gice = S.ebari[ic] + S.fbari[ic] * radice;
-            if (gice > (R)1. - epsg) gice = (R)1. - epsg;
-            forwice = gice * gice;
-        } else if (iceflag == 2) {
-            const R factor = (radice - (R)2.) / (R)3.;
-            int index = (int)factor; if (index == 43) index = 42;
-            const R fint = factor - (R)index;
-            index = clampi(index, 1, 42);      // memory safety only: the reference does not range-check here
-            extcoice = LIN_T(S.extice2, 43); ssacoice = LIN_T(S.ssaice2, 43); gice = LIN_T(S.asyice2, 43);
-            forwice = gice * gice;
-        } else if (iceflag == 3) {
-            const R factor = (radice - (R)2.) / (R)3.;
-            int index = (int)factor; if (index == 46) index = 45;
-            const R fint = factor - (R)index;
-            index = clampi(index, 1, 45);
-            extcoice = LIN_T(S.extice3, 46); ssacoice = LIN_T(S.ssaice3, 46); gice = LIN_T(S.asyice3, 46);
-            const R fdelta = LIN_T(S.fdlice3, 46);
-            forwice = fdelta + (R)0.5 / ssacoice;
-            if (forwice > gice) forwice = gice;
-        } else {
-            const R factor = radice;
-            int index = (int)factor;
-            const R fint = factor - (R)index;
-            index = clampi(index, 1, 199);
-            extcoice = LIN_T(S.extice4, 200); ssacoice = LIN_T(S.ssaice4, 200); gice = LIN_T(S.asyice4, 200);
-            forwice = gice * gice;
-        }
+    if (iceflag == 1) {
+        const int ic = S.icxa[jb - 15] - 1;
+        c.extcoice = S.abari[ic] + S.bbari[ic] / radice;
+        c.ssacoice = (R)1. - S.cbari[ic] - S.dbari[ic] * radice;
+        c.gice = S.ebari[ic] + S.fbari[ic] * radice;
+        if (c.gice > (R)1. - epsg) c.gice = (R)1. - epsg;
+        c.forwice = c.gice * c.gice;
+    } else if (iceflag == 2) {
+        const R factor = (radice - (R)2.) / (R)3.;
+        int index = (int)factor; if (index == 43) index = 42;
+        const R fint = factor - (R)index;
+        index = clampi(index, 1, 42);      // memory safety only: the reference does not range-check here
+        c.extcoice = LIN_T(S.extice2, 43); c.ssacoice = LIN_T(S.ssaice2, 43); c.gice = LIN_T(S.asyice2, 43);
+        c.forwice = c.gice * c.gice;
+    } else if (iceflag == 3) {
+        const R factor = (radice - (R)2.) / (R)3.;
+        int index = (int)factor; if (index == 46) index = 45;
+        const R fint = factor - (R)index;
+        index = clampi(index, 1, 45);
+        c.extcoice = LIN_T(S.extice3, 46); c.ssacoice = LIN_T(S.ssaice3, 46); c.gice = LIN_T(S.asyice3, 46);
+        const R fdelta = LIN_T(S.fdlice3, 46);
+        c.forwice = fdelta + (R)0.5 / c.ssacoice;
+        if (c.forwice > c.gice) c.forwice = c.gice;
+    } else {
+        const R factor = radice;
+        int index = (int)factor;
+        const R fint = factor - (R)index;
+        index = clampi(index, 1, 199);
+        c.extcoice = LIN_T(S.extice4, 200); c.ssacoice = LIN_T(S.ssaice4, 200); c.gice = LIN_T(S.asyice4, 200);
+        c.forwice = c.gice * c.gice;
     }
-    if (clwp != 0) {
+    {
         int index = (int)(radliq - (R)1.5);
         if (index == 0) index = 1;
         if (index == 58) index = 57;
         const R fint = radliq - (R)1.5 - (R)index;
         index = clampi(index, 1, 57);
-        extcoliq = LIN_T(S.extliq1, 58);
-        ssacoliq = LIN_T(S.ssaliq1, 58);
-        if (fint < 0 && ssacoliq > (R)1.) ssacoliq = S.ssaliq1[(size_t)ib * 58 + index - 1];
-        gliq = LIN_T(S.asyliq1, 58);
-        forwliq = gliq * gliq;
+        c.extcoliq = LIN_T(S.extliq1, 58);
+        c.ssacoliq = LIN_T(S.ssaliq1, 58);
+        if (fint < 0 && c.ssacoliq > (R)1.) c.ssacoliq = S.ssaliq1[(size_t)ib * 58 + index - 1];
+        c.gliq = LIN_T(S.asyliq1, 58);
+        c.forwliq = c.gliq * c.gliq;
     }
 #undef LIN_T
+    return c;
+}
+
+template <typename R>
+GR_DEV void sw_cloud_optics(const SwCldCoef<R> &c, int iceflag, R ciwp, R clwp, R &taor, R &tauc, R &ssac, R &asmc)
+{
+    const R cldmin = (R)1.e-20;
+    // a phase without condensate enters with zero coefficients, as the reference leaves them (:131-133)
+    const bool ice = ciwp != 0, liq = clwp != 0;
+    const R extcoice = ice ? c.extcoice : (R)0, ssacoice = ice ? c.ssacoice : (R)0, gice = ice ? c.gice : (R)0, forwice = ice ? c.forwice : (R)0;
+    const R extcoliq = liq ? c.extcoliq : (R)0, ssacoliq = liq ? c.ssacoliq : (R)0, gliq = liq ? c.gliq : (R)0, forwliq = liq ? c.forwliq : (R)0;
     const R tauliqorig = clwp * extcoliq, tauiceorig = ciwp * extcoice;
     taor = tauliqorig + tauiceorig;
     const R ssaliq = ssacoliq * ((R)1. - forwliq) / ((R)1. - forwliq * ssacoliq);
@@ -398,6 +410,8 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
         R kice = 0, kliq = 0;
         uint32_t kerr = 0;
         if (MODE == 0 && wany) lw_cloud_coef<R>(T, M.iceflg, ib, rei, rel, kice, kliq, kerr);
+        SwCldCoef<R> swc{};
+        if (MODE == 2 && wany) swc = sw_cloud_coef<R>(*Sp, M.iceflg, ib, rei, rel);
 #pragma unroll
         for (int s = 0; s < MC_S; s++) {
             if (s >= ns) continue;
@@ -435,7 +449,7 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
                 }
             } else if (MODE == 2) {
                 R taor = 0, tauc = 0, ssac = 1, asmc = 0;
-                if (c) sw_cloud_optics<R>(*Sp, M.iceflg, ib, ci, cl, rei, rel, taor, tauc, ssac, asmc);
+                if (c) sw_cloud_optics<R>(swc, M.iceflg, ci, cl, taor, tauc, ssac, asmc);
                 if (cf > 0) {
                     const size_t oc = tb0 + (size_t)s * n + (size_t)il * tbs;
                     M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
