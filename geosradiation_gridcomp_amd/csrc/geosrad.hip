@@ -335,7 +335,6 @@ template <typename R> struct Ctx : geosrad_ctx {
     ChouDev<R> *d_C = nullptr;
     bool have_chou = false;
     char *d_ws_ch = nullptr; size_t ws_ch_bytes = 0;
-    void *const *sw_na_out = nullptr;      // set by sw_driver_dev around its sw_dev call: outputs of the additional no-aerosol pass
     char *d_ws_drvs[2] = {nullptr, nullptr}; size_t ws_drvs_bytes[2] = {0, 0};      // RRTMG-side arrays of the LW / SW GridComp drivers (separate: the two may run on two streams)
     // McICA segment plans (jump-ahead constants), cached per (mode, nsubcol, nlay, inhomogeneous?)
     struct PlanEntry { McSegDev *d_seg; int nseg; KissJump jsub, jhalf; };
@@ -862,11 +861,9 @@ template <typename R> struct Ctx : geosrad_ctx {
             for (int k = 0; k < 6; k++) nout[SO_NIRR + k] = P(o_nsc[k]);
             for (int k = 0; k < 8; k++) nout[SO_COT0 + k] = P(o_nsc[6 + k]);
             nout[SO_FSWBAND] = out[GEOSRAD_SWD_FSWBANDNA] ? out[GEOSRAD_SWD_FSWBANDNA] : (void *)P(o_nband);
-            sw_na_out = nout;
         }
-        rc = sw_dev(st, ncol, lm, sc, dist, isolvar, sin, iceflg, liqflg, dyofyr, 10, lm - lcldlm + 1, lm - lcldmh + 1,
-                    normflx, cc, sout, 0, bndsolvar, indsolvar, nullptr);
-        sw_na_out = nullptr;
+        rc = sw_run(st, ncol, lm, sc, dist, isolvar, sin, iceflg, liqflg, dyofyr, 10, lm - lcldlm + 1, lm - lcldmh + 1,
+                    normflx, cc, sout, 0, bndsolvar, indsolvar, nullptr, want_na ? nout : nullptr);
         if (rc) return rc;
         SwdPost<R> Q{};
         Q.ncol = ncol; Q.lm = lm; Q.ngpt = NG_SW; Q.aerosols = include_aerosols; Q.undef = (R)consts[GEOSRAD_SWD_C_UNDEF];
@@ -1228,6 +1225,15 @@ template <typename R> struct Ctx : geosrad_ctx {
     int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
                int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband,
                const void *bndscl, const void *indsolvar, void *const *dbg) override
+    {
+        return sw_run(st, ncol, nlay, scon, adjes, isolvar, in, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx, clearCounts, out,
+                      do_drfband, bndscl, indsolvar, dbg, nullptr);
+    }
+
+    // sw_na_out (SwOutIx order, all of SO_UFLX .. SO_COT0 + 7 non-null) requests an additional pass without the aerosol terms
+    int sw_run(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
+               int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband,
+               const void *bndscl, const void *indsolvar, void *const *dbg, void *const *sw_na_out)
     {
         HIPCHK(hipSetDevice(device));
         if (!have_sw) return fail(GEOSRAD_EINVAL, "RRTMG_SW tables not set: call geosrad_set_tables_sw first (rrtmg_sw_ini)");
