@@ -375,6 +375,13 @@ class Context:
             ci(int(lcldmh)), ci(normflx), None if bs is None else _p(bs), None if ins is None else _p(ins),
             self._ptr_array(G.SWD_OUT, ptr)))
 
+    def lw_chou_post_dev(self, stream, ncol, lm, ptr):
+        """after irrad in the Chou-Suarez branch of LW_Driver (GEOS_IrradGridComp.F90:2101-2108, :3601-3616): gridcomp.LWC_IN / LWC_OUT"""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_lw_chou_post_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), self._ptr_array(G.LWC_IN, ptr),
+                                                  self._ptr_array(G.LWC_OUT, ptr)))
+
     def lw_update_flx_dev(self, stream, ncol, lm, rrtmg, lev_mid_high, lev_low_mid, undef, ptr):
         """Update_Flx (GEOS_IrradGridComp.F90:3796-3999): `ptr` holds gridcomp.LWU_IN internals and the requested gridcomp.LWU_OUT."""
         from . import gridcomp as G

@@ -268,6 +268,7 @@ struct geosrad_ctx {
     virtual int sw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg,
                               int liqflg, double sc, double dist, int isolvar, int dyofyr, int include_aerosols, int lcldlm,
                               int lcldmh, int normflx, const void *bndsolvar, const void *indsolvar, void *const *out) = 0;
+    virtual int lw_chou_post_dev(hipStream_t st, int ncol, int lm, const void *const *in, void *const *out) = 0;
     virtual int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
                                   const void *const *in, void *const *out) = 0;
     virtual int sw_update_export_dev(hipStream_t st, int ncol, int lm, int nbands, const void *const *in, void *const *out) = 0;
@@ -881,6 +882,27 @@ template <typename R> struct Ctx : geosrad_ctx {
             N.fscu = (R *)out[GEOSRAD_SWD_FSCUNA];
             hipLaunchKernelGGL((k_swd_post<R>), dim3(gx, lm + 1), blk, 0, st, N);
         }
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int lw_chou_post_dev(hipStream_t st, int ncol, int lm, const void *const *in, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/lm");
+        LwcPost<R> P{};
+        P.ncol = ncol; P.lm = lm;
+        static_assert(offsetof(LwcPost<R>, ts) - offsetof(LwcPost<R>, flxu) == (GEOSRAD_LWC_NIN - 1) * sizeof(void *), "LwcPost input layout");
+        static_assert(offsetof(LwcPost<R>, ts_int) - offsetof(LwcPost<R>, sfcem_int) == (GEOSRAD_LWC_NOUT - 1) * sizeof(void *), "LwcPost output layout");
+        const R **ip = &P.flxu;
+        for (int k = 0; k < GEOSRAD_LWC_NIN; k++) ip[k] = (const R *)in[k];
+        R **op = &P.sfcem_int;
+        for (int k = 0; k < GEOSRAD_LWC_NOUT; k++) op[k] = (R *)out[k];
+        auto need = [&](const R *o, const R *a, const R *b = (const R *)1) { return !o || (a && b); };
+        if (!(need(P.flx_int, P.flxd, P.flxu) && need(P.flxa_int, P.flxad, P.flxau) && need(P.flc_int, P.flcd, P.flcu) &&
+              need(P.fla_int, P.flad, P.flau) && need(P.dfdtsna, P.dfdts) && need(P.ts_int, P.ts)))
+            return fail(GEOSRAD_EINVAL, "an output was requested without the field it is computed from");
+        hipLaunchKernelGGL((k_lwd_chou_post<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, P);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -2008,6 +2030,12 @@ int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *c, void *stream, int ncol, int lm, 
     if (!c || !in || !consts || !out) return GEOSRAD_EINVAL;
     return c->sw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflgsw, liqflgsw, sc, dist, isolvar, dyofyr,
                             include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, out);
+}
+
+int geosrad_lw_chou_post_dev(geosrad_ctx *c, void *stream, int ncol, int lm, const void *const *in, void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->lw_chou_post_dev((hipStream_t)stream, ncol, lm, in, out);
 }
 
 int geosrad_lw_update_flx_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,

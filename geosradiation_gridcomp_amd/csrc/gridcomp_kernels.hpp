@@ -185,6 +185,34 @@ template <typename R> __global__ void __launch_bounds__(256) k_lwd_post(LwdPost<
     }
 }
 
+// Chou-Suarez branch of LW_Driver: `irrad` takes the GEOS fields as they are (no flip, no unit conversion) and fills the INTERNAL
+// fluxes itself; what the driver adds (IRR:2101-2108, :3601-3616): the derivatives irrad does not provide, the net fluxes of the four
+// flavours, the sign of SFCEM, TS_INT.
+template <typename R> struct LwcPost {
+    int ncol, lm;
+    const R *flxu, *flcu, *flau, *flxau, *flxd, *flcd, *flad, *flxad, *dfdts, *ts;
+    R *sfcem_int;                                                         // in: as irrad leaves it (negative); out: positive
+    R *flx_int, *flxa_int, *flc_int, *fla_int, *dfdtsc, *dfdtsna, *dfdtscna, *ts_int;
+};
+template <typename R> __global__ void __launch_bounds__(256) k_lwd_chou_post(LwcPost<R> P)
+{
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const size_t o = (size_t)blockIdx.y * P.ncol + ij;
+    if (P.flx_int) P.flx_int[o] = P.flxd[o] + P.flxu[o];
+    if (P.flxa_int) P.flxa_int[o] = P.flxad[o] + P.flxau[o];
+    if (P.flc_int) P.flc_int[o] = P.flcd[o] + P.flcu[o];
+    if (P.fla_int) P.fla_int[o] = P.flad[o] + P.flau[o];
+    if (P.dfdtsc) P.dfdtsc[o] = 0;                       // Chou-Suarez has no clear-sky derivative (IRR:2104-2108)
+    if (P.dfdtsna) P.dfdtsna[o] = P.dfdts[o];
+    if (P.dfdtscna) P.dfdtscna[o] = 0;
+    if (blockIdx.y == 0) {
+        if (P.sfcem_int) P.sfcem_int[ij] = -P.sfcem_int[ij];
+        if (P.ts_int) P.ts_int[ij] = P.ts[ij];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Update_Flx (IRR:3796-3999)
 // ---------------------------------------------------------------------------------------------------------------------------

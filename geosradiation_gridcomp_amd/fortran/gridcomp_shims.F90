@@ -8,7 +8,7 @@ module geosrad_gridcomp
    use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
    implicit none
    private
-   public :: lw_driver_rrtmg, sw_driver_rrtmg, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lw_driver_rrtmg, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
    ! ---- GEOSRAD_LWD_* ----
@@ -20,6 +20,11 @@ module geosrad_gridcomp
    integer, parameter, public :: LWD_FLXU_INT = 1, LWD_FLXD_INT = 2, LWD_FLCU_INT = 3, LWD_FLCD_INT = 4, LWD_DFDTS = 5, LWD_DFDTSC = 6, &
       LWD_DFDTSNA = 7, LWD_DFDTSCNA = 8, LWD_FLX_INT = 9, LWD_FLC_INT = 10, LWD_SFCEM_INT = 11, LWD_TS_INT = 12, LWD_CLDTTLW = 13, &
       LWD_CLDHILW = 14, LWD_CLDMDLW = 15, LWD_CLDLOLW = 16, LWD_OLRB = 17, LWD_DOLRB = 18, LWD_NOUT = 18
+   ! ---- GEOSRAD_LWC_* ----
+   integer, parameter, public :: LWC_FLXU_INT = 1, LWC_FLCU_INT = 2, LWC_FLAU_INT = 3, LWC_FLXAU_INT = 4, LWC_FLXD_INT = 5, LWC_FLCD_INT = 6, &
+      LWC_FLAD_INT = 7, LWC_FLXAD_INT = 8, LWC_DFDTS = 9, LWC_TS = 10, LWC_NIN = 10
+   integer, parameter, public :: LWC_SFCEM_INT = 1, LWC_FLX_INT = 2, LWC_FLXA_INT = 3, LWC_FLC_INT = 4, LWC_FLA_INT = 5, LWC_DFDTSC = 6, &
+      LWC_DFDTSNA = 7, LWC_DFDTSCNA = 8, LWC_TS_INT = 9, LWC_NOUT = 9
    ! ---- GEOSRAD_SWD_* ----
    integer, parameter, public :: SWD_PLE = 1, SWD_PL = 2, SWD_T = 3, SWD_Q = 4, SWD_O3 = 5, SWD_CH4 = 6, SWD_CL = 7, SWD_TS = 8, &
       SWD_QQ_ICE = 9, SWD_QQ_LIQ = 10, SWD_RR_ICE = 11, SWD_RR_LIQ = 12, SWD_TAUA = 13, SWD_SSAA = 14, SWD_ASYA = 15, SWD_ZT = 16, &
@@ -71,6 +76,12 @@ module geosrad_gridcomp
          real(c_double), value :: sc, dist
          type(c_ptr), intent(in) :: fin(*), fout(*)
          real(c_double), intent(in) :: consts(*)
+      end function
+      integer(c_int) function geosrad_lw_chou_post_dev(ctx, stream, ncol, lm, fin, fout) bind(C, name='geosrad_lw_chou_post_dev')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm
+         type(c_ptr), intent(in) :: fin(*), fout(*)
       end function
       integer(c_int) function geosrad_lw_update_flx_dev(ctx, stream, ncol, lm, rrtmg, lev_mid_high, lev_low_mid, undef, fin, fout) &
             bind(C, name='geosrad_lw_update_flx_dev')
@@ -177,6 +188,14 @@ contains
       rc = geosrad_sw_driver_rrtmg_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, consts, &
             int(iceflgsw,c_int), int(liqflgsw,c_int), real(sc,c_double), real(dist,c_double), int(isolvar,c_int), int(dyofyr,c_int), &
             merge(1_c_int, 0_c_int, include_aerosols), int(lcldlm,c_int), int(lcldmh,c_int), 1_c_int, c_null_ptr, c_null_ptr, fout)
+   end subroutine
+
+   ! after `call IRRAD` in the Chou-Suarez branch of LW_Driver (GEOS_IrradGridComp.F90:2101-2108, :3601-3616)
+   subroutine lw_chou_post(ncol, lm, fin, fout)
+      integer, intent(in) :: ncol, lm
+      type(c_ptr), intent(in) :: fin(LWC_NIN), fout(LWC_NOUT)
+      if (geosrad_lw_chou_post_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), fin, fout) /= 0) &
+         call geosrad_fail('LW_Driver (Chou-Suarez)')
    end subroutine
 
    ! Update_Flx (GEOS_IrradGridComp.F90:3796-3999)

@@ -13,6 +13,9 @@ LWD_OUT = ["FLXU_INT", "FLXD_INT", "FLCU_INT", "FLCD_INT", "DFDTS", "DFDTSC", "D
            "TS_INT", "CLDTTLW", "CLDHILW", "CLDMDLW", "CLDLOLW", "OLRB", "DOLRB"]
 LWD_OUT_3D = LWD_OUT[:10]
 
+LWC_IN = ["FLXU_INT", "FLCU_INT", "FLAU_INT", "FLXAU_INT", "FLXD_INT", "FLCD_INT", "FLAD_INT", "FLXAD_INT", "DFDTS", "TS"]
+LWC_OUT = ["SFCEM_INT", "FLX_INT", "FLXA_INT", "FLC_INT", "FLA_INT", "DFDTSC", "DFDTSNA", "DFDTSCNA", "TS_INT"]
+
 SWD_IN = ["PLE", "PL", "T", "Q", "O3", "CH4", "CL", "TS", "QQ_ICE", "QQ_LIQ", "RR_ICE", "RR_LIQ", "TAUA", "SSAA", "ASYA", "ZT", "ALAT",
           "ALBVR", "ALBVF", "ALBNR", "ALBNF"]
 SWD_CONST = ["CO2", "O2", "AIRMW", "H2OMW", "O3MW", "RGAS", "GRAV", "UNDEF"]

@@ -278,6 +278,15 @@ int geosrad_lw_driver_rrtmg_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm
                                 const double *consts, int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh,
                                 const int32_t *band_output, void *const *out);
 
+/* geosrad_lw_chou_post_dev: what the Chou-Suarez branch of LW_Driver adds after `call IRRAD` (which takes the GEOS fields as they are):
+ * DFDTSC = 0, DFDTSNA = DFDTS, DFDTSCNA = 0 (GEOS_IrradGridComp.F90:2101-2108), the four net fluxes FL*_INT = FL*D_INT + FL*U_INT,
+ * SFCEM_INT = -SFCEM_INT (in place), TS_INT = TS (:3601-3616).  Outputs may be NULL. */
+enum { GEOSRAD_LWC_FLXU_INT, GEOSRAD_LWC_FLCU_INT, GEOSRAD_LWC_FLAU_INT, GEOSRAD_LWC_FLXAU_INT, GEOSRAD_LWC_FLXD_INT, GEOSRAD_LWC_FLCD_INT,
+       GEOSRAD_LWC_FLAD_INT, GEOSRAD_LWC_FLXAD_INT, GEOSRAD_LWC_DFDTS, GEOSRAD_LWC_TS, GEOSRAD_LWC_NIN };
+enum { GEOSRAD_LWC_SFCEM_INT /*in-out*/, GEOSRAD_LWC_FLX_INT, GEOSRAD_LWC_FLXA_INT, GEOSRAD_LWC_FLC_INT, GEOSRAD_LWC_FLA_INT, GEOSRAD_LWC_DFDTSC,
+       GEOSRAD_LWC_DFDTSNA, GEOSRAD_LWC_DFDTSCNA, GEOSRAD_LWC_TS_INT, GEOSRAD_LWC_NOUT };
+int geosrad_lw_chou_post_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, const void *const *in, void *const *out);
+
 /* geosrad_sw_driver_rrtmg_dev: the RRTMG branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:6113-6219
  * prep / flip incl. the in-place aerosol normalisation, :6330-6388 the rrtmg_sw call, :6395-6450 un-flip, cloud fractions,
  * in-cloud optical thickness, net fluxes).  ple is (ncol,LM+1).  solvar = {bndscl[14], indsolvar[2]} host pointers or NULL. */

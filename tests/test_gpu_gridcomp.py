@@ -280,3 +280,52 @@ def test_lw_driver_137_layers_single_column_and_chunked_batches(gpu_ctx):
 def conftest_sub(inp, n):
     from tests.conftest import sub_columns
     return sub_columns(inp, n)
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_chou_branch_of_lw_driver_then_heartbeat(gpu_ctx, rk):
+    """irrad on device fields, the driver's post step (derivative copies, net fluxes, SFCEM sign, TS_INT), then Update_Flx in its
+    Chou-Suarez flavour (all four flux flavours) -- against numpy on the irrad outputs and the plain-C restatement of Update_Flx"""
+    import torch
+    from oracle import clib
+    ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
+    m, lm = 96, 72
+    inp = synth.make_columns(m, lm, start=1500, cloudy_frac=0.6, aerosol=True)
+    ch = synth.chou_lw_inputs(inp, aerosol=True)
+    names_in = ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg", "tv", "ev", "rv",
+                "taua", "ssaa", "asya")
+    t = {k: torch.from_numpy(np.ascontiguousarray(ch[k], dtype=dt)).cuda() for k in names_in}
+    for k in ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts"):
+        t[k] = torch.zeros((lm + 1, m), dtype=t["ta"].dtype, device="cuda")
+    t["sfcem"] = torch.zeros(m, dtype=t["ta"].dtype, device="cuda")
+    t["taudiag"] = torch.zeros((10, lm, m), dtype=t["ta"].dtype, device="cuda")
+    st = _stream()
+    ctx.irrad_dev(st, m, lm, {k: v.data_ptr() for k, v in t.items()}, ch["co2"], True, ch["ict"], ch["icb"], ch["ns"], ch["na"], ch["nb"])
+    g = {"FLXU_INT": t["flxu"], "FLCU_INT": t["flcu"], "FLAU_INT": t["flau"], "FLXAU_INT": t["flxau"], "FLXD_INT": t["flxd"], "FLCD_INT": t["flcd"],
+         "FLAD_INT": t["flad"], "FLXAD_INT": t["flxad"], "DFDTS": t["dfdts"], "SFCEM_INT": t["sfcem"]}
+    g["TS"] = torch.from_numpy(np.ascontiguousarray(inp["tsfc"], dtype=dt)).cuda()
+    sf0 = t["sfcem"].clone()
+    for k in ("FLX_INT", "FLXA_INT", "FLC_INT", "FLA_INT", "DFDTSC", "DFDTSNA", "DFDTSCNA"):
+        g[k] = torch.full((lm + 1, m), -7.0, dtype=t["ta"].dtype, device="cuda")
+    g["TS_INT"] = torch.zeros(m, dtype=t["ta"].dtype, device="cuda")
+    ctx.lw_chou_post_dev(st, m, lm, {k: v.data_ptr() for k, v in g.items()})
+    ctx.check(st)
+    assert torch.equal(g["FLX_INT"], t["flxd"] + t["flxu"]) and torch.equal(g["FLA_INT"], t["flad"] + t["flau"])
+    assert torch.equal(g["FLXA_INT"], t["flxad"] + t["flxau"]) and torch.equal(g["FLC_INT"], t["flcd"] + t["flcu"])
+    assert torch.equal(g["DFDTSNA"], t["dfdts"]) and not g["DFDTSC"].any() and not g["DFDTSCNA"].any()
+    assert torch.equal(g["SFCEM_INT"], -sf0) and (g["SFCEM_INT"] > 0).all() and torch.equal(g["TS_INT"], g["TS"])
+    # heartbeat, Chou flavour
+    u = {k: g[k] for k in G.LWU_IN if k in g}
+    u["FCLD"] = t["fcld"]
+    u["TSINST"] = g["TS"] + 0.5
+    want = ["FLX", "FLXA", "FLC", "FLA", "FLXU", "FLAU", "FLXAD", "OLR", "OLRA", "OLA", "SFCEM", "LWSA", "FLNSNA", "FLNSA", "CLDTT"]
+    tout, pout = _zeros({k: ((lm + 1, m) if k in G.LWU_OUT_3D else (m,)) for k in want}, dt)
+    ptr = {k: v.data_ptr() for k, v in u.items()}; ptr.update(pout)
+    lmh, llm = int(ch["ict"]), int(ch["icb"])
+    ctx.lw_update_flx_dev(st, m, lm, False, lmh, llm, 1e15, ptr)
+    ctx.check(st)
+    o = clib.lw_update_flx({k: v.cpu().numpy() for k, v in u.items()}, lm, False, lmh, llm, 1e15, prec, want=want)
+    for k in want:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
+    # clear sky emits at least as much as all sky (to the 2 W m-2 the scheme itself allows, see tests/test_gpu_chou.py)
+    assert (o["OLR"] > 100).all() and (o["OLA"] >= o["OLRA"] - 2.0).all()
