@@ -366,9 +366,17 @@ def main():
     from geosradiation_gridcomp_amd import synth
     from geosradiation_gridcomp_amd.api import Context
 
+    # GEOSRAD_BENCH_REHEARSAL=1: rehearse the N > 1 control path on fewer GPUs than ranks (gloo instead of RCCL, which refuses two
+    # ranks on one device; ranks wrap around the visible devices).  Never set by the driver.
+    rehearsal = os.environ.get("GEOSRAD_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
