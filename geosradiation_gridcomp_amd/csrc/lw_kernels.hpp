@@ -977,10 +977,16 @@ template <typename R> GR_DEV R planck_at(const R *__restrict__ totplnk, int ib, 
 // the transmittance table lives in LDS for 4-byte reals: 2 blocks x 80 KB fill a CU's 160 KB, which is the 2 waves/SIMD the
 // band kernels' register count allows anyway; the 8-byte table (160 KB) stays in L2
 template <typename R> struct LwLutInLds { static constexpr bool value = sizeof(R) == 4; };
-template <typename R> constexpr size_t lw_bands_lds_bytes() { return LwLutInLds<R>::value ? (size_t)(NTBL + 1) * 2 * sizeof(R) : 0; }
+// behind it (fp32) the band's four small tables - self and foreign continuum, Planck fractions of the lower / upper atmosphere, at most
+// (10 + 4 + 9 + 5) rows of 16 reals = 1 792 B: their rows are then LDS reads instead of 5-6 of the ~20 row gathers of a g-group
+constexpr size_t LW_LDS_LUT = (((size_t)(NTBL + 1) * 2 * sizeof(float)) + 15) & ~(size_t)15;
+constexpr size_t LW_LDS_SMALL = (size_t)(10 + 4 + 9 + 5) * 16 * sizeof(float);
+template <typename R> constexpr size_t lw_bands_lds_bytes() { return LwLutInLds<R>::value ? LW_LDS_LUT + LW_LDS_SMALL : 0; }
+__host__ __device__ constexpr int lw_nfraca(int ib) { constexpr int n[17] = {0, 1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9}; return n[ib]; }
+__host__ __device__ constexpr int lw_nfracb(int ib) { constexpr int n[17] = {0, 1, 1, 5, 5, 5, 0, 1, 1, 1, 1, 1, 0, 1, 1, 0, 1}; return n[ib]; }
 
 template <typename R, typename BAND, bool CLD, bool DBG>
-GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear, const typename Vec2<R>::T *luts)
+GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclear, const typename Vec2<R>::T *luts)
 {
     constexpr int NG = BAND::NG, IB = BAND::IB, G0 = BAND::G0;
     constexpr int W = NG >= 4 ? 4 : 2;
@@ -988,6 +994,15 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &T, int col, int nclear
     using R2 = typename Vec2<R>::T;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
     // (1 - transmittance, tfac) of a discretised optical depth: from the block's LDS copy of the table when there is one
+    // the band's small tables from the block's LDS copy (k_lw_bands): same layout as in HBM, [rows][S]
+    LwDev<R> TL = Tg;
+    if constexpr (LwLutInLds<R>::value) {
+        constexpr int S = BAND::S;
+        const R *sm = reinterpret_cast<const R *>(reinterpret_cast<const unsigned char *>(luts) + LW_LDS_LUT);
+        TL.b[IB].selfref = sm; TL.b[IB].forref = sm + 10 * S; TL.b[IB].fracrefa = sm + 14 * S;
+        if (lw_nfracb(IB) > 0) TL.b[IB].fracrefb = sm + (14 + lw_nfraca(IB)) * S;
+    }
+    const LwDev<R> &T = TL;
     auto lut_at = [&](int i) -> R2 {
         if constexpr (LwLutInLds<R>::value) return luts[i];
         else return ldg(T.lut, (uint32_t)i * (uint32_t)sizeof(R2));
@@ -1360,6 +1375,17 @@ __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
     if constexpr (LwLutInLds<R>::value) {
         R2 *const l = reinterpret_cast<R2 *>(lw_lds);
         for (int i = threadIdx.x; i <= NTBL; i += (int)blockDim.x) l[i] = ldg(T.lut, (uint32_t)i * (uint32_t)sizeof(R2));
+        {   // the band's small tables, [rows][S] each, in the order selfref (10), forref (4), fracrefa, fracrefb
+            const int ib = LW_BAND_ORDER[blockIdx.y], S = pad4(lw_band_ng(ib));
+            R *const sm = reinterpret_cast<R *>(lw_lds + LW_LDS_LUT);
+            const BandTab<R> &B = T.b[ib];
+            const int na = lw_nfraca(ib), nb = lw_nfracb(ib);
+            for (int i = threadIdx.x; i < (14 + na + nb) * S; i += (int)blockDim.x) {
+                const int r = i / S, c = i - r * S;
+                const R *src = r < 10 ? B.selfref + r * S : (r < 14 ? B.forref + (r - 10) * S : (r < 14 + na ? B.fracrefa + (r - 14) * S : B.fracrefb + (r - 14 - na) * S));
+                sm[i] = src[c];
+            }
+        }
         __syncthreads();
         luts = l;
     }
