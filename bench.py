@@ -231,8 +231,17 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
         side = None if a.no_overlap else torch.cuda.Stream()        # the two drivers are independent: two HIP streams
         sw_stream = stream if side is None else side.cuda_stream
 
+        rats = G.RAT_GAS[:a.rats]
+        if rats:
+            for k in G.LWD_RAT_OUT:
+                tl[k] = zeros(len(rats), ncol) if k == "SFCEM_RAT" else zeros(len(rats), lm + 1, ncol)
+            pl = {k: v.data_ptr() for k, v in tl.items()}
+
         def step():
-            ctx.lw_driver_rrtmg_dev(stream, ncol, lm, 16 if aerosol else 0, pl, cl, 3, 1, doy, fl["LCLDLM"], fl["LCLDMH"])
+            if rats:          # RATS_DIAGNOSTICS: the reference re-runs rrtmg_lw per gas (IRR:3405-3468); here the gases ride on the call
+                ctx.lw_driver_rrtmg_rats_dev(stream, ncol, lm, 16 if aerosol else 0, pl, cl, 3, 1, doy, fl["LCLDLM"], fl["LCLDMH"], rats)
+            else:
+                ctx.lw_driver_rrtmg_dev(stream, ncol, lm, 16 if aerosol else 0, pl, cl, 3, 1, doy, fl["LCLDLM"], fl["LCLDMH"])
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 for k in aer0:                  # the SW driver normalises the aerosol triplet in place: restore the inputs
                     ts[k].copy_(aer0[k])
@@ -314,7 +323,8 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
                 "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
                 "note": "same dominant kernel as the default bench; the driver adds prep / flip / post streaming kernels around the solvers"}
         wl = (f"RRTMG branches of LW_Driver + SORADCORE on GEOS-native fields (model ordering, SI units): {ncol} columns/GPU, {lm} layers, "
-              f"McICA clouds on {100 * a.cloudy:.0f} % of the columns, aerosols {'on' if aerosol else 'off'}")
+              f"McICA clouds on {100 * a.cloudy:.0f} % of the columns, aerosols {'on' if aerosol else 'off'}"
+              + (f", RATS diagnostics for {', '.join(G.RAT_GAS[:a.rats])}" if a.rats else ""))
         kms = {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0}
         kms["whole step (device)"] = dev_ms
     print(json.dumps({
@@ -339,6 +349,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="lwsw: RRTMG_LW and RRTMG_SW on ONE stream (default: two HIP streams - the two solvers are independent)")
     ap.add_argument("--na-pass", action="store_true", help="gridcomp: also request the no-aerosol flavour of the SW fluxes (FSWNA ...)")
+    ap.add_argument("--rats", type=int, default=0, help="gridcomp: RATS diagnostics for the first N gases of gridcomp.RAT_GAS (0-8)")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     a = ap.parse_args()

@@ -342,6 +342,22 @@ class Context:
             v("dflx"), v("uflxc"), v("dflxc"), v("duflx_dTs"), v("duflxc_dTs"), _p(bo), v("olrb"), v("dolrb_dTs"))
         self._chk(rc)
 
+    def rrtmg_lw_rats_dev(self, stream, ncol, nlay, dudTs, ptr, iceflg, liqflg, dyofyr, cloudLM, cloudMH, rat_gas, band_output=None):
+        """rrtmg_lw_dev + the RATS loop of LW_Driver (GEOS_IrradGridComp.F90:3405-3468) from the same call: `rat_gas` = names from
+        gridcomp.RAT_GAS; ptr["uflx_rat"], ["dflx_rat"], ["duflx_dTs_rat"] = device arrays [len(rat_gas)][nlay+1][ncol]."""
+        from . import gridcomp as G
+        bo = np.zeros(NBNDLW, dtype=np.int32) if band_output is None else np.ascontiguousarray(band_output, dtype=np.int32)
+        rg = np.ascontiguousarray([G.RAT_GAS.index(g) if isinstance(g, str) else int(g) for g in rat_gas], dtype=np.int32)
+        v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
+        ci = ctypes.c_int
+        rc = self.L.geosrad_rrtmg_lw_rats_dev(
+            self.h, ctypes.c_void_p(stream), ci(ncol), ci(nlay), ci(4), ci(1 if dudTs else 0), v("play"), v("plev"), v("tlay"),
+            v("tlev"), v("tsfc"), v("emis"), *[v(k) for k in _IN2D[:10]], *[v(k) for k in _IN2D[10:]], ci(iceflg), ci(liqflg),
+            v("tauaer"), v("zm"), v("alat"), ci(int(dyofyr)), ci(int(cloudLM)), ci(int(cloudMH)), v("clearCounts"), v("uflx"),
+            v("dflx"), v("uflxc"), v("dflxc"), v("duflx_dTs"), v("duflxc_dTs"), _p(bo), v("olrb"), v("dolrb_dTs"),
+            ci(len(rg)), _p(rg), v("uflx_rat"), v("dflx_rat"), v("duflx_dTs_rat"))
+        self._chk(rc)
+
     # ---- GridComp data path either side of the solvers (device pointers, GEOS layout) ---------------------------------------
     @staticmethod
     def _ptr_array(names, ptr):
@@ -360,6 +376,20 @@ class Context:
         self._chk(self.L.geosrad_lw_driver_rrtmg_dev(
             self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nb_aer), self._ptr_array(G.LWD_IN, ptr), cs, ci(iceflg), ci(liqflg),
             ci(int(doy)), ci(int(lcldlm)), ci(int(lcldmh)), _p(bo), self._ptr_array(G.LWD_OUT, ptr)))
+
+    def lw_driver_rrtmg_rats_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, doy, lcldlm, lcldmh, rat_gas,
+                                 band_output=None):
+        """lw_driver_rrtmg_dev with the RATS loop (IRR:3389-3469, :3522-3530, :3614): `rat_gas` = names from gridcomp.RAT_GAS,
+        `ptr` additionally holds gridcomp.LWD_RAT_OUT ((nrats, LM+1, ncol), SFCEM_RAT (nrats, ncol); missing = not associated)."""
+        from . import gridcomp as G
+        bo = np.zeros(NBNDLW, dtype=np.int32) if band_output is None else np.ascontiguousarray(band_output, dtype=np.int32)
+        rg = np.ascontiguousarray([G.RAT_GAS.index(g) if isinstance(g, str) else int(g) for g in rat_gas], dtype=np.int32)
+        cs = (ctypes.c_double * len(G.LWD_CONST))(*consts)
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_lw_driver_rrtmg_rats_dev(
+            self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nb_aer), self._ptr_array(G.LWD_IN, ptr), cs, ci(iceflg), ci(liqflg),
+            ci(int(doy)), ci(int(lcldlm)), ci(int(lcldmh)), _p(bo), self._ptr_array(G.LWD_OUT, ptr), ci(len(rg)), _p(rg),
+            self._ptr_array(G.LWD_RAT_OUT, ptr)))
 
     def sw_driver_rrtmg_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, sc, dist, isolvar, dyofyr, include_aerosols,
                             lcldlm, lcldmh, normflx=1, bndsolvar=None, indsolvar=None):

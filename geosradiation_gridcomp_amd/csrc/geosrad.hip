@@ -236,9 +236,11 @@ struct geosrad_ctx {
     virtual int set_inhomogeneity(int ih, const void *blob, size_t n) = 0;
     virtual int set_corr(const double *adl, const double *rdl) = 0;
     virtual size_t workspace_bytes() const = 0;
+    // RATS diagnostics of LW_Driver (GEOS_IrradGridComp.F90:3405-3468): total-sky profiles with one gas removed, per gas
+    struct LwRats { int n; int gas[GEOSRAD_RAT_NGAS]; void *uflx, *dflx, *duflx_dTs; };      // outputs [n][nlay+1][ncol]
     virtual int lw_dev(hipStream_t st, int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr,
                        int cloudLM, int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output,
-                       void *dbg_taug, void *dbg_pfracs) = 0;
+                       void *dbg_taug, void *dbg_pfracs, const LwRats *rats) = 0;
     virtual int lw_host(int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr, int cloudLM,
                         int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output, void *taug,
                         void *pfracs) = 0;
@@ -264,7 +266,8 @@ struct geosrad_ctx {
                        int liqflg, int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
                        int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
     virtual int lw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg,
-                              int liqflg, int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out) = 0;
+                              int liqflg, int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out, int nrats,
+                              const int32_t *rat_gas, void *const *rat_out) = 0;
     virtual int sw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg,
                               int liqflg, double sc, double dist, int isolvar, int dyofyr, int include_aerosols, int lcldlm,
                               int lcldmh, int normflx, const void *bndsolvar, const void *indsolvar, void *const *out) = 0;
@@ -342,6 +345,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     std::map<std::tuple<int, int, int, int>, PlanEntry> plans;
     // workspace
     char *d_ws = nullptr; size_t ws_bytes = 0; int ws_ncol = 0, ws_nlay = 0;
+    char *d_zero = nullptr; size_t zero_bytes = 0;      // all-zero (nlay, ncol) plane of the RATS passes
     uint32_t *d_err = nullptr;
     // staging for host-pointer entry points
     char *d_io = nullptr; size_t io_bytes = 0;
@@ -353,6 +357,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_xcw) (void)hipFree(d_xcw);
         if (d_T) (void)hipFree(d_T);
         if (d_ws) (void)hipFree(d_ws);
+        if (d_zero) (void)hipFree(d_zero);
         for (auto &pe : plans) if (pe.second.d_seg) (void)hipFree(pe.second.d_seg);
         if (d_tab_sw) (void)hipFree(d_tab_sw);
         if (d_tab_ch) (void)hipFree(d_tab_ch);
@@ -619,7 +624,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     // ---- RRTMG_LW, device pointers ---------------------------------------------------------------------------
     int lw_dev(hipStream_t st, int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr,
                int cloudLM, int cloudMH, int32_t *clearCounts, void *const *out, const int32_t *band_output, void *dbg_taug,
-               void *dbg_pfracs) override
+               void *dbg_pfracs, const LwRats *rats) override
     {
         HIPCHK(hipSetDevice(device));
         if (!have_lw) return fail(GEOSRAD_EINVAL, "RRTMG_LW tables not set: call geosrad_set_tables_lw first (rrtmg_lw_ini)");
@@ -643,6 +648,20 @@ template <typename R> struct Ctx : geosrad_ctx {
         if ((long)nc_max > cap) nc_max = (int)cap;
         int rc = ensure_ws(nc_max, nlay);
         if (rc) return rc;
+        if (rats && rats->n > 0) {
+            if (rats->n > GEOSRAD_RAT_NGAS || !rats->uflx || !rats->dflx || (dudTs && !rats->duflx_dTs))
+                return fail(GEOSRAD_EINVAL, "RATS: at most 8 gases; uflx_rat / dflx_rat (and duflx_dTs_rat with dudTs) must not be null");
+            for (int r = 0; r < rats->n; r++)
+                if (rats->gas[r] < 0 || rats->gas[r] >= GEOSRAD_RAT_NGAS) return fail(GEOSRAD_EINVAL, "RATS: unknown gas code");
+            // an all-zero (nlay, ncol) plane stands for the removed gas's mixing ratio (and for pwvcm of a dry column)
+            const size_t need = (size_t)nlay * ncol * sizeof(R);
+            if (need > zero_bytes) {
+                if (d_zero) { HIPCHK(hipFree(d_zero)); d_zero = nullptr; zero_bytes = 0; }
+                if (hipMalloc((void **)&d_zero, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the RATS zero plane failed");
+                HIPCHK(hipMemset(d_zero, 0, need));
+                zero_bytes = need;
+            }
+        }
 
         for (int c0 = 0; c0 < ncol; c0 += nc_max) {
             const int nc = (ncol - c0) < nc_max ? (ncol - c0) : nc_max;
@@ -702,6 +721,39 @@ template <typename R> struct Ctx : geosrad_ctx {
             O.duflx_dTs = Q(O_DUFLX); O.duflxc_dTs = Q(O_DUFLXC);
             O.olrb = (R *)out[O_OLRB]; O.dolrb_dTs = (R *)out[O_DOLRB]; O.col0 = c0;
             span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, A, O); span_end(st);
+
+            // RATS diagnostics (GEOS_IrradGridComp.F90:3405-3468): the reference calls the whole of rrtmg_lw once more per listed
+            // gas with that gas's mixing ratio set to zero and keeps the total-sky uflx, dflx, duflx_dTs of each call.  Nothing
+            // the clouds decide depends on the gases: the input checks (zero passes them), the clear | cloudy partition, the
+            // overlap correlations, the sub-columns with their cloud optical depths (`taucmc`, `laycloudy`) and clearCounts of
+            // the batch are still in the workspace, so a gas costs setcoef + the band sweeps + the reduction only.  Without
+            // water vapour the precipitable water (rrtmg_lw_setcoef.F90:206-272) is 0 / amttl = exactly zero.
+            for (int r = 0; rats && r < rats->n; r++) {
+                LwArgs<R> B = A;
+                const R *z = (const R *)d_zero;
+                switch (rats->gas[r]) {
+                case GEOSRAD_RAT_H2O: B.h2o = z; B.pwvcm = (R *)d_zero; break;      // pwvcm is only read from here on
+                case GEOSRAD_RAT_O3: B.o3 = z; break;
+                case GEOSRAD_RAT_CO2: B.co2 = z; break;
+                case GEOSRAD_RAT_CH4: B.ch4 = z; break;
+                case GEOSRAD_RAT_N2O: B.n2o = z; break;
+                case GEOSRAD_RAT_CFC11: B.cfc11 = z; break;
+                case GEOSRAD_RAT_CFC12: B.cfc12 = z; break;
+                default: B.cfc22 = z; break;
+                }
+                B.dbg_taug = nullptr; B.dbg_pfracs = nullptr;
+                span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, B, d_T); span_end(st);
+                span_begin(4, st);
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
+                span_end(st);
+                LwOut<R> OR{};
+                const size_t ro = (size_t)r * (nlay + 1) * ncol + c0;
+                OR.uflx = (R *)rats->uflx + ro; OR.dflx = (R *)rats->dflx + ro;
+                OR.duflx_dTs = rats->duflx_dTs ? (R *)rats->duflx_dTs + ro : nullptr;
+                OR.col0 = c0;
+                span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, B, OR); span_end(st);
+            }
         }
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
@@ -718,10 +770,12 @@ template <typename R> struct Ctx : geosrad_ctx {
     }
 
     int lw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg, int liqflg,
-                      int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out) override
+                      int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out, int nrats, const int32_t *rat_gas,
+                      void *const *rat_out) override
     {
         HIPCHK(hipSetDevice(device));
         if (ncol <= 0 || lm < 4 || nb < 0 || nb > 16) return fail(GEOSRAD_EINVAL, "bad ncol/lm/nb_aer");
+        if (nrats < 0 || nrats > GEOSRAD_RAT_NGAS || (nrats > 0 && (!rat_gas || !rat_out))) return fail(GEOSRAD_EINVAL, "bad RATS arguments");
         for (int k = 0; k < GEOSRAD_LWD_NIN; k++)
             if (!in[k] && k != GEOSRAD_LWD_CO2_3D && k != GEOSRAD_LWD_TAUA && k != GEOSRAD_LWD_SSAA) return fail(GEOSRAD_EINVAL, "null input array");
         if ((in[GEOSRAD_LWD_TAUA] == nullptr) != (in[GEOSRAD_LWD_SSAA] == nullptr)) return fail(GEOSRAD_EINVAL, "TAUA and SSAA go together");
@@ -734,6 +788,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         const size_t o_tsfc = take(n), o_alat = take(n), o_emis = take(n * 16), o_aer = take(cl * 16);
         for (auto &o : o_flux) o = take(cv);
         const size_t o_olrb = take(n * 16), o_dolrb = take(n * 16), o_cc = take(n * 4);
+        size_t o_rat[3] = {0, 0, 0};
+        for (auto &o : o_rat) o = take(cv * (size_t)nrats);
         int rc = drv_reserve(0, off);
         if (rc) return rc;
         char *const d_ws_drv = d_ws_drvs[0];
@@ -774,9 +830,20 @@ template <typename R> struct Ctx : geosrad_ctx {
                               out[GEOSRAD_LWD_DOLRB] ? out[GEOSRAD_LWD_DOLRB] : (void *)P(o_dolrb)};
         int32_t *cc = (int32_t *)(d_ws_drv + o_cc);
         static const int32_t no_bands[16] = {0};
+        LwRats RT{};
+        RT.n = nrats; RT.uflx = P(o_rat[0]); RT.dflx = P(o_rat[1]); RT.duflx_dTs = P(o_rat[2]);
+        for (int r = 0; r < nrats; r++) RT.gas[r] = rat_gas[r];
         rc = lw_dev(st, ncol, lm, 1, lin, iceflg, liqflg, doy, cloudLM, cloudMH, cc, lout, band_output ? band_output : no_bands, nullptr,
-                    nullptr);
+                    nullptr, nrats > 0 ? &RT : nullptr);
         if (rc) return rc;
+        if (nrats > 0) {
+            LwdRatPost<R> RP{};
+            RP.ncol = ncol; RP.lm = lm; RP.nrats = nrats; RP.uflx = P(o_rat[0]); RP.dflx = P(o_rat[1]); RP.duflx = P(o_rat[2]); RP.emis = A.emis;
+            RP.flxu_rat = (R *)rat_out[GEOSRAD_LWD_FLXU_RAT]; RP.flxd_rat = (R *)rat_out[GEOSRAD_LWD_FLXD_RAT];
+            RP.flx_rat = (R *)rat_out[GEOSRAD_LWD_FLX_RAT]; RP.dfdts_rat = (R *)rat_out[GEOSRAD_LWD_DFDTS_RAT];
+            RP.sfcem_rat = (R *)rat_out[GEOSRAD_LWD_SFCEM_RAT];
+            hipLaunchKernelGGL((k_lwd_rat_post<R>), dim3(gx, lm + 1, nrats), blk, 0, st, RP);
+        }
         LwdPost<R> Q{};
         Q.ncol = ncol; Q.lm = lm; Q.ngpt = NG_LW;
         Q.uflx = P(o_flux[0]); Q.dflx = P(o_flux[1]); Q.uflxc = P(o_flux[2]); Q.dflxc = P(o_flux[3]); Q.duflx = P(o_flux[4]);
@@ -1079,7 +1146,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         void *dout_eff[O_NOUT];
         for (int k = 0; k < O_NOUT; k++) dout_eff[k] = out[k] ? dout[k] : nullptr;
         rc = lw_dev(stream, ncol, nlay, dudTs, din, iceflg, liqflg, dyofyr, cloudLM, cloudMH, (int32_t *)(d_io + cco), dout_eff,
-                    band_output, taug ? d_io + dbgo[0] : nullptr, taug ? d_io + dbgo[1] : nullptr);
+                    band_output, taug ? d_io + dbgo[0] : nullptr, taug ? d_io + dbgo[1] : nullptr, nullptr);
         if (rc) return rc;
         rc = check(stream);
         if (rc) return rc;
@@ -2013,14 +2080,46 @@ int geosrad_rrtmg_lw_dev(geosrad_ctx *c, void *stream, int ncol, int nlay, int p
     LW_PACK_IN();
     void *out[O_NOUT] = {uflx, dflx, uflxc, dflxc, duflx_dTs, duflxc_dTs, olrb, dolrb_dTs};
     return c->lw_dev((hipStream_t)stream, ncol, nlay, dudTs, in, iceflglw, liqflglw, dyofyr, cloudLM, cloudMH, clearCounts, out,
-                     band_output, nullptr, nullptr);
+                     band_output, nullptr, nullptr, nullptr);
+}
+
+int geosrad_rrtmg_lw_rats_dev(geosrad_ctx *c, void *stream, int ncol, int nlay, int psize, int dudTs, const void *play, const void *plev,
+                              const void *tlay, const void *tlev, const void *tsfc, const void *emis, const void *h2ovmr, const void *o3vmr,
+                              const void *co2vmr, const void *ch4vmr, const void *n2ovmr, const void *o2vmr, const void *cfc11vmr,
+                              const void *cfc12vmr, const void *cfc22vmr, const void *ccl4vmr, const void *cldf, const void *ciwp,
+                              const void *clwp, const void *rei, const void *rel, int iceflglw, int liqflglw, const void *tauaer,
+                              const void *zm, const void *alat, int dyofyr, int cloudLM, int cloudMH, int32_t *clearCounts, void *uflx,
+                              void *dflx, void *uflxc, void *dflxc, void *duflx_dTs, void *duflxc_dTs, const int32_t *band_output,
+                              void *olrb, void *dolrb_dTs, int nrats, const int32_t *rat_gas, void *uflx_rat, void *dflx_rat,
+                              void *duflx_dTs_rat)
+{
+    if (!c || !clearCounts) return GEOSRAD_EINVAL;
+    if (nrats < 0 || nrats > GEOSRAD_RAT_NGAS || (nrats > 0 && !rat_gas)) return c->fail(GEOSRAD_EINVAL, "bad RATS arguments");
+    (void)psize;
+    LW_PACK_IN();
+    void *out[O_NOUT] = {uflx, dflx, uflxc, dflxc, duflx_dTs, duflxc_dTs, olrb, dolrb_dTs};
+    geosrad_ctx::LwRats RT{};
+    RT.n = nrats; RT.uflx = uflx_rat; RT.dflx = dflx_rat; RT.duflx_dTs = duflx_dTs_rat;
+    for (int r = 0; r < nrats; r++) RT.gas[r] = rat_gas[r];
+    return c->lw_dev((hipStream_t)stream, ncol, nlay, dudTs, in, iceflglw, liqflglw, dyofyr, cloudLM, cloudMH, clearCounts, out,
+                     band_output, nullptr, nullptr, nrats > 0 ? &RT : nullptr);
 }
 
 int geosrad_lw_driver_rrtmg_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nb_aer, const void *const *in, const double *consts,
                                 int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out)
 {
     if (!c || !in || !consts || !out) return GEOSRAD_EINVAL;
-    return c->lw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflglw, liqflglw, doy, lcldlm, lcldmh, band_output, out);
+    return c->lw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflglw, liqflglw, doy, lcldlm, lcldmh, band_output, out, 0,
+                            nullptr, nullptr);
+}
+
+int geosrad_lw_driver_rrtmg_rats_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nb_aer, const void *const *in, const double *consts,
+                                     int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh, const int32_t *band_output,
+                                     void *const *out, int nrats, const int32_t *rat_gas, void *const *rat_out)
+{
+    if (!c || !in || !consts || !out) return GEOSRAD_EINVAL;
+    return c->lw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflglw, liqflglw, doy, lcldlm, lcldmh, band_output, out,
+                            nrats, rat_gas, rat_out);
 }
 
 int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nb_aer, const void *const *in, const double *consts,

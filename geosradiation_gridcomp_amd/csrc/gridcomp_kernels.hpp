@@ -185,6 +185,29 @@ template <typename R> __global__ void __launch_bounds__(256) k_lwd_post(LwdPost<
     }
 }
 
+// RATS share of the un-flip (IRR:3522-3530) and of the net fluxes (IRR:3614): one thread per (column, GEOS level K, gas)
+template <typename R> struct LwdRatPost {
+    int ncol, lm, nrats;
+    const R *uflx, *dflx, *duflx;               // RRTMG (ncol, LM+1, nrats), 1 = surface
+    const R *emis;                              // EMIS(I,J) = EMISS(IJ,1): all bands share it (IRR:3249)
+    R *flxu_rat, *flxd_rat, *flx_rat, *dfdts_rat, *sfcem_rat;     // (ncol,0:LM,nrats), SFCEM_RAT (ncol,nrats); any may be null
+};
+template <typename R> __global__ void __launch_bounds__(256) k_lwd_rat_post(LwdRatPost<R> P)
+{
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const int n = P.ncol, lm = P.lm, K = blockIdx.y, r = blockIdx.z, LV = lm - K + 1;
+    const size_t plane = (size_t)(lm + 1) * n * r;
+    const size_t s = plane + (size_t)(LV - 1) * n + ij, o = plane + (size_t)K * n + ij;
+    const R fu = -P.uflx[s], fd = P.dflx[s];
+    if (P.flxu_rat) P.flxu_rat[o] = fu;
+    if (P.flxd_rat) P.flxd_rat[o] = fd;
+    if (P.dfdts_rat) P.dfdts_rat[o] = -P.duflx[s];
+    if (P.flx_rat) P.flx_rat[o] = fd + fu;
+    if (K == lm && P.sfcem_rat) P.sfcem_rat[(size_t)r * n + ij] = P.uflx[plane + ij] - P.dflx[plane + ij] * ((R)1.0 - P.emis[ij]);
+}
+
 // Chou-Suarez branch of LW_Driver: `irrad` takes the GEOS fields as they are (no flip, no unit conversion) and fills the INTERNAL
 // fluxes itself; what the driver adds (IRR:2101-2108, :3601-3616): the derivatives irrad does not provide, the net fluxes of the four
 // flavours, the sign of SFCEM, TS_INT.

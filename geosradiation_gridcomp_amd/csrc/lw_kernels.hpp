@@ -1447,8 +1447,10 @@ __global__ void __launch_bounds__(256) k_lw_reduce(LwArgs<R> A, LwOut<R> O)
     }
     if (!ccol) { s[1] = s[0]; s[3] = s[2]; s[5] = s[4]; }
     const size_t i = (size_t)lev * ld + pc;
-    O.dflx[i] = s[0]; O.dflxc[i] = s[1]; O.uflx[i] = s[2]; O.uflxc[i] = s[3];
-    if (A.dudTs) { O.duflx_dTs[i] = s[4]; O.duflxc_dTs[i] = s[5]; }
+    // a RATS pass (geosrad.hip, lw_dev) asks for the total-sky profiles only: null clear-sky outputs are skipped
+    O.dflx[i] = s[0]; O.uflx[i] = s[2];
+    if (O.dflxc) { O.dflxc[i] = s[1]; O.uflxc[i] = s[3]; }
+    if (A.dudTs) { O.duflx_dTs[i] = s[4]; if (O.duflxc_dTs) O.duflxc_dTs[i] = s[5]; }
     if (lev == nlay) {
         for (int ib = 0; ib < NB_LW; ib++) {
             if (O.band_output[ib]) {

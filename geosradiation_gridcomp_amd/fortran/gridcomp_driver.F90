@@ -1,7 +1,8 @@
 ! gridcomp_driver.F90 -- the RRTMG branch of LW_Driver followed by one heartbeat Update_Flx, as GEOS_IrradGridComp would run them with
 ! its fields on the device: GEOS-native fields (model ordering, SI units) in, INTERNAL state and exports out.
 ! Reads a batch written by tests/test_fortran_shim.py (fields in LWD_* order), writes FLX_INT, DFDTS, SFCEM_INT, CLDTTLW and the
-! exports FLX, OLR, FLNS, SFCEM of a step with TSINST = TS + 1 K.
+! exports FLX, OLR, FLNS, SFCEM of a step with TSINST = TS + 1 K, then the RATS internals FLX_RAT, SFCEM_RAT of
+! RATS_DIAGNOSTICS: CO2 H2O (GEOS_IrradGridComp.F90:3389-3469) from the same driver call.
 program gridcomp_driver
    use iso_c_binding
    use rrtmg_lw_init, only : rrtmg_lw_ini
@@ -13,7 +14,10 @@ program gridcomp_driver
    real(8) :: consts(LWD_NCONST)
    real(4), allocatable :: buf(:)
    real, allocatable :: a(:), ts(:), flx_int(:), dfdts(:), sfcem_int(:), cldtt(:), flx(:), olr(:), flns(:), sfcem(:)
-   type(c_ptr) :: fin(LWD_NIN), fout(LWD_NOUT), uin(LWU_NIN), uout(LWU_NOUT), d_tsinst
+   type(c_ptr) :: fin(LWD_NIN), fout(LWD_NOUT), uin(LWU_NIN), uout(LWU_NOUT), d_tsinst, rout(LWD_NRATOUT)
+   integer, parameter :: nrats = 2
+   character(len=6) :: nameRATS(nrats) = ['CO2   ', 'H2O   ']
+   real, allocatable :: flx_rat(:), sfcem_rat(:)
    logical :: bo(16)
    character(len=512) :: fi, fo
    call get_command_argument(1, fi); call get_command_argument(2, fo)
@@ -45,7 +49,9 @@ program gridcomp_driver
    call set_inhomogeneity(ih)
    call rrtmg_lw_ini
    bo = .false.
-   call lw_driver_rrtmg(ncol, lm, nb, fin, consts, 3, 1, doy, lcldlm, lcldmh, bo, fout)
+   rout = c_null_ptr                     ! FLXU_RAT, FLXD_RAT, DFDTS_RAT: "not associated"
+   rout(LWD_FLX_RAT) = dev_alloc(n3p * nrats); rout(LWD_SFCEM_RAT) = dev_alloc(ncol * nrats)
+   call lw_driver_rrtmg_rats(ncol, lm, nb, fin, consts, 3, 1, doy, lcldlm, lcldmh, bo, fout, nrats, nameRATS, rout)
    ! heartbeat: the surface has warmed by 1 K since the full calculation
    d_tsinst = dev_alloc(ncol)
    ts = ts + 1.0
@@ -65,11 +71,17 @@ program gridcomp_driver
    call dev_get(sfcem, uout(LWU_SFCEM), ncol)
    open(newunit=u, file=trim(fo), access='stream', form='unformatted', status='replace')
    write(u) real(flx_int,8), real(dfdts,8), real(sfcem_int,8), real(cldtt,8), real(flx,8), real(olr,8), real(flns,8), real(sfcem,8)
+   allocate(flx_rat(n3p * nrats), sfcem_rat(ncol * nrats))
+   call dev_get(flx_rat, rout(LWD_FLX_RAT), n3p * nrats); call dev_get(sfcem_rat, rout(LWD_SFCEM_RAT), ncol * nrats)
+   write(u) real(flx_rat,8), real(sfcem_rat,8)
    close(u)
    do k = 1, LWD_NIN
       call dev_free(fin(k))
    end do
    do k = 1, LWD_NOUT
       call dev_free(fout(k))
+   end do
+   do k = 1, LWD_NRATOUT
+      call dev_free(rout(k))
    end do
 end program gridcomp_driver

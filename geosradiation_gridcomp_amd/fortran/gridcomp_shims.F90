@@ -8,7 +8,7 @@ module geosrad_gridcomp
    use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
    implicit none
    private
-   public :: lw_driver_rrtmg, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
    ! ---- GEOSRAD_LWD_* ----
@@ -20,6 +20,7 @@ module geosrad_gridcomp
    integer, parameter, public :: LWD_FLXU_INT = 1, LWD_FLXD_INT = 2, LWD_FLCU_INT = 3, LWD_FLCD_INT = 4, LWD_DFDTS = 5, LWD_DFDTSC = 6, &
       LWD_DFDTSNA = 7, LWD_DFDTSCNA = 8, LWD_FLX_INT = 9, LWD_FLC_INT = 10, LWD_SFCEM_INT = 11, LWD_TS_INT = 12, LWD_CLDTTLW = 13, &
       LWD_CLDHILW = 14, LWD_CLDMDLW = 15, LWD_CLDLOLW = 16, LWD_OLRB = 17, LWD_DOLRB = 18, LWD_NOUT = 18
+   integer, parameter, public :: LWD_FLXU_RAT = 1, LWD_FLXD_RAT = 2, LWD_FLX_RAT = 3, LWD_DFDTS_RAT = 4, LWD_SFCEM_RAT = 5, LWD_NRATOUT = 5
    ! ---- GEOSRAD_LWC_* ----
    integer, parameter, public :: LWC_FLXU_INT = 1, LWC_FLCU_INT = 2, LWC_FLAU_INT = 3, LWC_FLXAU_INT = 4, LWC_FLXD_INT = 5, LWC_FLCD_INT = 6, &
       LWC_FLAD_INT = 7, LWC_FLXAD_INT = 8, LWC_DFDTS = 9, LWC_TS = 10, LWC_NIN = 10
@@ -67,6 +68,15 @@ module geosrad_gridcomp
          type(c_ptr), intent(in) :: fin(*), fout(*)
          real(c_double), intent(in) :: consts(*)
          integer(c_int), intent(in) :: band_output(*)
+      end function
+      integer(c_int) function geosrad_lw_driver_rrtmg_rats_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflglw, liqflglw, doy, lcldlm, &
+            lcldmh, band_output, fout, nrats, rat_gas, rat_out) bind(C, name='geosrad_lw_driver_rrtmg_rats_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm, nb_aer, iceflglw, liqflglw, doy, lcldlm, lcldmh, nrats
+         type(c_ptr), intent(in) :: fin(*), fout(*), rat_out(*)
+         real(c_double), intent(in) :: consts(*)
+         integer(c_int), intent(in) :: band_output(*), rat_gas(*)
       end function
       integer(c_int) function geosrad_sw_driver_rrtmg_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflgsw, liqflgsw, sc, dist, isolvar, &
             dyofyr, include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, fout) bind(C, name='geosrad_sw_driver_rrtmg_dev')
@@ -174,6 +184,37 @@ contains
       if (geosrad_lw_driver_rrtmg_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, consts, &
             int(iceflglw,c_int), int(liqflglw,c_int), int(doy,c_int), int(lcldlm,c_int), int(lcldmh,c_int), bo, fout) /= 0) &
          call geosrad_fail('LW_Driver (RRTMG)')
+   end subroutine
+
+   ! the same with the RATS loop (GEOS_IrradGridComp.F90:3389-3469, :3522-3530, :3614): nameRATS as in AGCM.rc's RATS_DIAGNOSTICS;
+   ! rat_out = INTERNAL FLXU_RAT, FLXD_RAT, FLX_RAT, DFDTS_RAT (IM,JM,0:LM,nRATS), SFCEM_RAT (IM,JM,nRATS) on the device
+   subroutine lw_driver_rrtmg_rats(ncol, lm, nb_aer, fin, consts, iceflglw, liqflglw, doy, lcldlm, lcldmh, band_output, fout, nrats, &
+         nameRATS, rat_out)
+      integer, intent(in) :: ncol, lm, nb_aer, iceflglw, liqflglw, doy, lcldlm, lcldmh, nrats
+      type(c_ptr), intent(in) :: fin(LWD_NIN), fout(LWD_NOUT), rat_out(LWD_NRATOUT)
+      real(c_double), intent(in) :: consts(LWD_NCONST)
+      logical, intent(in) :: band_output(16)
+      character(len=*), intent(in) :: nameRATS(nrats)
+      integer(c_int) :: bo(16), gas(8)
+      integer :: n
+      if (nrats > 8) error stop 'LW_Driver (RRTMG): more than 8 RATS'
+      do n = 1, nrats
+         select case (trim(nameRATS(n)))
+         case ('H2O');    gas(n) = 0
+         case ('O3');     gas(n) = 1
+         case ('CO2');    gas(n) = 2
+         case ('CH4');    gas(n) = 3
+         case ('N2O');    gas(n) = 4
+         case ('CFC11');  gas(n) = 5
+         case ('CFC12');  gas(n) = 6
+         case ('HCFC22'); gas(n) = 7
+         case default;    error stop 'LW_Driver (RRTMG): unknown RAT name'
+         end select
+      end do
+      bo = merge(1_c_int, 0_c_int, band_output)
+      if (geosrad_lw_driver_rrtmg_rats_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, &
+            consts, int(iceflglw,c_int), int(liqflglw,c_int), int(doy,c_int), int(lcldlm,c_int), int(lcldmh,c_int), bo, fout, &
+            int(nrats,c_int), gas, rat_out) /= 0) call geosrad_fail('LW_Driver (RRTMG, RATS)')
    end subroutine
 
    ! RRTMG branch of SORADCORE (GEOS_SolarGridComp.F90:6113-6450) on the packed daytime columns

@@ -255,6 +255,29 @@ int geosrad_mcica_dev(geosrad_ctx *ctx, void *stream, int ncol, int nsubcol, int
 int geosrad_clearcounts(geosrad_ctx *ctx, int ncol, int nsubcol, int nlay, int cloudLM, int cloudMH,
                         const int32_t *cldy_stoch, int32_t *clearCnts);
 
+/* ---- RATS diagnostics (GEOS_IrradGridComp.F90:3389-3469) ------------------------------------------
+ * LW_Driver calls rrtmg_lw once more per gas listed under RATS_DIAGNOSTICS: with that gas's mixing ratio set to zero and keeps
+ * the total-sky UFLX, DFLX, DUFLX_DTS of each call.  geosrad_rrtmg_lw_rats_dev = geosrad_rrtmg_lw_dev (same arguments, same
+ * results) + those profiles for `nrats` gases from the SAME call: uflx_rat, dflx_rat, duflx_dTs_rat are (ncol,nlay+1,nrats)
+ * device arrays (gas slowest, like UFLXRAT(IM*JM,LM+1,nRATS), :3390-3392).  The input checks, the clear | cloudy partition, the
+ * overlap correlations, the McICA sub-columns with their cloud optical depths and clearCounts do not depend on the gases and are
+ * computed once; a gas costs setcoef + the band sweeps + the flux reduction.  Results are bitwise those of a separate call with the
+ * gas's array zeroed.  NB the reference zeroes HCFC22 under the name 'HCFC22_R' but restores it under 'HCFC22' (:3434, :3464), so
+ * that toggle never matches there; GEOSRAD_RAT_HCFC22 implements the evident intent. */
+enum { GEOSRAD_RAT_H2O, GEOSRAD_RAT_O3, GEOSRAD_RAT_CO2, GEOSRAD_RAT_CH4, GEOSRAD_RAT_N2O, GEOSRAD_RAT_CFC11, GEOSRAD_RAT_CFC12,
+       GEOSRAD_RAT_HCFC22, GEOSRAD_RAT_NGAS };
+int geosrad_rrtmg_lw_rats_dev(geosrad_ctx *ctx, void *stream, int ncol, int nlay, int psize, int dudTs,
+                              const void *play, const void *plev, const void *tlay, const void *tlev, const void *tsfc, const void *emis,
+                              const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *n2ovmr,
+                              const void *o2vmr, const void *cfc11vmr, const void *cfc12vmr, const void *cfc22vmr, const void *ccl4vmr,
+                              const void *cldf, const void *ciwp, const void *clwp, const void *rei, const void *rel,
+                              int iceflglw, int liqflglw, const void *tauaer, const void *zm, const void *alat, int dyofyr,
+                              int cloudLM, int cloudMH, int32_t *clearCounts,
+                              void *uflx, void *dflx, void *uflxc, void *dflxc, void *duflx_dTs, void *duflxc_dTs,
+                              const int32_t *band_output, void *olrb, void *dolrb_dTs,
+                              int nrats, const int32_t *rat_gas /*host, GEOSRAD_RAT_**/, void *uflx_rat, void *dflx_rat,
+                              void *duflx_dTs_rat);
+
 /* ---- GridComp data path either side of the solvers -------------------------------------
  * All arrays are DEVICE pointers of the context's real kind in the GEOS layout (IM*JM columns fastest, then the level /
  * layer index in MODEL ordering, 1 = top), asynchronous on `stream`.  A NULL output = Fortran "not associated" (export
@@ -277,6 +300,13 @@ enum { GEOSRAD_LWD_FLXU_INT /*(ncol,0:LM)*/, GEOSRAD_LWD_FLXD_INT, GEOSRAD_LWD_F
 int geosrad_lw_driver_rrtmg_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nb_aer, const void *const *in,
                                 const double *consts, int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh,
                                 const int32_t *band_output, void *const *out);
+/* the same with the RATS loop (GEOS_IrradGridComp.F90:3389-3469) and its share of the un-flip (:3522-3530, :3614): rat_out =
+ * INTERNAL FLXU_RAT, FLXD_RAT, FLX_RAT, DFDTS_RAT (ncol,0:LM,nrats) and SFCEM_RAT (ncol,nrats); any may be NULL. */
+enum { GEOSRAD_LWD_FLXU_RAT, GEOSRAD_LWD_FLXD_RAT, GEOSRAD_LWD_FLX_RAT, GEOSRAD_LWD_DFDTS_RAT, GEOSRAD_LWD_SFCEM_RAT, GEOSRAD_LWD_NRATOUT };
+int geosrad_lw_driver_rrtmg_rats_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nb_aer, const void *const *in,
+                                     const double *consts, int iceflglw, int liqflglw, int doy, int lcldlm, int lcldmh,
+                                     const int32_t *band_output, void *const *out, int nrats, const int32_t *rat_gas,
+                                     void *const *rat_out);
 
 /* geosrad_lw_chou_post_dev: what the Chou-Suarez branch of LW_Driver adds after `call IRRAD` (which takes the GEOS fields as they are):
  * DFDTSC = 0, DFDTSNA = DFDTS, DFDTSCNA = 0 (GEOS_IrradGridComp.F90:2101-2108), the four net fluxes FL*_INT = FL*D_INT + FL*U_INT,

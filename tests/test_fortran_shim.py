@@ -174,8 +174,8 @@ def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
     subprocess.check_call([exe, str(fin), str(fout)], env=env)
     raw = np.fromfile(fout, dtype=np.float64)
     n3p = (lm + 1) * ncol
-    parts = np.split(raw, np.cumsum([n3p, n3p, ncol, ncol, n3p, ncol, ncol]))
-    got = dict(zip(["FLX_INT", "DFDTS", "SFCEM_INT", "CLDTTLW", "FLX", "OLR", "FLNS", "SFCEM"], parts))
+    parts = np.split(raw, np.cumsum([n3p, n3p, ncol, ncol, n3p, ncol, ncol, ncol, 2 * n3p]))
+    got = dict(zip(["FLX_INT", "DFDTS", "SFCEM_INT", "CLDTTLW", "FLX", "OLR", "FLNS", "SFCEM", "FLX_RAT", "SFCEM_RAT"], parts))
     # the same two calls through the Python mirror (inputs rounded to float32 first, as the file holds them)
     ctx = gpu_ctx[4 if kind == "r4" else 8]
     dt = ctx.dtype
@@ -186,7 +186,9 @@ def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
         t[k] = torch.zeros((lm + 1, ncol) if k in G.LWD_OUT_3D else (ncol,), dtype=tdt, device="cuda")
     ptr = {k: v.data_ptr() for k, v in t.items()}
     ctx.set_inhomogeneity(ih)
-    ctx.lw_driver_rrtmg_dev(st, ncol, lm, nb, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"])
+    t["FLX_RAT"] = torch.zeros((2, lm + 1, ncol), dtype=tdt, device="cuda"); t["SFCEM_RAT"] = torch.zeros((2, ncol), dtype=tdt, device="cuda")
+    ptr = {k: v.data_ptr() for k, v in t.items()}
+    ctx.lw_driver_rrtmg_rats_dev(st, ncol, lm, nb, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"], ["CO2", "H2O"])
     u = {k: t[k] for k in ("TS_INT", "SFCEM_INT", "FCLD", "FLX_INT", "FLC_INT", "FLXU_INT", "FLCU_INT", "FLXD_INT", "FLCD_INT", "DFDTS", "DFDTSC")}
     u["TSINST"] = t["TS"] + 1.0
     for k in ("FLX", "OLR", "FLNS", "SFCEM"):
@@ -194,8 +196,10 @@ def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
     ctx.lw_update_flx_dev(st, ncol, lm, True, f["LCLDMH"], f["LCLDLM"], 1.0e15, {k: v.data_ptr() for k, v in u.items()})
     ctx.check(st)
     ctx.set_inhomogeneity(0)
-    for k in ("FLX_INT", "DFDTS", "SFCEM_INT", "CLDTTLW"):
+    for k in ("FLX_INT", "DFDTS", "SFCEM_INT", "CLDTTLW", "FLX_RAT", "SFCEM_RAT"):
         np.testing.assert_array_equal(got[k], t[k].cpu().numpy().astype(np.float64).ravel(), err_msg=k)
+    # without CO2 / without water vapour more leaves at the top (FLX is net downward: more negative)
+    assert (got["FLX_RAT"].reshape(2, lm + 1, ncol)[:, 0] < got["FLX_INT"].reshape(lm + 1, ncol)[0]).all()
     for k in ("FLX", "OLR", "FLNS", "SFCEM"):
         np.testing.assert_array_equal(got[k], u[k].cpu().numpy().astype(np.float64).ravel(), err_msg=k)
     assert (got["OLR"] > 100).all() and (got["SFCEM"] > got["SFCEM_INT"]).all()      # a warmer surface emits more

@@ -329,3 +329,45 @@ def test_chou_branch_of_lw_driver_then_heartbeat(gpu_ctx, rk):
         np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)
     # clear sky emits at least as much as all sky (to the 2 W m-2 the scheme itself allows, see tests/test_gpu_chou.py)
     assert (o["OLR"] > 100).all() and (o["OLA"] >= o["OLRA"] - 2.0).all()
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_lw_driver_rats_internals(gpu_ctx, rk):
+    """LW_Driver with RATS_DIAGNOSTICS (IRR:3389-3469, :3522-3530, :3614): FLXU_RAT / FLXD_RAT / FLX_RAT / DFDTS_RAT / SFCEM_RAT
+    from the driver call = the reference's statements applied to separate solver calls with the gas removed (bitwise)."""
+    from oracle import clib
+    ctx = gpu_ctx[rk]; dt = ctx.dtype; prec = PREC[rk]
+    ncol, lm = 300, 72
+    inp = synth.make_columns(ncol, lm, start=4100, cloudy_frac=0.6, aerosol=True)
+    f = synth.geos_lw_fields(inp)
+    consts = G.lwd_consts()
+    gases = ["CO2", "H2O", "CH4"]
+    ctx.set_inhomogeneity(1)
+    tin, ptr = _dev(f, dt)
+    shapes = {k: ((lm + 1, ncol) if k in G.LWD_OUT_3D else ((ncol, 16) if k in ("OLRB", "DOLRB") else (ncol,))) for k in G.LWD_OUT}
+    shapes.update({k: (len(gases), lm + 1, ncol) for k in G.LWD_RAT_OUT[:4]})
+    shapes["SFCEM_RAT"] = (len(gases), ncol)
+    tout, pout = _zeros(shapes, dt)
+    ptr.update(pout)
+    ctx.lw_driver_rrtmg_rats_dev(_stream(), ncol, lm, 16, ptr, consts, 3, 1, int(inp["dyofyr"]), f["LCLDLM"], f["LCLDMH"], gases)
+    ctx.check(_stream())
+    rr = clib.lwd_prep(f, consts, 3, 1, prec)
+    inp2 = dict(rr); inp2.update(dyofyr=inp["dyofyr"], cloudLM=inp["cloudLM"], cloudMH=inp["cloudMH"])
+    h = ctx.rrtmg_lw_columns(inp2, dudTs=True)
+    o = clib.lwd_post(h, h["clearCounts"], f["EMIS"], f["TS"], prec)
+    for k in G.LWD_OUT[:16]:
+        np.testing.assert_array_equal(tout[k].cpu().numpy(), o[k], err_msg=k)      # the main call is untouched by the RATS passes
+    one = dt(1.0)
+    for r, gas in enumerate(gases):
+        z = dict(inp2); key = G.RAT_VMR[gas]
+        z[key] = np.zeros_like(z[key])
+        s = ctx.rrtmg_lw_columns(z, dudTs=True)
+        fu, fd = -s["uflx"][::-1], s["dflx"][::-1]
+        np.testing.assert_array_equal(tout["FLXU_RAT"][r].cpu().numpy(), fu, err_msg=gas)
+        np.testing.assert_array_equal(tout["FLXD_RAT"][r].cpu().numpy(), fd, err_msg=gas)
+        np.testing.assert_array_equal(tout["DFDTS_RAT"][r].cpu().numpy(), -s["duflx_dTs"][::-1], err_msg=gas)
+        np.testing.assert_array_equal(tout["FLX_RAT"][r].cpu().numpy(), fd + fu, err_msg=gas)
+        sf = s["uflx"][0] - s["dflx"][0] * (one - np.asarray(f["EMIS"], dtype=dt))
+        np.testing.assert_array_equal(tout["SFCEM_RAT"][r].cpu().numpy(), sf.astype(dt), err_msg=gas)
+        assert (tout["FLX_RAT"][r][0] != tout["FLX_INT"][0]).any()
+    ctx.set_inhomogeneity(0)
