@@ -648,19 +648,23 @@ template <typename R> struct Ctx : geosrad_ctx {
         if ((long)nc_max > cap) nc_max = (int)cap;
         int rc = ensure_ws(nc_max, nlay);
         if (rc) return rc;
+        R *rat_part = nullptr;
         if (rats && rats->n > 0) {
             if (rats->n > GEOSRAD_RAT_NGAS || !rats->uflx || !rats->dflx || (dudTs && !rats->duflx_dTs))
                 return fail(GEOSRAD_EINVAL, "RATS: at most 8 gases; uflx_rat / dflx_rat (and duflx_dTs_rat with dudTs) must not be null");
             for (int r = 0; r < rats->n; r++)
                 if (rats->gas[r] < 0 || rats->gas[r] >= GEOSRAD_RAT_NGAS) return fail(GEOSRAD_EINVAL, "RATS: unknown gas code");
-            // an all-zero (nlay, ncol) plane stands for the removed gas's mixing ratio (and for pwvcm of a dry column)
-            const size_t need = (size_t)nlay * ncol * sizeof(R);
+            // an all-zero (nlay, ncol) plane stands for the removed gas's mixing ratio (and for pwvcm of a dry column); behind it
+            // a second set of band partials, so that the main call's stay available to the bands a gas does not touch
+            const size_t zplane = al((size_t)nlay * ncol * sizeof(R));
+            const size_t need = zplane + (size_t)6 * NB_LW * (nlay + 1) * nc_max * sizeof(R);
             if (need > zero_bytes) {
                 if (d_zero) { HIPCHK(hipFree(d_zero)); d_zero = nullptr; zero_bytes = 0; }
-                if (hipMalloc((void **)&d_zero, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the RATS zero plane failed");
-                HIPCHK(hipMemset(d_zero, 0, need));
+                if (hipMalloc((void **)&d_zero, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the RATS workspace failed");
                 zero_bytes = need;
             }
+            HIPCHK(hipMemsetAsync(d_zero, 0, zplane, st));
+            rat_part = (R *)(d_zero + zplane);
         }
 
         for (int c0 = 0; c0 < ncol; c0 += nc_max) {
@@ -682,6 +686,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.dbg_taug = dbg_taug ? (R *)dbg_taug + (size_t)c0 * NG_LW * nlay : nullptr;
             A.dbg_pfracs = dbg_pfracs ? (R *)dbg_pfracs + (size_t)c0 * NG_LW * nlay : nullptr;
             A.clearCounts = clearCounts + c0;
+            A.band_mask = LW_ALL_BANDS;
 
             const dim3 blk(256);
             const unsigned gx = (unsigned)((nc + 255) / 256);
@@ -726,8 +731,10 @@ template <typename R> struct Ctx : geosrad_ctx {
             // gas with that gas's mixing ratio set to zero and keeps the total-sky uflx, dflx, duflx_dTs of each call.  Nothing
             // the clouds decide depends on the gases: the input checks (zero passes them), the clear | cloudy partition, the
             // overlap correlations, the sub-columns with their cloud optical depths (`taucmc`, `laycloudy`) and clearCounts of
-            // the batch are still in the workspace, so a gas costs setcoef + the band sweeps + the reduction only.  Without
-            // water vapour the precipitable water (rrtmg_lw_setcoef.F90:206-272) is 0 / amttl = exactly zero.
+            // the batch are still in the workspace, so a gas costs setcoef + band sweeps + the reduction only - and only the bands
+            // the gas appears in are swept again (LW_RAT_BANDS, lw_device.hpp): their partials go to a second buffer and the
+            // reduction takes every other band's from the main call.  Without water vapour the precipitable water
+            // (rrtmg_lw_setcoef.F90:206-272) is 0 / amttl = exactly zero.
             for (int r = 0; rats && r < rats->n; r++) {
                 LwArgs<R> B = A;
                 const R *z = (const R *)d_zero;
@@ -742,6 +749,8 @@ template <typename R> struct Ctx : geosrad_ctx {
                 default: B.cfc22 = z; break;
                 }
                 B.dbg_taug = nullptr; B.dbg_pfracs = nullptr;
+                B.band_mask = LW_RAT_BANDS[rats->gas[r]];
+                B.part = rat_part;
                 span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, B, d_T); span_end(st);
                 span_begin(4, st);
                 hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
@@ -751,7 +760,8 @@ template <typename R> struct Ctx : geosrad_ctx {
                 const size_t ro = (size_t)r * (nlay + 1) * ncol + c0;
                 OR.uflx = (R *)rats->uflx + ro; OR.dflx = (R *)rats->dflx + ro;
                 OR.duflx_dTs = rats->duflx_dTs ? (R *)rats->duflx_dTs + ro : nullptr;
-                OR.col0 = c0;
+                OR.col0 = c0; OR.part_alt = rat_part; OR.alt_mask = B.band_mask;
+                B.part = A.part;
                 span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, B, OR); span_end(st);
             }
         }

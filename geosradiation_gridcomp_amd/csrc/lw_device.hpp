@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <initializer_list>
 
 namespace geosrad {
 
@@ -92,6 +93,29 @@ template <typename R> struct LwArgs {
     uint32_t *err;               // error bit mask
     R *dbg_taug, *dbg_pfracs;    // optional Fortran (nlay,140,ncol) dumps (nullptr in production)
     int32_t *clearCounts;        // (ncol,4)
+    uint32_t band_mask;          // bit ib set: k_lw_bands runs band ib (all 16 except in a RATS pass, see lw_rat_bands)
+};
+
+// RATS passes (GEOS_IrradGridComp.F90:3405-3468) remove one gas: only the bands whose optical depths read that gas's column amount
+// - or, for the members of setcoef's `summol` (co2, o3, n2o, ch4: rrtmg_lw_setcoef.F90:416-418), the broadening-gas amount of the
+// N2 continuum in bands 1 and 15 (rrtmg_lw_taumol.F90 taugb1, taugb15) - change; every other band's partial fluxes are those of
+// the main call.  Bit ib = band ib (1..16).  Water vapour enters coldry, the continua and the diffusivity angle: all bands.
+__host__ __device__ constexpr uint32_t lw_bandbits(std::initializer_list<int> l)
+{
+    uint32_t m = 0;
+    for (int b : l) m |= 1u << b;
+    return m;
+}
+constexpr uint32_t LW_ALL_BANDS = 0x1FFFEu;
+constexpr uint32_t LW_RAT_BANDS[8] = {
+    LW_ALL_BANDS,                                         // H2O
+    lw_bandbits({4, 5, 7, 8, 13, 1, 15}),                 // O3
+    lw_bandbits({3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 1}),   // CO2
+    lw_bandbits({9, 16, 1, 15}),                          // CH4
+    lw_bandbits({3, 8, 9, 13, 15, 1}),                    // N2O
+    lw_bandbits({6}),                                     // CFC11
+    lw_bandbits({6, 8}),                                  // CFC12
+    lw_bandbits({8}),                                     // HCFC22
 };
 
 }  // namespace geosrad

@@ -1361,6 +1361,7 @@ __host__ __device__ constexpr int lw_band_ng(int ib)
 template <typename R, bool CLD, bool DBG>
 __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
 {
+    if (!((A.band_mask >> LW_BAND_ORDER[blockIdx.y]) & 1u)) return;      // a RATS pass re-runs the bands its gas appears in
     const int nclear = *A.nclear;
     // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
     // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
@@ -1420,6 +1421,8 @@ template <typename R> struct LwOut {
     R *uflx, *dflx, *uflxc, *dflxc, *duflx_dTs, *duflxc_dTs, *olrb, *dolrb_dTs;
     int band_output[NB_LW];
     long col0;   // global index of the batch's first column (for olrb)
+    const R *part_alt;       // RATS pass: the partials of the bands in alt_mask (bit ib) come from here, the others from A.part
+    uint32_t alt_mask;
 };
 
 template <typename R>
@@ -1432,10 +1435,12 @@ __global__ void __launch_bounds__(256) k_lw_reduce(LwArgs<R> A, LwOut<R> O)
     const bool ccol = col >= *A.nclear;
     const int pc = A.perm[col];
     const size_t qs = (size_t)NB_LW * (nlay + 1) * n;
-    const R *p = A.part + (size_t)lev * n + col;
+    const R *const pmain = A.part + (size_t)lev * n + col;
+    const R *const palt = O.part_alt + (size_t)lev * n + col;      // only dereferenced for bands in alt_mask
     R s[6] = {0, 0, 0, 0, 0, 0};
     for (int ib = 0; ib < NB_LW; ib++) {
         const size_t o = (size_t)ib * (nlay + 1) * n;
+        const R *const p = ((O.alt_mask >> (ib + 1)) & 1u) ? palt : pmain;
         s[0] += p[0 * qs + o];
         s[2] += p[2 * qs + o];
         if (A.dudTs) s[4] += p[4 * qs + o];
@@ -1455,8 +1460,8 @@ __global__ void __launch_bounds__(256) k_lw_reduce(LwArgs<R> A, LwOut<R> O)
         for (int ib = 0; ib < NB_LW; ib++) {
             if (O.band_output[ib]) {
                 const size_t o = (size_t)ib * (nlay + 1) * n;
-                O.olrb[(size_t)(O.col0 + pc) * NB_LW + ib] = p[2 * qs + o];
-                if (A.dudTs) O.dolrb_dTs[(size_t)(O.col0 + pc) * NB_LW + ib] = p[4 * qs + o];
+                O.olrb[(size_t)(O.col0 + pc) * NB_LW + ib] = pmain[2 * qs + o];
+                if (A.dudTs) O.dolrb_dTs[(size_t)(O.col0 + pc) * NB_LW + ib] = pmain[4 * qs + o];
             }
         }
     }
