@@ -335,6 +335,105 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
         "roofline": roof, "kernels_ms_per_step": kms, "cpu_baseline": cpu}))
 
 
+def _mcica_cpu_worker(args):
+    start, ncol, nlay, nsub, cloudy = args
+    from geosradiation_gridcomp_amd import synth
+    from oracle import reflib, clib
+    batch, busy = 2048, 0.0              # outputs are 12 B x nsub x nlay per column: batches keep a process below 0.4 GB
+    for b0 in range(0, ncol, batch):
+        inp = synth.make_columns(min(batch, ncol - b0), nlay, start=start + b0, cloudy_frac=cloudy, aerosol=False)
+        a = (inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"], inp["ciwp"], inp["clwp"], nsub)
+        if reflib.available("r4"):
+            reflib.lib("r4"); reflib.set_inhomogeneity(1, "r4")
+            t = time.perf_counter(); reflib.mcica(*a, kind="r4")
+        else:
+            clib.lib(); clib.set_inhomogeneity(1, "f32")
+            t = time.perf_counter(); clib.mcica(*a, prec="f32")
+        busy += time.perf_counter() - t
+    return busy
+
+
+def mcica_cpu_baseline(nlay, nsub, cloudy, per_core=14336):
+    import multiprocessing as mp
+    from oracle import reflib
+    kind = "reference" if reflib.available("r4") else "port"
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    with mp.get_context("fork").Pool(cores) as pool:
+        per = pool.map(_mcica_cpu_worker, [(20_000_000 + i * per_core, per_core, nlay, nsub, cloudy) for i in range(cores)])
+    return {"value": cores * per_core / max(per), "unit": "columns/s", "cores": cores, "kind": kind,
+            "sample": f"{cores} processes x {per_core} columns, generate_stochastic_clouds(nsubcol={nsub}) "
+                      f"({'reference Fortran, oracle/_ref' if kind == 'reference' else 'plain-C oracle'}), {nlay} layers, cloudy fraction "
+                      f"{cloudy}, ih=1; slowest process {max(per):.2f} s",
+            "single_core_columns_per_s": per_core / (sum(per) / len(per))}
+
+
+def bench_mcica(a, rank, world, dev, local_rank, cpu):
+    """--scheme mcica: the stand-alone generator API (cloud_subcol_gen.F90:132, generate_stochastic_clouds) with BASELINE configs[2]'s
+    200 sub-columns: every cell of cldy_stoch (Fortran logical, 4 B), ciwp_stoch, clwp_stoch materialised in HBM.  The one unit of
+    work of SURVEY 8(d) whose compulsory bytes (5 layer fields in, 12 B per (layer, sub-column) cell out) are of the order of
+    its arithmetic: the HBM roofline is the relevant bound."""
+    import torch
+    import torch.distributed as dist
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import Context
+    ncol, nlay, nsub = a.ncol, a.nlay, a.nsubcol
+    tdt = torch.float32 if a.real == 4 else torch.float64
+    inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=False)
+    d = {k: torch.from_numpy(np.ascontiguousarray(inp[k])).to(dev, dtype=tdt) for k in ("zm", "alat", "play", "cldf", "ciwp", "clwp")}
+    d["cldy_stoch"] = torch.zeros((ncol, nsub, nlay), dtype=torch.int32, device=dev)
+    d["ciwp_stoch"] = torch.zeros((ncol, nsub, nlay), dtype=tdt, device=dev)
+    d["clwp_stoch"] = torch.zeros((ncol, nsub, nlay), dtype=tdt, device=dev)
+    ptr = {k: v.data_ptr() for k, v in d.items()}
+    ctx = Context(a.real, device=local_rank)
+    ctx.set_inhomogeneity(1)
+    stream = torch.cuda.current_stream().cuda_stream
+    doy = int(inp["dyofyr"])
+
+    def step():
+        ctx.generate_stochastic_clouds_dev(stream, ncol, nsub, nlay, ptr, doy, 1e-20)
+
+    for _ in range(a.warmup):
+        step()
+    ctx.check(stream)
+    ctx.profile(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    ctx.check(stream)
+    prof = ctx.profile_read()
+    if rank != 0:
+        return
+    ms, n = prof["k_mcica"]
+    abytes = (5 * nlay + 1) * a.real + nsub * nlay * (4 + 2 * a.real)      # zm, play, cldf, ciwp, clwp, alat in; mask + 2 water paths out
+    per_launch_s = ms / max(n, 1) * 1e-3
+    achieved = abytes * ncol / per_launch_s / 1e9
+    frac_cloudy_cells = float((d["cldy_stoch"][: min(ncol, 2000)] != 0).float().mean())
+    print(json.dumps({
+        "metric": "columns/sec", "value": world * ncol * a.steps / elapsed, "unit": "columns/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 (KISS) + " + ("f32" if a.real == 4 else "f64"), "data": "synthetic",
+        "config": {"workload": f"McICA generator stand-alone (generate_stochastic_clouds, BASELINE configs[2]): {ncol} columns/GPU, {nlay} layers, "
+                               f"{nsub} sub-columns, clouds on {100 * a.cloudy:.0f} % of the columns, beta-PDF condensate inhomogeneity (ih=1); "
+                               f"{100 * frac_cloudy_cells:.1f} % of the cells cloudy",
+                   "columns_per_gpu": ncol, "layers": nlay, "sub_columns": nsub, "sharding": "independent column batches per GPU, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "k_mcica", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                     "traffic": 18.6e9 if (ncol, nlay, nsub, a.cloudy, a.real) == (100_000, 72, 200, 0.6, 4) else None,      # profiles/r01_v11_mcica.md
+                     "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
+                     "columns_per_launch": ncol,
+                     "note": "algorithmic bytes = the five layer fields + latitude read once, every (layer, sub-column) cell of the three "
+                             "outputs written once (the Fortran logical mask is 4 B); launch duration from HIP events on the launch stream"},
+        "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0}, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,7 +442,8 @@ def main():
     ap.add_argument("--ncol", type=int, default=97_200, help="columns per GPU (default: C360 tile / 8)")
     ap.add_argument("--nlay", type=int, default=72)
     ap.add_argument("--real", type=int, default=4, choices=[4, 8], help="arithmetic type: 4 = the reference's default real")
-    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw", "chou", "irrad", "sorad", "gridcomp", "heartbeat"])
+    ap.add_argument("--scheme", default="lwsw", choices=["lwsw", "lw", "sw", "chou", "irrad", "sorad", "gridcomp", "heartbeat", "mcica"])
+    ap.add_argument("--nsubcol", type=int, default=200, help="mcica: sub-columns per column (BASELINE configs[2]: 200)")
     ap.add_argument("--cloudy", type=float, default=0.6, help="fraction of cloudy columns (0 = clear-sky)")
     ap.add_argument("--no-aerosol", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
@@ -367,6 +467,8 @@ def main():
     if rank == 0 and a.gpus == 1 and not a.no_cpu:                 # before any GPU initialisation in this process (fork pool)
         if a.scheme == "heartbeat":
             cpu = heartbeat_cpu_baseline(a.nlay)
+        elif a.scheme == "mcica":
+            cpu = mcica_cpu_baseline(a.nlay, a.nsubcol, a.cloudy)
         elif a.scheme == "gridcomp":      # the solvers dominate: same baseline as the default line
             cpu = cpu_baseline(a.nlay, "lwsw", a.cloudy, aerosol)
         else:
@@ -391,6 +493,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if a.scheme == "mcica":
+        if a.ncol == 97_200:
+            a.ncol = 100_000          # BASELINE configs[2]
+        bench_mcica(a, rank, world, dev, local_rank, cpu)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if a.scheme in ("gridcomp", "heartbeat"):
         bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu)
         if world > 1:

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -372,6 +373,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_err) (void)hipFree(d_err);
         if (d_io) (void)hipFree(d_io);
         if (d_mc) (void)hipFree(d_mc);
+        for (auto &e : sa_jumps) if (e.second) (void)hipFree(e.second);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -1768,6 +1770,7 @@ template <typename R> struct Ctx : geosrad_ctx {
 
     // ---- stand-alone McICA generator ---------------------------------------------------------------------------------
     char *d_mc = nullptr; size_t mc_bytes = 0;      // alpha / rcorr scratch of the stand-alone generator
+    std::map<std::tuple<int, int, int>, KissJump *> sa_jumps;      // (nsubcol, nlay, inhomogeneous?) -> jump to every sub-column
     int mcica_dev(hipStream_t st, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
                   const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so, int32_t *cldy,
                   void *ciwp_s, void *clwp_s) override
@@ -1792,8 +1795,10 @@ template <typename R> struct Ctx : geosrad_ctx {
         }
         R *d_alpha = (R *)d_mc, *d_rcorr = (R *)(d_mc + al(cl * sizeof(R)));
         const unsigned gx = (unsigned)((ncol + 255) / 256);
+        span_begin(2, st);
         hipLaunchKernelGGL(k_overlap<R>, dim3(gx, nlay), dim3(256), 0, st, ncol, ncol, nlay, doy, (const R *)zmid, (const R *)alat,
                            (const int32_t *)nullptr, (const int32_t *)nullptr, (const LwDev<R> *)d_T, d_alpha, d_rcorr, (uint8_t *)nullptr);
+        span_end(st);
         McArgs<R> M{};
         M.ncol = ncol; M.ld = ncol; M.nlay = nlay; M.nsubcol = nsubcol; M.doy = doy; M.cloudLM = 1; M.cloudMH = 2;
         for (int k = 0; k < 4; k++) M.so[k] = sov[k];
@@ -1804,7 +1809,31 @@ template <typename R> struct Ctx : geosrad_ctx {
         McPlan MP; int nseg = 0;
         int rc = mc_plan(1, nsubcol, nlay, MP, nseg);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+        const size_t lds = mc_sa_lds_reals(nlay, nsubcol) * sizeof(R);
+        const long nblk = ((long)ncol * nsubcol + 64 * MC_SA_K - 1) / (64 * MC_SA_K);
+        span_begin(3, st);
+        if (lds <= 160 * 1024 && nblk <= 0x7FFFFFFFL && !getenv("GEOSRAD_MCICA_LANE_COLUMN")) {
+            // lane = (column, sub-column) pair, outputs written row-major through an LDS tile (k_mcica_sa)
+            const bool inhomo = h_T.xcw != nullptr;
+            const auto key = std::make_tuple(nsubcol, nlay, inhomo ? 1 : 0);
+            auto it = sa_jumps.find(key);
+            if (it == sa_jumps.end()) {
+                const uint64_t per = (uint64_t)(inhomo ? 4 : 2) * (uint64_t)nlay;
+                std::vector<KissJump> js((size_t)nsubcol);
+                for (int q = 0; q < nsubcol; q++) js[q] = make_kiss_jump((uint64_t)q * per);
+                KissJump *dj = nullptr;
+                HIPCHK(hipMalloc((void **)&dj, js.size() * sizeof(KissJump)));
+                HIPCHK(hipMemcpy(dj, js.data(), js.size() * sizeof(KissJump), hipMemcpyHostToDevice));
+                it = sa_jumps.emplace(key, dj).first;
+            }
+            if (lds > 65536) HIPCHK(hipFuncSetAttribute((const void *)k_mcica_sa<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_mcica_sa<R>), dim3((unsigned)nblk), dim3(64), lds, st, M, (const KissJump *)it->second, MP.jhalf,
+                               (const LwDev<R> *)d_T);
+        } else {
+            // lane = column (tiles beyond 64 KB of LDS: fp64 with more than 127 layers)
+            hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+        }
+        span_end(st);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }

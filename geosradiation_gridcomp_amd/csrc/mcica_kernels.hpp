@@ -119,6 +119,29 @@ template <typename R> GR_DEV R zcw_lookup(const R *__restrict__ xcw, R cdf, R si
     return nf_add(nf_add(nf_add(t1, t2), t3), t4);
 }
 
+// zcw_lookup in two halves, same operations in the same order: the four table values are requested in one place and combined in
+// another, so that independent work can sit between the request and its first use (k_mcica_sa)
+template <typename R> struct ZcwReq { R v0, v1, v2, v3, r1, r2; };
+template <typename R> GR_DEV void zcw_request(const R *__restrict__ xcw, R cdf, R sigma, ZcwReq<R> &q)
+{
+    constexpr int n1 = 1000, n2 = 140;
+    R rind1 = nf_add(nf_mul(cdf, (R)(n1 - 1)), (R)1.);
+    int ind1 = (int)rind1; ind1 = ind1 > n1 - 1 ? n1 - 1 : ind1; ind1 = ind1 < 1 ? 1 : ind1;
+    q.r1 = nf_sub(rind1, (R)ind1);
+    R rind2 = nf_sub(nf_mul((R)40., sigma), (R)3.);
+    int ind2 = (int)rind2; ind2 = ind2 > n2 - 1 ? n2 - 1 : ind2; ind2 = ind2 < 1 ? 1 : ind2;
+    q.r2 = nf_sub(rind2, (R)ind2);
+    const R *p = xcw + (size_t)(ind2 - 1) * n1 + (ind1 - 1);
+    q.v0 = p[0]; q.v1 = p[n1]; q.v2 = p[1]; q.v3 = p[n1 + 1];
+}
+template <typename R> GR_DEV R zcw_combine(const ZcwReq<R> &q)
+{
+    const R u1 = nf_sub((R)1.0, q.r1), u2 = nf_sub((R)1.0, q.r2);
+    const R t1 = nf_mul(nf_mul(u1, u2), q.v0), t2 = nf_mul(nf_mul(u1, q.r2), q.v1);
+    const R t3 = nf_mul(nf_mul(q.r1, u2), q.v2), t4 = nf_mul(nf_mul(q.r1, q.r2), q.v3);
+    return nf_add(nf_add(nf_add(t1, t2), t3), t4);
+}
+
 // KISS seeds from the fractional part of the four lowest-layer pressures (cloud_subcol_gen.F90:375-400)
 template <typename R> GR_DEV Kiss kiss_seed(const R *__restrict__ play, int ld, int nlay, int col, bool surface_at_one,
                                             const int *so)
@@ -481,6 +504,172 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
         atomicAdd(&M.clearCounts[(size_t)3 * ld + pc], __popc(~any_lo & act));
         if (err) atomicOr(M.err, err);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_mcica_sa: the stand-alone generator API (generate_stochastic_clouds, cloud_subcol_gen.F90:132-487) with every cell of
+// cldy_stoch / ciwp_stoch / clwp_stoch, Fortran (nlay,nsubcol,ncol), materialised: 12 B out per (layer, sub-column) cell against
+// ~60 integer operations - the HBM roofline is the bound that matters here, so the mapping follows the OUTPUT.
+//   lane = one (column, sub-column) pair, pairs numbered f = col * nsubcol + isub: the 64 pairs of a wavefront own the contiguous
+//   block [f0 * nlay, (f0 + 64) * nlay) of each output array whatever nsubcol is (a wave may straddle two columns).
+//   Each lane reaches its sub-column's two stream positions by jump-ahead (table of nsubcol jumps, built once on the host) and walks
+//   the layers once; the only per-cell state the outputs need - the condensate scaling factor, or "clear" - goes to an LDS tile
+//   [64 pairs][nlay] (row stride odd: conflict-free both ways).  The tile is then written out ROW-MAJOR: consecutive lanes write
+//   consecutive addresses (256 B per store instruction), the water paths re-formed from the layer's ciwp / clwp exactly as
+//   the walk would have (one multiplication, cloud_subcol_gen.F90:438-466).  k_mcica<R, 1> (lane = column) wrote 4 B per lane at a
+//   stride of nsubcol * nlay * 4 B.
+// A pair whose column has no cloud fraction anywhere is clear in every cell (the generator's numbers are < 1): its lanes skip the
+// walk, a wave of such pairs skips it altogether.
+// ---------------------------------------------------------------------------------------------------
+constexpr int MC_SA_K = 8;          // chunks of 64 pairs per wavefront: the staged layer fields and the prologue are shared by the chunks
+// LDS reals per block (one wavefront): the tile, five staged layer fields of the block's columns, their "has cloud fraction" flags
+__host__ __device__ constexpr int mc_sa_ncw(int nsub) { return (64 * MC_SA_K - 1) / nsub + 2; }      // columns MC_SA_K chunks can touch
+__host__ __device__ constexpr size_t mc_sa_lds_reals(int nlay, int nsub)
+{
+    return (size_t)64 * (nlay | 1) + (size_t)5 * mc_sa_ncw(nsub) * nlay + (size_t)mc_sa_ncw(nsub);
+}
+template <typename R>
+__global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__restrict__ jsubs, KissJump jhalf,
+                                                 const LwDev<R> *__restrict__ Tp)
+{
+    extern __shared__ __align__(16) unsigned char mc_lds[];
+    const LwDev<R> &T = *Tp;
+    const int nlay = M.nlay, ld = M.ld, nsub = M.nsubcol, n = M.ncol;
+    const int rs = nlay | 1;
+    const long ntot = (long)n * nsub;
+    const int lane = threadIdx.x;
+    const int ncw = mc_sa_ncw(nsub);
+    R *const tile = reinterpret_cast<R *>(mc_lds);
+    const long fb = (long)blockIdx.x * (64 * MC_SA_K);      // first pair of the block
+    const bool inhomo = T.xcw != nullptr;
+    const bool surface_at_one = M.play[0] > M.play[(size_t)(nlay - 1) * ld];
+
+    // the layer inputs of the block's columns, staged once: the walk and the write-out read them from LDS (a loop with a run-time trip
+    // count is not unrolled, so a global load per layer inside it would cost a full memory round trip per layer)
+    const int col0 = (int)(fb / nsub), nst = ncw * nlay;
+    R *const cwi = tile + 64 * rs, *const cwl = cwi + nst, *const cfs = cwl + nst, *const als = cfs + nst, *const rcs = als + nst;
+    int *const colflag = reinterpret_cast<int *>(rcs + nst);
+    if (lane < ncw) colflag[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    {
+        int c = 0, l = lane;
+        while (l >= nlay) { l -= nlay; c++; }
+        for (int i = lane; i < nst; i += 64) {
+            const int cc = col0 + c < n ? col0 + c : n - 1;
+            const size_t a = (size_t)l * ld + cc, w = (size_t)l * n + cc;
+            const R v0 = M.ciwp[a], v1 = M.clwp[a], v2 = M.cldf[a], v3 = M.alpha[w], v4 = inhomo ? M.rcorr[w] : (R)0;
+            cwi[i] = v0; cwl[i] = v1; cfs[i] = v2; als[i] = v3; rcs[i] = v4;
+            if (v2 > 0) colflag[c] = 1;              // every writer writes 1
+            l += 64;
+            while (l >= nlay) { l -= nlay; c++; }
+        }
+    }
+    __syncthreads();
+  for (int ch = 0; ch < MC_SA_K; ch++) {
+    const long f0 = fb + (long)ch * 64;
+    if (f0 >= ntot) break;                           // uniform
+    const bool active = f0 + lane < ntot;
+    const long f = active ? f0 + lane : ntot - 1;
+    const int col = (int)(f / nsub), isub = (int)(f - (long)col * nsub);
+    const int cofs = (col - col0) * nlay;
+    const bool colcloudy = active && colflag[col - col0] != 0;
+    const bool wave_cloudy = __ballot(colcloudy) != 0;
+    if (wave_cloudy) {
+        Kiss k1 = kiss_seed<R>(M.play, ld, nlay, col, surface_at_one, M.so);
+        if (isub > 0) {       // n = 0 must stay the identity (a raw seed may be a non-canonical MWC residue)
+            KissJump J = jsubs[isub];
+            kiss_jump(k1, J);
+        }
+        Kiss k2 = k1;
+        if (inhomo) kiss_jump(k2, jhalf);
+        R cprev = 0, c3prev = 0;
+        // layers in groups of MC_G: the group's draws (integer work only), then the previous group's scaling factors are combined
+        // and stored, then this group's table values are requested - a request has a whole group's arithmetic to arrive in;
+        // the layer inputs of the next group are requested a group ahead as well
+        constexpr int MC_G = 4;
+        ZcwReq<R> pq[MC_G];
+        bool pcl[MC_G];
+#pragma unroll
+        for (int k = 0; k < MC_G; k++) { pcl[k] = false; pq[k].v0 = pq[k].v1 = pq[k].v2 = pq[k].v3 = pq[k].r1 = pq[k].r2 = 0; }
+        bool ppend = false;
+        for (int g0 = 0; g0 < nlay + MC_G; g0 += MC_G) {      // one extra trip stores the last group
+            R al[MC_G], rc[MC_G], cf[MC_G];
+#pragma unroll
+            for (int k = 0; k < MC_G; k++) {
+                int il = g0 + k; il = il < nlay ? il : nlay - 1;
+                al[k] = als[cofs + il]; rc[k] = rcs[cofs + il]; cf[k] = cfs[cofs + il];
+            }
+            bool cl[MC_G];
+            R c3[MC_G], sg[MC_G];
+            bool anyc = false;
+#pragma unroll
+            for (int k = 0; k < MC_G; k++) {
+                const int il = g0 + k;
+                cl[k] = false; c3[k] = 0; sg[k] = 1;
+                if (il >= nlay) continue;
+                const R thr = nf_sub((R)1., cf[k]);
+                sg[k] = cf[k] > (R)0.99 ? (R)0.5 : (cf[k] > (R)0.9 ? (R)0.71 : (R)1.0);
+                // cloud presence with exponential overlap (:406-414)
+                R cdf1 = kiss_next<R>(k1);
+                const R cdf2 = kiss_next<R>(k1);
+                if (il > 0 && cdf2 < al[k]) cdf1 = cprev;
+                cprev = cdf1;
+                cl[k] = colcloudy && cdf1 >= thr;
+                anyc = anyc || cl[k];
+                if (inhomo) {     // condensate with exponential overlap (:416-466); the stream is consumed for every layer
+                    const R c2 = kiss_next<R>(k2);
+                    R cdf3 = kiss_next<R>(k2);
+                    if (il > 0 && c2 < rc[k]) cdf3 = c3prev;
+                    c3prev = cdf3;
+                    c3[k] = cdf3;
+                }
+            }
+            // the previous group's cells
+#pragma unroll
+            for (int k = 0; k < MC_G; k++) {
+                const int il = g0 - MC_G + k;
+                if (il < 0 || il >= nlay) continue;
+                const R z = ppend ? zcw_combine<R>(pq[k]) : (R)1;
+                tile[lane * rs + il] = pcl[k] ? z : (R)-1;
+            }
+            // this group's requests (wave-uniform test around the gathers)
+            ppend = inhomo && __ballot(anyc) != 0;
+            if (ppend) {
+#pragma unroll
+                for (int k = 0; k < MC_G; k++) zcw_request<R>(T.xcw, c3[k], sg[k], pq[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < MC_G; k++) pcl[k] = cl[k];
+        }
+    }
+    __syncthreads();
+    const long rows = (ntot - f0) < 64 ? (ntot - f0) : 64;
+    const int total = (int)rows * nlay;
+    const size_t o0 = (size_t)f0 * nlay;
+    // row r of the tile = pair f0 + r; its column, relative to col0, is tracked with r (no division in the loop)
+    const int c0rel = (int)(f0 / nsub) - col0;
+    int r = 0, j = lane, rq = (int)(f0 - (long)(col0 + c0rel) * nsub), crel = c0rel;
+    while (j >= nlay) { j -= nlay; r++; if (++rq >= nsub) { rq -= nsub; crel++; } }
+#pragma unroll 4
+    for (int idx = lane; idx < total; idx += 64) {
+        const R z = wave_cloudy ? tile[r * rs + j] : (R)-1;
+        R ci = 0, cl = 0;
+        bool c = false;
+        if (z >= (R)0) {
+            const int a = crel * nlay + j;
+            // homogeneous condensate: z = 1 and x * 1 = x (:438-443)
+            ci = nf_mul(cwi[a], z); cl = nf_mul(cwl[a], z);
+            const bool cin = ci <= M.cwp_tiny, cln = cl <= M.cwp_tiny;
+            if (cin) ci = 0;
+            if (cln) cl = 0;
+            c = !(cin && cln);
+        }
+        M.cldy[o0 + idx] = c ? 1 : 0; M.ciwp_s[o0 + idx] = ci; M.clwp_s[o0 + idx] = cl;
+        j += 64;
+        while (j >= nlay) { j -= nlay; r++; if (++rq >= nsub) { rq -= nsub; crel++; } }
+    }
+    __syncthreads();                                 // the tile is reused by the next chunk
+  }
 }
 
 // clearCounts_threeBand stand-alone (cloud_subcol_gen.F90:611-769): cldy Fortran (nlay,nsubcol,ncol)

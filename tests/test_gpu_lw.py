@@ -283,3 +283,31 @@ def test_rats_passes_equal_separate_calls_with_the_gas_removed(gpu_ctx, rk):
     finally:
         ctx.set_chunk(131072)
         ctx.set_inhomogeneity(0)
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+@pytest.mark.parametrize("ih", [0, 1])
+def test_standalone_generator_pair_mapping_equals_column_mapping(gpu_ctx, rk, ih):
+    """generate_stochastic_clouds stand-alone: k_mcica_sa (lane = (column, sub-column) pair, outputs written row-major through an LDS
+    tile) against k_mcica<R, 1> (lane = column), which test_mcica_generator_matches_reference pins to the reference's masks:
+    identical bits for sub-column counts below, at and above a wavefront's 64 pairs, ragged last waves included."""
+    import os
+    from geosradiation_gridcomp_amd import synth
+    ctx = gpu_ctx[rk]
+    ncol, nlay = 37, 72
+    inp = synth.make_columns(ncol, nlay, start=777, cloudy_frac=0.7, aerosol=False)
+    a = (inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"], inp["ciwp"], inp["clwp"], 1e-20)
+    ctx.set_inhomogeneity(ih)
+    try:
+        for nsub in (1, 8, 64, 140, 200, 333):
+            new = ctx.generate_stochastic_clouds(ncol, nsub, nlay, *a)
+            os.environ["GEOSRAD_MCICA_LANE_COLUMN"] = "1"
+            try:
+                old = ctx.generate_stochastic_clouds(ncol, nsub, nlay, *a)
+            finally:
+                del os.environ["GEOSRAD_MCICA_LANE_COLUMN"]
+            for x, y, nm in zip(new, old, ("cldy_stoch", "ciwp_stoch", "clwp_stoch")):
+                np.testing.assert_array_equal(x, y, err_msg=f"{nm} nsubcol={nsub}")
+            assert nsub < 8 or (new[0].any() and not new[0].all())
+    finally:
+        ctx.set_inhomogeneity(0)
