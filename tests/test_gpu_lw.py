@@ -311,3 +311,41 @@ def test_standalone_generator_pair_mapping_equals_column_mapping(gpu_ctx, rk, ih
             assert nsub < 8 or (new[0].any() and not new[0].all())
     finally:
         ctx.set_inhomogeneity(0)
+
+
+def test_rats_argument_errors_and_empty_list(gpu_ctx):
+    """no gas listed = the plain call; unknown gas codes, missing output arrays and input errors are refused (negative values in the
+    inputs are reported by the shared input check, as the reference's first rrtmg_lw call of the loop would)"""
+    import torch
+    from geosradiation_gridcomp_amd.api import GeosradError, GeosradInputError
+    from geosradiation_gridcomp_amd import synth, gridcomp as G
+    ctx = gpu_ctx[4]
+    ncol, nlay = 70, 72
+    inp = synth.make_columns(ncol, nlay, start=99, cloudy_frac=0.5, aerosol=False)
+    names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + list(G.RAT_VMR.values()) + \
+            ["o2vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel"]
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).cuda() for k in names}
+    for k in FLUX:
+        t[k] = torch.zeros((nlay + 1, ncol), device="cuda")
+    t["clearCounts"] = torch.zeros((4, ncol), dtype=torch.int32, device="cuda")
+    for k in ("uflx_rat", "dflx_rat", "duflx_dTs_rat"):
+        t[k] = torch.zeros((1, nlay + 1, ncol), device="cuda")
+    ptr = {k: v.data_ptr() for k, v in t.items()}
+    st = torch.cuda.current_stream().cuda_stream
+    a = (st, ncol, nlay, True, ptr, 3, 1, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]))
+    ctx.rrtmg_lw_rats_dev(*a, [])
+    ctx.check(st)
+    want = ctx.rrtmg_lw_columns(inp)
+    for k in FLUX:
+        np.testing.assert_array_equal(t[k].cpu().numpy(), want[k], err_msg=k)
+    with pytest.raises(GeosradError, match="unknown gas code"):
+        ctx.rrtmg_lw_rats_dev(*a, [8])
+    with pytest.raises(GeosradError, match="at most 8 gases|bad RATS"):
+        ctx.rrtmg_lw_rats_dev(*a, list(range(8)) + [0])
+    p2 = dict(ptr); p2["dflx_rat"] = 0
+    with pytest.raises(GeosradError, match="must not be null"):
+        ctx.rrtmg_lw_rats_dev(st, ncol, nlay, True, p2, 3, 1, 180, int(inp["cloudLM"]), int(inp["cloudMH"]), ["CO2"])
+    t["tlay"][5, 3] = -1.0
+    ctx.rrtmg_lw_rats_dev(*a, ["CO2"])
+    with pytest.raises(GeosradInputError, match="negative values in input: tlay"):
+        ctx.check(st)
