@@ -648,6 +648,38 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
     const size_t o0 = (size_t)f0 * nlay;
     // row r of the tile = pair f0 + r; its column, relative to col0, is tracked with r (no division in the loop)
     const int c0rel = (int)(f0 / nsub) - col0;
+    if constexpr (sizeof(R) == 4) {
+        if ((nlay & 3) == 0) {
+            // four consecutive layers of a row per lane: 16-byte stores, 1 KB per store instruction, a quarter of the loop trips
+            int r = 0, j = lane * 4, rq = (int)(f0 - (long)(col0 + c0rel) * nsub), crel = c0rel;
+            while (j >= nlay) { j -= nlay; r++; if (++rq >= nsub) { rq -= nsub; crel++; } }
+            for (int idx = lane * 4; idx < total; idx += 256) {
+                R z[4], ci[4], cl[4];
+                int c[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { z[k] = wave_cloudy ? tile[r * rs + j + k] : (R)-1; ci[k] = 0; cl[k] = 0; c[k] = 0; }
+                if (z[0] >= (R)0 || z[1] >= (R)0 || z[2] >= (R)0 || z[3] >= (R)0) {
+                    const int a = crel * nlay + j;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (z[k] >= (R)0) {
+                            R x = nf_mul(cwi[a + k], z[k]), y = nf_mul(cwl[a + k], z[k]);
+                            const bool cin = x <= M.cwp_tiny, cln = y <= M.cwp_tiny;
+                            ci[k] = cin ? (R)0 : x; cl[k] = cln ? (R)0 : y;
+                            c[k] = !(cin && cln);
+                        }
+                    }
+                }
+                *reinterpret_cast<int4 *>(M.cldy + o0 + idx) = make_int4(c[0], c[1], c[2], c[3]);
+                *reinterpret_cast<float4 *>(M.ciwp_s + o0 + idx) = make_float4(ci[0], ci[1], ci[2], ci[3]);
+                *reinterpret_cast<float4 *>(M.clwp_s + o0 + idx) = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                j += 256;
+                while (j >= nlay) { j -= nlay; r++; if (++rq >= nsub) { rq -= nsub; crel++; } }
+            }
+            __syncthreads();                         // the tile is reused by the next chunk
+            continue;
+        }
+    }
     int r = 0, j = lane, rq = (int)(f0 - (long)(col0 + c0rel) * nsub), crel = c0rel;
     while (j >= nlay) { j -= nlay; r++; if (++rq >= nsub) { rq -= nsub; crel++; } }
 #pragma unroll 4
