@@ -349,3 +349,42 @@ def test_rats_argument_errors_and_empty_list(gpu_ctx):
     ctx.rrtmg_lw_rats_dev(*a, ["CO2"])
     with pytest.raises(GeosradInputError, match="negative values in input: tlay"):
         ctx.check(st)
+
+
+def test_standalone_generator_full_size_is_batch_independent(gpu_ctx):
+    """BASELINE configs[2] at full size (100 000 columns x 200 sub-columns x 72 layers, 17.3 GB of outputs, element offsets beyond
+    2^32 bytes): a column's sub-columns do not depend on the batch it is generated in - the first, a middle and the last 70 columns
+    of the big batch equal the same columns generated alone - and the clear columns are clear."""
+    import torch
+    from geosradiation_gridcomp_amd import synth
+    ctx = gpu_ctx[4]
+    ncol, nlay, nsub, m = 100_000, 72, 200, 70
+    ctx.set_inhomogeneity(1)
+    try:
+        inp = synth.make_columns(ncol, nlay, start=0, cloudy_frac=0.6, aerosol=False)
+        keys = ("zm", "alat", "play", "cldf", "ciwp", "clwp")
+        d = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).cuda() for k in keys}
+        d["cldy_stoch"] = torch.full((ncol, nsub, nlay), -1, dtype=torch.int32, device="cuda")
+        d["ciwp_stoch"] = torch.full((ncol, nsub, nlay), -1.0, device="cuda")
+        d["clwp_stoch"] = torch.full((ncol, nsub, nlay), -1.0, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        ctx.generate_stochastic_clouds_dev(st, ncol, nsub, nlay, {k: v.data_ptr() for k, v in d.items()}, int(inp["dyofyr"]), 1e-20)
+        ctx.check(st)
+        assert int((d["cldy_stoch"] < 0).sum()) == 0 and float(d["ciwp_stoch"].min()) >= 0.0      # every cell written
+        for c0 in (0, 54_321, ncol - m):
+            sub = {k: (v[..., c0:c0 + m] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v) for k, v in inp.items()}
+            cl, ci, cw = ctx.generate_stochastic_clouds(m, nsub, nlay, sub["zm"], sub["alat"], int(inp["dyofyr"]), sub["play"],
+                                                        sub["cldf"], sub["ciwp"], sub["clwp"], 1e-20)
+            np.testing.assert_array_equal(d["cldy_stoch"][c0:c0 + m].cpu().numpy(), cl)
+            np.testing.assert_array_equal(d["ciwp_stoch"][c0:c0 + m].cpu().numpy(), ci)
+            np.testing.assert_array_equal(d["clwp_stoch"][c0:c0 + m].cpu().numpy(), cw)
+            assert cl.any()
+        clearcol = torch.from_numpy((inp["cldf"] > 0).any(axis=0) == False).cuda()      # noqa: E712
+        assert int(d["cldy_stoch"][clearcol].sum()) == 0 and int(clearcol.sum()) > 30_000
+        cloudy_cells = d["cldy_stoch"] != 0
+        assert bool(((d["ciwp_stoch"] > 0) | (d["clwp_stoch"] > 0))[cloudy_cells].all())
+        assert float(d["ciwp_stoch"][~cloudy_cells].max()) == 0.0
+        del d, cloudy_cells
+        torch.cuda.empty_cache()
+    finally:
+        ctx.set_inhomogeneity(0)
