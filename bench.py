@@ -449,6 +449,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="lwsw: RRTMG_LW and RRTMG_SW on ONE stream (default: two HIP streams - the two solvers are independent)")
     ap.add_argument("--na-pass", action="store_true", help="gridcomp: also request the no-aerosol flavour of the SW fluxes (FSWNA ...)")
+    ap.add_argument("--lit", type=float, default=1.0, help="lwsw / sw: fraction of the columns RRTMG_SW runs on (packed daytime columns; default: all)")
     ap.add_argument("--rats", type=int, default=0, help="gridcomp: RATS diagnostics for the first N gases of gridcomp.RAT_GAS (0-8)")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -464,6 +465,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     cpu = None
+    if a.lit < 1.0:
+        a.no_cpu = True           # the CPU leg times LW and SW on the same columns: not the --lit workload
     if rank == 0 and a.gpus == 1 and not a.no_cpu:                 # before any GPU initialisation in this process (fork pool)
         if a.scheme == "heartbeat":
             cpu = heartbeat_cpu_baseline(a.nlay)
@@ -548,6 +551,21 @@ def main():
             d["so_" + k] = torch.zeros(ncol, device=dev, dtype=tdt)
         d["so_flx_sfc_band"] = torch.zeros((8, ncol), device=dev, dtype=tdt)
     ptr = {k: v.data_ptr() for k, v in d.items()}
+    # --lit f < 1: RRTMG_SW runs on the packed daytime columns only, as SORADCORE does after PackIt (SOL:3686, :7753-7773; SURVEY
+    # 8(d) cfg 4 has about half of a tile lit): the first f * ncol columns of the batch, as contiguous arrays of their own
+    ncol_sw = ncol if a.lit >= 1.0 else max(64, int(round(ncol * a.lit)))
+    ptr_sw = ptr
+    if do_sw and ncol_sw < ncol:
+        sw_names = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat"] \
+            + SW_IN + (SW_AER if aerosol else [])
+        dsw = {k: d[k][..., :ncol_sw].contiguous() for k in sw_names}
+        for k in ("swuflx", "swdflx", "swuflxc", "swdflxc"):
+            dsw[k] = torch.zeros((nlay + 1, ncol_sw), device=dev, dtype=tdt)
+        for k in SW_OUT1:
+            dsw[k] = torch.zeros(ncol_sw, device=dev, dtype=tdt)
+        dsw["fswband"] = torch.zeros((14, ncol_sw), device=dev, dtype=tdt)
+        dsw["clearCounts_sw"] = torch.zeros((4, ncol_sw), device=dev, dtype=torch.int32)
+        ptr_sw = {k: v.data_ptr() for k, v in dsw.items()}
     ptr_ch = {k[3:]: v for k, v in ptr.items() if k.startswith("ch_")}
     ptr_so = {k[3:]: v for k, v in ptr.items() if k.startswith("so_")}
 
@@ -565,7 +583,7 @@ def main():
         if do_lw:
             ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
         if do_sw:      # GEOS call: isolvar 0 scaled to scon, normalised fluxes (SOL:6230-6300)
-            ctx.rrtmg_sw_dev(sw_stream, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 10 if aerosol else 0, lm, mh, normFlx=1)
+            ctx.rrtmg_sw_dev(sw_stream, ncol_sw, nlay, 1361.0, 1.0, 0, ptr_sw, 3, 1, doy, 10 if aerosol else 0, lm, mh, normFlx=1)
         if do_irrad:
             for k in aer0:                    # taua / ssaa / asya are in-out (rescaled in place): restore the inputs
                 d["ch_" + k].copy_(aer0[k])
@@ -611,11 +629,12 @@ def main():
         else:
             abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(nlay, a.real, aerosol)
         per_launch_s = (ms / max(n, 1)) * 1e-3
-        achieved = abytes * (ncol / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        ncol_k = ncol_sw if kname == "k_sw_bands" else ncol          # columns the dominant kernel's launches cover
+        achieved = abytes * (ncol_k / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
         # separate rocprofv3 --pmc runs): only quoted for the exact configuration those passes were collected on
         traffic = None
-        if a.scheme == "lwsw" and (ncol, nlay, a.cloudy, aerosol, a.real) == (97_200, 72, 0.6, True, 4):
+        if a.scheme == "lwsw" and (ncol, ncol_sw, nlay, a.cloudy, aerosol, a.real) == (97_200, 97_200, 72, 0.6, True, 4):
             traffic = {"k_sw_bands": 66.6e9, "k_lw_bands": 30.1e9}.get(kname)      # profiles/r01_v9_lwsw_pmc_traffic.md (both instantiations)
         elif a.scheme == "chou" and (ncol, nlay, a.cloudy, aerosol, a.real) == (20_000, 72, 0.6, True, 4):
             traffic = {"k_sorad_pass": 32.9e9, "k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
@@ -626,8 +645,9 @@ def main():
             wl = "BASELINE configs[1]: %d columns/GPU, %d layers, RRTMG_LW 140 g-points clear-sky" % (ncol, nlay)
         else:
             wl = ("%sper-GPU share: %d columns/GPU, %d layers, %s, McICA clouds on %.0f %% of the columns (ih=1), aerosols %s, "
-                  "every column lit" % ("BASELINE configs[3] (C360 tile / 8 GPUs) " if ncol == 97_200 and a.scheme == "lwsw" else "",
-                                         ncol, nlay, schemes, 100 * a.cloudy, "on" if aerosol else "off"))
+                  "%s" % ("BASELINE configs[3] (C360 tile / 8 GPUs) " if ncol == 97_200 and a.scheme == "lwsw" else "",
+                                         ncol, nlay, schemes, 100 * a.cloudy, "on" if aerosol else "off",
+                                         "every column lit" if ncol_sw == ncol else "RRTMG_SW on the %d lit columns (packed)" % ncol_sw))
         out = {
             "metric": "columns/sec (LW+SW, 72 layers)" if a.scheme == "lwsw" else "columns/sec", "value": value, "unit": "columns/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -639,7 +659,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
-                         "columns_per_launch": ncol / launches_per_step,
+                         "columns_per_launch": ncol_k / launches_per_step,
                          "note": "fused k-distribution + two-stream sweep is FP32/latency bound (~170 FLOP per algorithmic byte, "
                                  "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small; `traffic` (PMC) is in "
                                  "profiles/" + ("; LW and SW kernels run concurrently on two streams, so this kernel's launch duration "
