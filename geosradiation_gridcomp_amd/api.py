@@ -391,6 +391,14 @@ class Context:
             ci(int(doy)), ci(int(lcldlm)), ci(int(lcldmh)), _p(bo), self._ptr_array(G.LWD_OUT, ptr), ci(len(rg)), _p(rg),
             self._ptr_array(G.LWD_RAT_OUT, ptr)))
 
+    def lw_update_rats_dev(self, stream, ncol, lm, nrats, ptr):
+        """RATS exports of Update_Flx (GEOS_IrradGridComp.F90:4036-4120).  `ptr`: name -> device address for gridcomp.LWR_IN and
+        gridcomp.LWR_OUT (missing = export not associated)."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_lw_update_rats_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nrats),
+                                                     self._ptr_array(G.LWR_IN, ptr), self._ptr_array(G.LWR_OUT, ptr)))
+
     def sw_driver_rrtmg_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, sc, dist, isolvar, dyofyr, include_aerosols,
                             lcldlm, lcldmh, normflx=1, bndsolvar=None, indsolvar=None):
         """RRTMG branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:6113-6450)."""

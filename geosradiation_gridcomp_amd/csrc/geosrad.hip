@@ -275,6 +275,7 @@ struct geosrad_ctx {
     virtual int lw_chou_post_dev(hipStream_t st, int ncol, int lm, const void *const *in, void *const *out) = 0;
     virtual int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
                                   const void *const *in, void *const *out) = 0;
+    virtual int lw_update_rats_dev(hipStream_t st, int ncol, int lm, int nrats, const void *const *in, void *const *out) = 0;
     virtual int sw_update_export_dev(hipStream_t st, int ncol, int lm, int nbands, const void *const *in, void *const *out) = 0;
     virtual int rad_tendencies_dev(hipStream_t st, int ncol, int lm, double grav, double cp, const void *const *in,
                                    void *const *out) = 0;
@@ -1017,6 +1018,28 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (int k = 0; k < GEOSRAD_LWU_NOUT; k++) wide = wide && ((uintptr_t)out[k] & 15) == 0;
         if (wide) hipLaunchKernelGGL((k_lw_update_flx<R, VW>), dim3((unsigned)((ncol / VW + 255) / 256), lm + 1), dim3(256), 0, st, U);
         else hipLaunchKernelGGL((k_lw_update_flx<R, 1>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, U);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int lw_update_rats_dev(hipStream_t st, int ncol, int lm, int nrats, const void *const *in, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm <= 0 || nrats < 0 || nrats > GEOSRAD_RAT_NGAS) return fail(GEOSRAD_EINVAL, "bad ncol/lm/nrats");
+        if (nrats == 0) return GEOSRAD_OK;
+        for (int k = 0; k < GEOSRAD_LWR_NIN; k++)
+            if (!in[k] && !(k == GEOSRAD_LWR_DFDTS || k == GEOSRAD_LWR_DFDTS_RAT)) return fail(GEOSRAD_EINVAL, "null internal-state array");
+        if (out[GEOSRAD_LWR_DFDTS_OUT] && (!in[GEOSRAD_LWR_DFDTS] || !in[GEOSRAD_LWR_DFDTS_RAT]))
+            return fail(GEOSRAD_EINVAL, "DFDTS_<gas> requested without DFDTS / DFDTS_RAT");
+        LwRatUpd<R> U{};
+        U.ncol = ncol; U.lm = lm; U.nrats = nrats;
+        auto I = [&](int k) { return (const R *)in[k]; };
+        U.flx_int = I(GEOSRAD_LWR_FLX_INT); U.sfcem_int = I(GEOSRAD_LWR_SFCEM_INT); U.dfdts = I(GEOSRAD_LWR_DFDTS);
+        U.flx_rat = I(GEOSRAD_LWR_FLX_RAT); U.sfcem_rat = I(GEOSRAD_LWR_SFCEM_RAT); U.dfdts_rat = I(GEOSRAD_LWR_DFDTS_RAT);
+        auto O = [&](int k) { return (R *)out[k]; };
+        U.dolr = O(GEOSRAD_LWR_DOLR); U.dlws = O(GEOSRAD_LWR_DLWS); U.dflns = O(GEOSRAD_LWR_DFLNS); U.dsfcem = O(GEOSRAD_LWR_DSFCEM);
+        U.nettrap = O(GEOSRAD_LWR_NETTRAP); U.coltrap = O(GEOSRAD_LWR_COLTRAP); U.flx = O(GEOSRAD_LWR_FLX); U.dfdts_out = O(GEOSRAD_LWR_DFDTS_OUT);
+        hipLaunchKernelGGL((k_lw_update_rats<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1, nrats), dim3(256), 0, st, U);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -2181,6 +2204,12 @@ int geosrad_lw_update_flx_dev(geosrad_ctx *c, void *stream, int ncol, int lm, in
 {
     if (!c || !in || !out) return GEOSRAD_EINVAL;
     return c->lw_update_flx_dev((hipStream_t)stream, ncol, lm, rrtmg, lev_mid_high, lev_low_mid, undef, in, out);
+}
+
+int geosrad_lw_update_rats_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nrats, const void *const *in, void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->lw_update_rats_dev((hipStream_t)stream, ncol, lm, nrats, in, out);
 }
 
 int geosrad_sw_update_export_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nbands, const void *const *in, void *const *out)

@@ -208,6 +208,41 @@ template <typename R> __global__ void __launch_bounds__(256) k_lwd_rat_post(LwdR
     if (K == lm && P.sfcem_rat) P.sfcem_rat[(size_t)r * n + ij] = P.uflx[plane + ij] - P.dflx[plane + ij] * ((R)1.0 - P.emis[ij]);
 }
 
+// RATS exports of Update_Flx (IRR:4036-4120): one thread per (column, level K = 0..LM, gas)
+template <typename R> struct LwRatUpd {
+    int ncol, lm, nrats;
+    const R *flx_int, *sfcem_int, *dfdts;                 // (ncol,0:LM), (ncol), (ncol,0:LM)
+    const R *flx_rat, *sfcem_rat, *dfdts_rat;             // (ncol,0:LM,nrats), (ncol,nrats), (ncol,0:LM,nrats)
+    R *dolr, *dlws, *dflns, *dsfcem, *nettrap;            // (ncol,nrats)
+    R *coltrap;                                           // (ncol,LM,nrats)
+    R *flx, *dfdts_out;                                   // (ncol,0:LM,nrats)
+};
+template <typename R> __global__ void __launch_bounds__(256) k_lw_update_rats(LwRatUpd<R> P)
+{
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const int n = P.ncol, lm = P.lm, K = blockIdx.y, r = blockIdx.z;
+    const size_t pl = (size_t)(lm + 1) * n * r, o = (size_t)K * n + ij;
+    const R f = P.flx_int[o], fr = P.flx_rat[pl + o];
+    if (P.flx) P.flx[pl + o] = f - fr;
+    if (P.dfdts_out) P.dfdts_out[pl + o] = P.dfdts[o] - P.dfdts_rat[pl + o];
+    if (K >= 1 && P.coltrap) {
+        R t = f - P.flx_int[o - n];
+        t = t - (fr - P.flx_rat[pl + o - n]);
+        P.coltrap[(size_t)lm * n * r + (size_t)(K - 1) * n + ij] = t;
+    }
+    if (K == lm) {
+        const size_t q = (size_t)r * n + ij;
+        const R f0 = P.flx_int[ij], fr0 = P.flx_rat[pl + ij], se = P.sfcem_int[ij], ser = P.sfcem_rat[q];
+        if (P.dolr) { const R a = -(fr0); P.dolr[q] = (-(f0)) - a; }
+        if (P.dlws) P.dlws[q] = (f + se) - (fr + ser);
+        if (P.dflns) P.dflns[q] = f - fr;
+        if (P.dsfcem) P.dsfcem[q] = se - ser;
+        if (P.nettrap) { R t = f - f0; t = t - (fr - fr0); P.nettrap[q] = t; }
+    }
+}
+
 // Chou-Suarez branch of LW_Driver: `irrad` takes the GEOS fields as they are (no flip, no unit conversion) and fills the INTERNAL
 // fluxes itself; what the driver adds (IRR:2101-2108, :3601-3616): the derivatives irrad does not provide, the net fluxes of the four
 // flavours, the sign of SFCEM, TS_INT.

@@ -8,7 +8,7 @@ module geosrad_gridcomp
    use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
    implicit none
    private
-   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
    ! ---- GEOSRAD_LWD_* ----
@@ -20,6 +20,10 @@ module geosrad_gridcomp
    integer, parameter, public :: LWD_FLXU_INT = 1, LWD_FLXD_INT = 2, LWD_FLCU_INT = 3, LWD_FLCD_INT = 4, LWD_DFDTS = 5, LWD_DFDTSC = 6, &
       LWD_DFDTSNA = 7, LWD_DFDTSCNA = 8, LWD_FLX_INT = 9, LWD_FLC_INT = 10, LWD_SFCEM_INT = 11, LWD_TS_INT = 12, LWD_CLDTTLW = 13, &
       LWD_CLDHILW = 14, LWD_CLDMDLW = 15, LWD_CLDLOLW = 16, LWD_OLRB = 17, LWD_DOLRB = 18, LWD_NOUT = 18
+   ! ---- GEOSRAD_LWR_* (RATS exports of Update_Flx) ----
+   integer, parameter, public :: LWR_FLX_INT = 1, LWR_SFCEM_INT = 2, LWR_DFDTS = 3, LWR_FLX_RAT = 4, LWR_SFCEM_RAT = 5, LWR_DFDTS_RAT = 6, LWR_NIN = 6
+   integer, parameter, public :: LWR_DOLR = 1, LWR_DLWS = 2, LWR_DFLNS = 3, LWR_DSFCEM = 4, LWR_NETTRAP = 5, LWR_COLTRAP = 6, LWR_FLX = 7, &
+      LWR_DFDTS_OUT = 8, LWR_NOUT = 8
    integer, parameter, public :: LWD_FLXU_RAT = 1, LWD_FLXD_RAT = 2, LWD_FLX_RAT = 3, LWD_DFDTS_RAT = 4, LWD_SFCEM_RAT = 5, LWD_NRATOUT = 5
    ! ---- GEOSRAD_LWC_* ----
    integer, parameter, public :: LWC_FLXU_INT = 1, LWC_FLCU_INT = 2, LWC_FLAU_INT = 3, LWC_FLXAU_INT = 4, LWC_FLXD_INT = 5, LWC_FLCD_INT = 6, &
@@ -77,6 +81,12 @@ module geosrad_gridcomp
          type(c_ptr), intent(in) :: fin(*), fout(*), rat_out(*)
          real(c_double), intent(in) :: consts(*)
          integer(c_int), intent(in) :: band_output(*), rat_gas(*)
+      end function
+      integer(c_int) function geosrad_lw_update_rats_dev(ctx, stream, ncol, lm, nrats, fin, fout) bind(C, name='geosrad_lw_update_rats_dev')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm, nrats
+         type(c_ptr), intent(in) :: fin(*), fout(*)
       end function
       integer(c_int) function geosrad_sw_driver_rrtmg_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflgsw, liqflgsw, sc, dist, isolvar, &
             dyofyr, include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, fout) bind(C, name='geosrad_sw_driver_rrtmg_dev')
@@ -215,6 +225,15 @@ contains
       if (geosrad_lw_driver_rrtmg_rats_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, &
             consts, int(iceflglw,c_int), int(liqflglw,c_int), int(doy,c_int), int(lcldlm,c_int), int(lcldmh,c_int), bo, fout, &
             int(nrats,c_int), gas, rat_out) /= 0) call geosrad_fail('LW_Driver (RRTMG, RATS)')
+   end subroutine
+
+   ! RATS exports of Update_Flx (GEOS_IrradGridComp.F90:4036-4120): fout(LWR_DOLR) = device array (IM,JM,nRATS) whose slice n is the export
+   ! 'dOLR_'//nameRATS(n), ... ; c_null_ptr = not associated
+   subroutine lw_update_rats(ncol, lm, nrats, fin, fout)
+      integer, intent(in) :: ncol, lm, nrats
+      type(c_ptr), intent(in) :: fin(LWR_NIN), fout(LWR_NOUT)
+      if (geosrad_lw_update_rats_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nrats,c_int), fin, fout) /= 0) &
+         call geosrad_fail('Update_Flx (RATS)')
    end subroutine
 
    ! RRTMG branch of SORADCORE (GEOS_SolarGridComp.F90:6113-6450) on the packed daytime columns

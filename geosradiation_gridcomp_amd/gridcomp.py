@@ -17,6 +17,9 @@ LWD_OUT_3D = LWD_OUT[:10]
 RAT_GAS = ["H2O", "O3", "CO2", "CH4", "N2O", "CFC11", "CFC12", "HCFC22"]
 RAT_VMR = dict(H2O="h2ovmr", O3="o3vmr", CO2="co2vmr", CH4="ch4vmr", N2O="n2ovmr", CFC11="cfc11vmr", CFC12="cfc12vmr", HCFC22="cfc22vmr")
 LWD_RAT_OUT = ["FLXU_RAT", "FLXD_RAT", "FLX_RAT", "DFDTS_RAT", "SFCEM_RAT"]
+# RATS exports of Update_Flx (IRR:4036-4120), GEOSRAD_LWR_*: per listed gas "dOLR_<gas>" ...; arrays with the gas slowest
+LWR_IN = ["FLX_INT", "SFCEM_INT", "DFDTS", "FLX_RAT", "SFCEM_RAT", "DFDTS_RAT"]
+LWR_OUT = ["dOLR", "dLWS", "dFLNS", "dSFCEM", "NETTRAP", "COLTRAP", "FLX", "DFDTS_OUT"]
 
 LWC_IN = ["FLXU_INT", "FLCU_INT", "FLAU_INT", "FLXAU_INT", "FLXD_INT", "FLCD_INT", "FLAD_INT", "FLXAD_INT", "DFDTS", "TS"]
 LWC_OUT = ["SFCEM_INT", "FLX_INT", "FLXA_INT", "FLC_INT", "FLA_INT", "DFDTSC", "DFDTSNA", "DFDTSCNA", "TS_INT"]

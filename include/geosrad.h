@@ -355,6 +355,15 @@ enum { GEOSRAD_LWU_FLX, GEOSRAD_LWU_FLXA, GEOSRAD_LWU_FLC, GEOSRAD_LWU_FLA, GEOS
 int geosrad_lw_update_flx_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid,
                               double undef, const void *const *in, void *const *out);
 
+/* geosrad_lw_update_rats_dev: the RATS exports of Update_Flx (GEOS_IrradGridComp.F90:4036-4120): for every listed gas n, from the
+ * INTERNAL state with and without the gas: dOLR_n, dLWS_n, dFLNS_n, dSFCEM_n, NETTRAP_n (ncol,nrats); COLTRAP_n (ncol,LM,nrats);
+ * FLX_n, DFDTS_n (ncol,0:LM,nrats).  Gas slowest, like the (IM,JM,0:LM,nRATS) internals; any output may be NULL. */
+enum { GEOSRAD_LWR_FLX_INT /*(ncol,0:LM)*/, GEOSRAD_LWR_SFCEM_INT /*(ncol)*/, GEOSRAD_LWR_DFDTS, GEOSRAD_LWR_FLX_RAT /*(ncol,0:LM,nrats)*/,
+       GEOSRAD_LWR_SFCEM_RAT /*(ncol,nrats)*/, GEOSRAD_LWR_DFDTS_RAT, GEOSRAD_LWR_NIN };
+enum { GEOSRAD_LWR_DOLR, GEOSRAD_LWR_DLWS, GEOSRAD_LWR_DFLNS, GEOSRAD_LWR_DSFCEM, GEOSRAD_LWR_NETTRAP, GEOSRAD_LWR_COLTRAP, GEOSRAD_LWR_FLX,
+       GEOSRAD_LWR_DFDTS_OUT, GEOSRAD_LWR_NOUT };
+int geosrad_lw_update_rats_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nrats, const void *const *in, void *const *out);
+
 /* geosrad_sw_update_export_dev: the flux part of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7540-7579): exports = normalised
  * internals x SLR (3-D net / up / down, per-band, TOA and surface). */
 enum { GEOSRAD_SWU_SLR, GEOSRAD_SWU_FSWN, GEOSRAD_SWU_FSCN, GEOSRAD_SWU_FSWNAN, GEOSRAD_SWU_FSCNAN, GEOSRAD_SWU_FSWUN,

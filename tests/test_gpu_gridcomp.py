@@ -371,3 +371,35 @@ def test_lw_driver_rats_internals(gpu_ctx, rk):
         np.testing.assert_array_equal(tout["SFCEM_RAT"][r].cpu().numpy(), sf.astype(dt), err_msg=gas)
         assert (tout["FLX_RAT"][r][0] != tout["FLX_INT"][0]).any()
     ctx.set_inhomogeneity(0)
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_update_flx_rats_exports(gpu_ctx, rk):
+    """RATS exports of Update_Flx (IRR:4036-4120) against the reference's statements evaluated with numpy in the same precision, operation
+    by operation (numpy does not fuse): bitwise; exports not associated are left alone."""
+    import torch
+    ctx = gpu_ctx[rk]; dt = ctx.dtype
+    n, lm, nr = 300, 72, 3
+    rng = np.random.default_rng(11)
+    st = {"FLX_INT": rng.uniform(-400, 100, (lm + 1, n)), "SFCEM_INT": rng.uniform(300, 450, n), "DFDTS": rng.uniform(-6, 0, (lm + 1, n)),
+          "FLX_RAT": rng.uniform(-400, 100, (nr, lm + 1, n)), "SFCEM_RAT": rng.uniform(300, 450, (nr, n)), "DFDTS_RAT": rng.uniform(-6, 0, (nr, lm + 1, n))}
+    st = {k: np.ascontiguousarray(v, dtype=dt) for k, v in st.items()}
+    t = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    shp = {"COLTRAP": (nr, lm, n), "FLX": (nr, lm + 1, n), "DFDTS_OUT": (nr, lm + 1, n)}
+    want = [k for k in G.LWR_OUT if k != "dFLNS"]              # dFLNS_<gas> not associated
+    for k in want:
+        t[k] = torch.full(shp.get(k, (nr, n)), 7.0, dtype=t["FLX_INT"].dtype, device="cuda")
+    ctx.lw_update_rats_dev(_stream(), n, lm, nr, {k: v.data_ptr() for k, v in t.items()})
+    ctx.check(_stream())
+    F, FR, S, SR = st["FLX_INT"], st["FLX_RAT"], st["SFCEM_INT"], st["SFCEM_RAT"]
+    ref = {}
+    a = -(FR[:, 0]); ref["dOLR"] = (-(F[0])) - a
+    ref["dLWS"] = (F[lm] + S) - (FR[:, lm] + SR)
+    ref["dSFCEM"] = S - SR
+    x = F[lm] - F[0]; ref["NETTRAP"] = x - (FR[:, lm] - FR[:, 0])
+    y = F[1:] - F[:-1]; ref["COLTRAP"] = y[None] - (FR[:, 1:] - FR[:, :-1])
+    ref["FLX"] = F[None] - FR
+    ref["DFDTS_OUT"] = st["DFDTS"][None] - st["DFDTS_RAT"]
+    for k in want:
+        assert ref[k].dtype == dt
+        np.testing.assert_array_equal(t[k].cpu().numpy(), ref[k], err_msg=k)
