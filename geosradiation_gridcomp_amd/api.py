@@ -399,6 +399,16 @@ class Context:
         self._chk(self.L.geosrad_lw_update_rats_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ci(nrats),
                                                      self._ptr_array(G.LWR_IN, ptr), self._ptr_array(G.LWR_OUT, ptr)))
 
+    def lw_update_bands_dev(self, stream, ncol, band_output, undef, ptr):
+        """Band OLR / brightness-temperature exports of Update_Flx (GEOS_IrradGridComp.F90:3993-4021).  `ptr`: TSINST, TS_INT, OLRB,
+        DOLRB (internals, (ncol,16) C order) and the exports OLRB_EXP, TBRB_EXP ((16,ncol) C order; missing = not associated)."""
+        from . import gridcomp as G
+        bo = np.ascontiguousarray(band_output, dtype=np.int32)
+        w1 = (ctypes.c_double * 16)(*G.LW_WAVENUM1); w2 = (ctypes.c_double * 16)(*G.LW_WAVENUM2)
+        v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
+        self._chk(self.L.geosrad_lw_update_bands_dev(self.h, ctypes.c_void_p(stream), ctypes.c_int(ncol), _p(bo), w1, w2, ctypes.c_double(undef),
+                                                      v("TSINST"), v("TS_INT"), v("OLRB"), v("DOLRB"), v("OLRB_EXP"), v("TBRB_EXP")))
+
     def sw_driver_rrtmg_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, sc, dist, isolvar, dyofyr, include_aerosols,
                             lcldlm, lcldmh, normflx=1, bndsolvar=None, indsolvar=None):
         """RRTMG branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:6113-6450)."""

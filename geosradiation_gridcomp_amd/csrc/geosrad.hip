@@ -276,6 +276,9 @@ struct geosrad_ctx {
     virtual int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
                                   const void *const *in, void *const *out) = 0;
     virtual int lw_update_rats_dev(hipStream_t st, int ncol, int lm, int nrats, const void *const *in, void *const *out) = 0;
+    virtual int lw_update_bands_dev(hipStream_t st, int ncol, const int32_t *band_output, const double *wn1, const double *wn2, double undef,
+                                    const void *tsinst, const void *ts_int, const void *olrb_int, const void *dolrb_int, void *olrb_exp,
+                                    void *tbrb_exp) = 0;
     virtual int sw_update_export_dev(hipStream_t st, int ncol, int lm, int nbands, const void *const *in, void *const *out) = 0;
     virtual int rad_tendencies_dev(hipStream_t st, int ncol, int lm, double grav, double cp, const void *const *in,
                                    void *const *out) = 0;
@@ -348,6 +351,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     // workspace
     char *d_ws = nullptr; size_t ws_bytes = 0; int ws_ncol = 0, ws_nlay = 0;
     char *d_zero = nullptr; size_t zero_bytes = 0;      // all-zero (nlay, ncol) plane of the RATS passes
+    int *d_bandflags = nullptr;                         // Update_Flx band exports: "band has a non-zero flux somewhere"
     uint32_t *d_err = nullptr;
     // staging for host-pointer entry points
     char *d_io = nullptr; size_t io_bytes = 0;
@@ -360,6 +364,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_T) (void)hipFree(d_T);
         if (d_ws) (void)hipFree(d_ws);
         if (d_zero) (void)hipFree(d_zero);
+        if (d_bandflags) (void)hipFree(d_bandflags);
         for (auto &pe : plans) if (pe.second.d_seg) (void)hipFree(pe.second.d_seg);
         if (d_tab_sw) (void)hipFree(d_tab_sw);
         if (d_tab_ch) (void)hipFree(d_tab_ch);
@@ -1040,6 +1045,31 @@ template <typename R> struct Ctx : geosrad_ctx {
         U.dolr = O(GEOSRAD_LWR_DOLR); U.dlws = O(GEOSRAD_LWR_DLWS); U.dflns = O(GEOSRAD_LWR_DFLNS); U.dsfcem = O(GEOSRAD_LWR_DSFCEM);
         U.nettrap = O(GEOSRAD_LWR_NETTRAP); U.coltrap = O(GEOSRAD_LWR_COLTRAP); U.flx = O(GEOSRAD_LWR_FLX); U.dfdts_out = O(GEOSRAD_LWR_DFDTS_OUT);
         hipLaunchKernelGGL((k_lw_update_rats<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1, nrats), dim3(256), 0, st, U);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int lw_update_bands_dev(hipStream_t st, int ncol, const int32_t *band_output, const double *wn1, const double *wn2, double undef,
+                            const void *tsinst, const void *ts_int, const void *olrb_int, const void *dolrb_int, void *olrb_exp,
+                            void *tbrb_exp) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || !band_output || !wn1 || !wn2 || !tsinst || !ts_int || !olrb_int || !dolrb_int) return fail(GEOSRAD_EINVAL, "bad arguments");
+        if (!olrb_exp && !tbrb_exp) return GEOSRAD_OK;
+        if (!d_bandflags) HIPCHK(hipMalloc((void **)&d_bandflags, 16 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(d_bandflags, 0, 16 * sizeof(int), st));
+        LwBandUpd<R> U{};
+        U.ncol = ncol; U.undef = (R)undef;
+        for (int b = 0; b < 16; b++) {
+            U.band_output[b] = band_output[b] != 0;
+            U.wn1[b] = (R)wn1[b] * (R)100.; U.wn2[b] = (R)wn2[b] * (R)100.;      // wavenum1(ibnd)*100. [m-1] (IRR:4016)
+            if (U.band_output[b] && !(wn2[b] > wn1[b] && wn1[b] + wn2[b] > 0)) return fail(GEOSRAD_EINVAL, "band limits must satisfy 0 <= wavenum1 < wavenum2");
+        }
+        U.tsinst = (const R *)tsinst; U.ts_int = (const R *)ts_int; U.olrb_int = (const R *)olrb_int; U.dolrb_int = (const R *)dolrb_int;
+        U.olrb_exp = (R *)olrb_exp; U.tbrb_exp = (R *)tbrb_exp; U.nonzero = d_bandflags;
+        const dim3 grid((unsigned)((ncol + 255) / 256), 16);
+        hipLaunchKernelGGL((k_lw_update_bands<R, 0>), grid, dim3(256), 0, st, U);
+        if (tbrb_exp) hipLaunchKernelGGL((k_lw_update_bands<R, 1>), grid, dim3(256), 0, st, U);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -2210,6 +2240,15 @@ int geosrad_lw_update_rats_dev(geosrad_ctx *c, void *stream, int ncol, int lm, i
 {
     if (!c || !in || !out) return GEOSRAD_EINVAL;
     return c->lw_update_rats_dev((hipStream_t)stream, ncol, lm, nrats, in, out);
+}
+
+int geosrad_lw_update_bands_dev(geosrad_ctx *c, void *stream, int ncol, const int32_t *band_output, const double *wavenum1,
+                                const double *wavenum2, double undef, const void *tsinst, const void *ts_int, const void *olrb_int,
+                                const void *dolrb_int, void *olrb_exp, void *tbrb_exp)
+{
+    if (!c) return GEOSRAD_EINVAL;
+    return c->lw_update_bands_dev((hipStream_t)stream, ncol, band_output, wavenum1, wavenum2, undef, tsinst, ts_int, olrb_int, dolrb_int,
+                                  olrb_exp, tbrb_exp);
 }
 
 int geosrad_sw_update_export_dev(geosrad_ctx *c, void *stream, int ncol, int lm, int nbands, const void *const *in, void *const *out)

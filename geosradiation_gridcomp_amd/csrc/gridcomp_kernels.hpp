@@ -243,6 +243,42 @@ template <typename R> __global__ void __launch_bounds__(256) k_lw_update_rats(Lw
     }
 }
 
+// band OLR and brightness temperature of Update_Flx (IRR:3993-4021, Tbr_from_band_flux :4132-4186, invert_Planck_for_T :4188-4208):
+// one thread per (column, band).  PASS 0 writes the updated band flux and records whether any column of the band is non-zero
+// (the reference tests `all(Fband_ == 0.0)` on the whole field); PASS 1 inverts the Planck function.
+template <typename R> struct LwBandUpd {
+    int ncol;
+    int band_output[16];
+    R wn1[16], wn2[16];                 // [m-1], in the caller's real kind like wavenum1(ibnd)*100.
+    R undef;
+    const R *tsinst, *ts_int, *olrb_int, *dolrb_int;      // (ncol), (ncol), (16,ncol), (16,ncol)
+    R *olrb_exp, *tbrb_exp;             // (ncol,16); either may be null
+    int *nonzero;                       // [16]
+};
+template <typename R, int PASS> __global__ void __launch_bounds__(256) k_lw_update_bands(LwBandUpd<R> P)
+{
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x, ib = blockIdx.y;
+    if (ij >= P.ncol || !P.band_output[ib]) return;
+    const R delt = P.tsinst[ij] - P.ts_int[ij];
+    const R f = P.olrb_int[(size_t)ij * 16 + ib] + P.dolrb_int[(size_t)ij * 16 + ib] * delt;
+    const size_t o = (size_t)ib * P.ncol + ij;
+    if (PASS == 0) {
+        if (P.olrb_exp) P.olrb_exp[o] = f;
+        if (f != (R)0) P.nonzero[ib] = 1;           // every writer writes 1
+    } else {
+        if (!P.nonzero[ib]) { P.tbrb_exp[o] = P.undef; return; }
+        const double h = 6.626070040e-34, c = 2.99792458e8, kB = 1.38064852e-23, pi = 3.14159265358979323846;
+        const double alT = h * c / kB, bigC = 2.0 * h * (c * c);
+        const double Fband = (double)f;
+        const double Bmean = Fband / (pi * (double)(P.wn2[ib] - P.wn1[ib]));
+        const R wnMid = (R)((double)(P.wn1[ib] + P.wn2[ib]) / 2.0);
+        const R wn3 = (wnMid * wnMid) * wnMid;       // wn**3 in the real kind of wn
+        const double T = alT * (double)wnMid / log(bigC * (double)wn3 / Bmean + 1.0);
+        P.tbrb_exp[o] = (R)T;
+    }
+}
+
 // Chou-Suarez branch of LW_Driver: `irrad` takes the GEOS fields as they are (no flip, no unit conversion) and fills the INTERNAL
 // fluxes itself; what the driver adds (IRR:2101-2108, :3601-3616): the derivatives irrad does not provide, the net fluxes of the four
 // flavours, the sign of SFCEM, TS_INT.

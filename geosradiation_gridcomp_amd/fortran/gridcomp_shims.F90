@@ -8,7 +8,7 @@ module geosrad_gridcomp
    use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
    implicit none
    private
-   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
    ! ---- GEOSRAD_LWD_* ----
@@ -87,6 +87,15 @@ module geosrad_gridcomp
          type(c_ptr), value :: ctx, stream
          integer(c_int), value :: ncol, lm, nrats
          type(c_ptr), intent(in) :: fin(*), fout(*)
+      end function
+      integer(c_int) function geosrad_lw_update_bands_dev(ctx, stream, ncol, band_output, wavenum1, wavenum2, undef, tsinst, ts_int, olrb_int, &
+            dolrb_int, olrb_exp, tbrb_exp) bind(C, name='geosrad_lw_update_bands_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream, tsinst, ts_int, olrb_int, dolrb_int, olrb_exp, tbrb_exp
+         integer(c_int), value :: ncol
+         integer(c_int), intent(in) :: band_output(*)
+         real(c_double), intent(in) :: wavenum1(*), wavenum2(*)
+         real(c_double), value :: undef
       end function
       integer(c_int) function geosrad_sw_driver_rrtmg_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflgsw, liqflgsw, sc, dist, isolvar, &
             dyofyr, include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, fout) bind(C, name='geosrad_sw_driver_rrtmg_dev')
@@ -234,6 +243,19 @@ contains
       type(c_ptr), intent(in) :: fin(LWR_NIN), fout(LWR_NOUT)
       if (geosrad_lw_update_rats_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nrats,c_int), fin, fout) /= 0) &
          call geosrad_fail('Update_Flx (RATS)')
+   end subroutine
+
+   ! band OLR / brightness temperature exports of Update_Flx (GEOS_IrradGridComp.F90:3993-4021): wavenum1 / wavenum2 = rrlw_wvn's [cm-1];
+   ! olrb_int / dolrb_int = the driver's OLRB / DOLRB (16,IM*JM); olrb_exp / tbrb_exp (IM,JM,16) device arrays or c_null_ptr
+   subroutine lw_update_bands(ncol, band_output, wavenum1, wavenum2, undef, tsinst, ts_int, olrb_int, dolrb_int, olrb_exp, tbrb_exp)
+      integer, intent(in) :: ncol
+      logical, intent(in) :: band_output(16)
+      real, intent(in) :: wavenum1(16), wavenum2(16), undef
+      type(c_ptr), intent(in) :: tsinst, ts_int, olrb_int, dolrb_int, olrb_exp, tbrb_exp
+      integer(c_int) :: bo(16)
+      bo = merge(1_c_int, 0_c_int, band_output)
+      if (geosrad_lw_update_bands_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), bo, real(wavenum1,c_double), real(wavenum2,c_double), &
+            real(undef,c_double), tsinst, ts_int, olrb_int, dolrb_int, olrb_exp, tbrb_exp) /= 0) call geosrad_fail('Update_Flx (band OLR)')
    end subroutine
 
    ! RRTMG branch of SORADCORE (GEOS_SolarGridComp.F90:6113-6450) on the packed daytime columns

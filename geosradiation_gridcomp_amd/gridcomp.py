@@ -68,3 +68,7 @@ def swd_consts(**over):
              GRAV=MAPL["GRAV"], UNDEF=MAPL["UNDEF"])
     d.update(over)
     return [float(d[k]) for k in SWD_CONST]
+
+# rrlw_wvn: band limits of RRTMG_LW [cm-1] (LW/modules/rrlw_wvn.F90, set in rrtmg_lw_init.F90)
+LW_WAVENUM1 = [10., 350., 500., 630., 700., 820., 980., 1080., 1180., 1390., 1480., 1800., 2080., 2250., 2380., 2600.]
+LW_WAVENUM2 = [350., 500., 630., 700., 820., 980., 1080., 1180., 1390., 1480., 1800., 2080., 2250., 2380., 2600., 3250.]

@@ -364,6 +364,16 @@ enum { GEOSRAD_LWR_DOLR, GEOSRAD_LWR_DLWS, GEOSRAD_LWR_DFLNS, GEOSRAD_LWR_DSFCEM
        GEOSRAD_LWR_DFDTS_OUT, GEOSRAD_LWR_NOUT };
 int geosrad_lw_update_rats_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nrats, const void *const *in, void *const *out);
 
+/* geosrad_lw_update_bands_dev: the band OLR / brightness-temperature exports of Update_Flx (GEOS_IrradGridComp.F90:3993-4021 with
+ * Tbr_from_band_flux / invert_Planck_for_T, :4132-4208) for the bands selected by band_output[16]: OLRBbbRG = OLRB_int + DOLRB_int *
+ * (TSINST - TS_INT); TBRBbbRG = narrow-band inversion of the Planck function in double precision, MAPL_UNDEF for a band whose updated
+ * flux is zero everywhere (before the first full calculation).  olrb_int / dolrb_int: (16,ncol) as the driver returns them
+ * (GEOSRAD_LWD_OLRB / _DOLRB); olrb_exp / tbrb_exp: (ncol,16), band bb's export is the contiguous slice bb, either may be NULL;
+ * wavenum1 / wavenum2: rrlw_wvn's band limits in cm-1 (host). */
+int geosrad_lw_update_bands_dev(geosrad_ctx *ctx, void *stream, int ncol, const int32_t *band_output, const double *wavenum1,
+                                const double *wavenum2, double undef, const void *tsinst, const void *ts_int, const void *olrb_int,
+                                const void *dolrb_int, void *olrb_exp, void *tbrb_exp);
+
 /* geosrad_sw_update_export_dev: the flux part of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7540-7579): exports = normalised
  * internals x SLR (3-D net / up / down, per-band, TOA and surface). */
 enum { GEOSRAD_SWU_SLR, GEOSRAD_SWU_FSWN, GEOSRAD_SWU_FSCN, GEOSRAD_SWU_FSWNAN, GEOSRAD_SWU_FSCNAN, GEOSRAD_SWU_FSWUN,

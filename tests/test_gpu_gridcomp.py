@@ -403,3 +403,46 @@ def test_update_flx_rats_exports(gpu_ctx, rk):
     for k in want:
         assert ref[k].dtype == dt
         np.testing.assert_array_equal(t[k].cpu().numpy(), ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_update_flx_band_olr_and_brightness_temperature(gpu_ctx, rk):
+    """OLRBbbRG / TBRBbbRG of Update_Flx (IRR:3993-4021, Tbr_from_band_flux :4132-4208) against the reference's statements in numpy (same
+    kinds, same order): the band flux bitwise; the brightness temperature - a double-precision log - to 1 ulp of the export's kind;
+    a band whose flux is zero everywhere gives MAPL_UNDEF; bands not selected are not touched."""
+    import torch
+    ctx = gpu_ctx[rk]; dt = ctx.dtype
+    n = 1000
+    rng = np.random.default_rng(5)
+    olrb = rng.uniform(0.5, 40.0, (n, 16)).astype(dt); dolrb = rng.uniform(0.0, 0.3, (n, 16)).astype(dt)
+    olrb[:, 9] = 0; dolrb[:, 9] = 0                       # band 10: before the first full calculation
+    ts = rng.uniform(270, 300, n).astype(dt); tsinst = (ts + rng.uniform(-3, 3, n)).astype(dt)
+    bo = np.zeros(16, dtype=np.int32); bo[[0, 5, 9, 15]] = 1
+    t = {"TSINST": tsinst, "TS_INT": ts, "OLRB": olrb, "DOLRB": dolrb}
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in t.items()}
+    t["OLRB_EXP"] = torch.full((16, n), -5.0, dtype=t["OLRB"].dtype, device="cuda")
+    t["TBRB_EXP"] = torch.full((16, n), -5.0, dtype=t["OLRB"].dtype, device="cuda")
+    undef = G.MAPL["UNDEF"]
+    ctx.lw_update_bands_dev(_stream(), n, bo, undef, {k: v.data_ptr() for k, v in t.items()})
+    ctx.check(_stream())
+    got_f, got_t = t["OLRB_EXP"].cpu().numpy(), t["TBRB_EXP"].cpu().numpy()
+    h, c, kB, pi = 6.626070040e-34, 2.99792458e8, 1.38064852e-23, 3.14159265358979323846
+    alT, bigC = h * c / kB, 2.0 * h * (c * c)
+    delt = tsinst - ts
+    for ib in range(16):
+        if not bo[ib]:
+            assert (got_f[ib] == -5.0).all() and (got_t[ib] == -5.0).all()
+            continue
+        f = olrb[:, ib] + dolrb[:, ib] * delt
+        assert f.dtype == dt
+        np.testing.assert_array_equal(got_f[ib], f)
+        if ib == 9:
+            assert (got_t[ib] == dt(undef)).all()
+            continue
+        wn1, wn2 = dt(G.LW_WAVENUM1[ib]) * dt(100.), dt(G.LW_WAVENUM2[ib]) * dt(100.)
+        bmean = f.astype(np.float64) / (pi * np.float64(wn2 - wn1))
+        wnmid = dt(np.float64(wn1 + wn2) / 2.0)
+        wn3 = (wnmid * wnmid) * wnmid
+        tbr = (alT * np.float64(wnmid) / np.log(bigC * np.float64(wn3) / bmean + 1.0)).astype(dt)
+        np.testing.assert_allclose(got_t[ib], tbr, rtol=float(np.finfo(dt).eps), atol=0)
+        assert (tbr > 20).all() and (tbr < 2000).all() and tbr.std() > 1
