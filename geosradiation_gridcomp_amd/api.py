@@ -409,6 +409,14 @@ class Context:
         self._chk(self.L.geosrad_lw_update_bands_dev(self.h, ctypes.c_void_p(stream), ctypes.c_int(ncol), _p(bo), w1, w2, ctypes.c_double(undef),
                                                       v("TSINST"), v("TS_INT"), v("OLRB"), v("DOLRB"), v("OLRB_EXP"), v("TBRB_EXP")))
 
+    def sw_update_surface_dev(self, stream, ncol, lm, undef, ptr):
+        """2-D block of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7403-7533): `ptr` name -> device address for gridcomp.SWS_IN / SWS_OUT
+        (the albedo exports are named ALBVF_X ...; missing = not associated)."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        self._chk(self.L.geosrad_sw_update_surface_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), ctypes.c_double(undef),
+                                                        self._ptr_array(G.SWS_IN, ptr), self._ptr_array(G.SWS_OUT, ptr)))
+
     def sw_driver_rrtmg_dev(self, stream, ncol, lm, nb_aer, ptr, consts, iceflg, liqflg, sc, dist, isolvar, dyofyr, include_aerosols,
                             lcldlm, lcldmh, normflx=1, bndsolvar=None, indsolvar=None):
         """RRTMG branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:6113-6450)."""

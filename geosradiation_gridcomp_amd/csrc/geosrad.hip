@@ -280,6 +280,7 @@ struct geosrad_ctx {
                                     const void *tsinst, const void *ts_int, const void *olrb_int, const void *dolrb_int, void *olrb_exp,
                                     void *tbrb_exp) = 0;
     virtual int sw_update_export_dev(hipStream_t st, int ncol, int lm, int nbands, const void *const *in, void *const *out) = 0;
+    virtual int sw_update_surface_dev(hipStream_t st, int ncol, int lm, double undef, const void *const *in, void *const *out) = 0;
     virtual int rad_tendencies_dev(hipStream_t st, int ncol, int lm, double grav, double cp, const void *const *in,
                                    void *const *out) = 0;
     virtual int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
@@ -1103,6 +1104,37 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (int k = 0; k < GEOSRAD_SWU_NOUT; k++) wide = wide && ((uintptr_t)out[k] & 15) == 0;
         if (wide) hipLaunchKernelGGL((k_sw_update_export<R, VW>), dim3((unsigned)((ncol / VW + 255) / 256), lm + 1 + nbands), dim3(256), 0, st, U);
         else hipLaunchKernelGGL((k_sw_update_export<R, 1>), dim3((unsigned)((ncol + 255) / 256), lm + 1 + nbands), dim3(256), 0, st, U);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    int sw_update_surface_dev(hipStream_t st, int ncol, int lm, double undef, const void *const *in, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/lm");
+        for (int k = 0; k <= GEOSRAD_SWS_FSWN; k++) {
+            const bool alb_imp = k >= GEOSRAD_SWS_ALBVF && k <= GEOSRAD_SWS_ALBNR;
+            if (!in[k] && !(alb_imp && !out[GEOSRAD_SWS_ALBVF_X + (k - GEOSRAD_SWS_ALBVF)]) &&
+                !(k == GEOSRAD_SWS_ZTH && !out[GEOSRAD_SWS_DRNUVR] && !out[GEOSRAD_SWS_DRNPAR] && !out[GEOSRAD_SWS_DRNNIR]))
+                return fail(GEOSRAD_EINVAL, "null input field");
+        }
+        if ((!in[GEOSRAD_SWS_FSCN] && (out[GEOSRAD_SWS_SLRSFC] || out[GEOSRAD_SWS_SLRSUFC])) ||
+            (!in[GEOSRAD_SWS_FSWNAN] && (out[GEOSRAD_SWS_SLRSFNA] || out[GEOSRAD_SWS_SLRSUFNA])) ||
+            (!in[GEOSRAD_SWS_FSCNAN] && (out[GEOSRAD_SWS_SLRSFCNA] || out[GEOSRAD_SWS_SLRSUFCNA])))
+            return fail(GEOSRAD_EINVAL, "a requested surface export needs an internal flux that is null");
+        SwSfc<R> U{};
+        U.ncol = ncol; U.lm = lm; U.undef = (R)undef;
+        auto I = [&](int k) { return (const R *)in[k]; };
+        auto O = [&](int k) { return (R *)out[k]; };
+        U.slr = I(GEOSRAD_SWS_SLR); U.zth = I(GEOSRAD_SWS_ZTH);
+        for (int k = 0; k < 4; k++) { U.alb_imp[k] = I(GEOSRAD_SWS_ALBVF + k); U.alb_exp[k] = O(GEOSRAD_SWS_ALBVF_X + k); }
+        for (int k = 0; k < 6; k++) { U.dn[k] = I(GEOSRAD_SWS_DRUVRN + k); U.dx[k] = O(GEOSRAD_SWS_DRUVR + k); }
+        U.fswn = I(GEOSRAD_SWS_FSWN); U.fscn = I(GEOSRAD_SWS_FSCN); U.fswnan = I(GEOSRAD_SWS_FSWNAN); U.fscnan = I(GEOSRAD_SWS_FSCNAN);
+        U.albedo = O(GEOSRAD_SWS_ALBEDO); U.slrtp = O(GEOSRAD_SWS_SLRTP);
+        for (int k = 0; k < 3; k++) U.drn[k] = O(GEOSRAD_SWS_DRNUVR + k);
+        U.slrsf = O(GEOSRAD_SWS_SLRSF); U.slrsfc = O(GEOSRAD_SWS_SLRSFC); U.slrsfna = O(GEOSRAD_SWS_SLRSFNA); U.slrsfcna = O(GEOSRAD_SWS_SLRSFCNA);
+        U.slrsuf = O(GEOSRAD_SWS_SLRSUF); U.slrsufc = O(GEOSRAD_SWS_SLRSUFC); U.slrsufna = O(GEOSRAD_SWS_SLRSUFNA); U.slrsufcna = O(GEOSRAD_SWS_SLRSUFCNA);
+        hipLaunchKernelGGL((k_sw_update_surface<R>), dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, U);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -2255,6 +2287,12 @@ int geosrad_sw_update_export_dev(geosrad_ctx *c, void *stream, int ncol, int lm,
 {
     if (!c || !in || !out) return GEOSRAD_EINVAL;
     return c->sw_update_export_dev((hipStream_t)stream, ncol, lm, nbands, in, out);
+}
+
+int geosrad_sw_update_surface_dev(geosrad_ctx *c, void *stream, int ncol, int lm, double undef, const void *const *in, void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->sw_update_surface_dev((hipStream_t)stream, ncol, lm, undef, in, out);
 }
 
 int geosrad_rad_tendencies_dev(geosrad_ctx *c, void *stream, int ncol, int lm, double grav, double cp, const void *const *in,

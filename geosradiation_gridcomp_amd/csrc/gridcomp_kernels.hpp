@@ -560,6 +560,56 @@ template <typename R> __global__ void __launch_bounds__(256) k_swd_post(SwdPost<
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// UPDATE_EXPORT, 2-D block (SOL:7403-7533): albedo exports, total surface albedo, incident / surface fluxes.  One thread per column.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename R> struct SwSfc {
+    int ncol, lm;
+    R undef;
+    const R *slr, *zth, *alb_imp[4], *dn[6];          // ALBVF ALBVR ALBNF ALBNR; DRUVRN DFUVRN DRPARN DFPARN DRNIRN DFNIRN
+    const R *fswn, *fscn, *fswnan, *fscnan;           // (ncol,0:LM)
+    R *alb_exp[4], *albedo, *slrtp, *dx[6], *drn[3], *slrsf, *slrsfc, *slrsfna, *slrsfcna, *slrsuf, *slrsufc, *slrsufna, *slrsufcna;
+};
+template <typename R> __global__ void __launch_bounds__(256) k_sw_update_surface(SwSfc<R> U)
+{
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= U.ncol) return;
+    const size_t sfc = (size_t)U.lm * U.ncol + ij;
+    const R slr = U.slr[ij], undef = U.undef;
+    for (int k = 0; k < 4; k++)
+        if (U.alb_exp[k]) U.alb_exp[k][ij] = slr > 0 ? U.alb_imp[k][ij] * (R)1. : undef;      // FAC = 1. (SOL:7406)
+    R d[6];
+    for (int k = 0; k < 6; k++) d[k] = U.dn[k][ij];
+    const R sum6 = d[0] + d[1] + d[2] + d[3] + d[4] + d[5];      // DRUVRN+DFUVRN+DRPARN+DFPARN+DRNIRN+DFNIRN, left to right
+    R alb = sum6;
+    if (slr > (R)0.0 && alb > (R)0.0) {
+        R x = (R)1.0 - U.fswn[sfc] / alb;
+        x = x > (R).01 ? x : (R).01;                 // max(x, .01)
+        alb = x < (R)0.9 ? x : (R)0.9;               // min(.., 0.9)
+    } else alb = undef;
+    if (U.albedo) U.albedo[ij] = alb;
+    if (U.slrtp) U.slrtp[ij] = slr;
+    for (int k = 0; k < 6; k++)
+        if (U.dx[k]) U.dx[k][ij] = d[k] * slr;
+    if (U.drn[0] || U.drn[1] || U.drn[2]) {
+        const R zth = U.zth[ij] > (R)0.0 ? U.zth[ij] : (R)0.0;          // ZTH = max(ZTH,0.0)
+        const R sln = zth > (R)0.0 ? slr / zth : (R)0.0;
+        if (U.drn[0]) U.drn[0][ij] = d[0] * sln;
+        if (U.drn[1]) U.drn[1][ij] = d[2] * sln;
+        if (U.drn[2]) U.drn[2][ij] = d[4] * sln;
+    }
+    if (U.slrsf) U.slrsf[ij] = sum6 * slr;
+    const bool def = alb != undef;
+    if (U.slrsfc) U.slrsfc[ij] = def ? (U.fscn[sfc] * slr) / ((R)1. - alb) : (R)0.0;
+    if (U.slrsfna) U.slrsfna[ij] = def ? (U.fswnan[sfc] * slr) / ((R)1. - alb) : (R)0.0;
+    if (U.slrsfcna) U.slrsfcna[ij] = def ? (U.fscnan[sfc] * slr) / ((R)1. - alb) : (R)0.0;
+    if (U.slrsuf) U.slrsuf[ij] = alb * sum6 * slr;
+    if (U.slrsufc) U.slrsufc[ij] = def ? alb * (U.fscn[sfc] / ((R)1. - alb)) * slr : (R)0.0;
+    if (U.slrsufna) U.slrsufna[ij] = def ? alb * (U.fswnan[sfc] / ((R)1. - alb)) * slr : (R)0.0;
+    if (U.slrsufcna) U.slrsufcna[ij] = def ? alb * (U.fscnan[sfc] / ((R)1. - alb)) * slr : (R)0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // UPDATE_EXPORT, flux part (SOL:7540-7579): exports = normalised internals x SLR
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename R> struct SwUpd {

@@ -8,7 +8,7 @@ module geosrad_gridcomp
    use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
    implicit none
    private
-   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_update_surface, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
    ! ---- GEOSRAD_LWD_* ----
@@ -20,6 +20,12 @@ module geosrad_gridcomp
    integer, parameter, public :: LWD_FLXU_INT = 1, LWD_FLXD_INT = 2, LWD_FLCU_INT = 3, LWD_FLCD_INT = 4, LWD_DFDTS = 5, LWD_DFDTSC = 6, &
       LWD_DFDTSNA = 7, LWD_DFDTSCNA = 8, LWD_FLX_INT = 9, LWD_FLC_INT = 10, LWD_SFCEM_INT = 11, LWD_TS_INT = 12, LWD_CLDTTLW = 13, &
       LWD_CLDHILW = 14, LWD_CLDMDLW = 15, LWD_CLDLOLW = 16, LWD_OLRB = 17, LWD_DOLRB = 18, LWD_NOUT = 18
+   ! ---- GEOSRAD_SWS_* (2-D block of UPDATE_EXPORT) ----
+   integer, parameter, public :: SWS_SLR = 1, SWS_ZTH = 2, SWS_ALBVF = 3, SWS_ALBVR = 4, SWS_ALBNF = 5, SWS_ALBNR = 6, SWS_DRUVRN = 7, SWS_DFUVRN = 8, &
+      SWS_DRPARN = 9, SWS_DFPARN = 10, SWS_DRNIRN = 11, SWS_DFNIRN = 12, SWS_FSWN = 13, SWS_FSCN = 14, SWS_FSWNAN = 15, SWS_FSCNAN = 16, SWS_NIN = 16
+   integer, parameter, public :: SWS_ALBVF_X = 1, SWS_ALBVR_X = 2, SWS_ALBNF_X = 3, SWS_ALBNR_X = 4, SWS_ALBEDO = 5, SWS_SLRTP = 6, SWS_DRUVR = 7, &
+      SWS_DFUVR = 8, SWS_DRPAR = 9, SWS_DFPAR = 10, SWS_DRNIR = 11, SWS_DFNIR = 12, SWS_DRNUVR = 13, SWS_DRNPAR = 14, SWS_DRNNIR = 15, SWS_SLRSF = 16, &
+      SWS_SLRSFC = 17, SWS_SLRSFNA = 18, SWS_SLRSFCNA = 19, SWS_SLRSUF = 20, SWS_SLRSUFC = 21, SWS_SLRSUFNA = 22, SWS_SLRSUFCNA = 23, SWS_NOUT = 23
    ! ---- GEOSRAD_LWR_* (RATS exports of Update_Flx) ----
    integer, parameter, public :: LWR_FLX_INT = 1, LWR_SFCEM_INT = 2, LWR_DFDTS = 3, LWR_FLX_RAT = 4, LWR_SFCEM_RAT = 5, LWR_DFDTS_RAT = 6, LWR_NIN = 6
    integer, parameter, public :: LWR_DOLR = 1, LWR_DLWS = 2, LWR_DFLNS = 3, LWR_DSFCEM = 4, LWR_NETTRAP = 5, LWR_COLTRAP = 6, LWR_FLX = 7, &
@@ -96,6 +102,13 @@ module geosrad_gridcomp
          integer(c_int), intent(in) :: band_output(*)
          real(c_double), intent(in) :: wavenum1(*), wavenum2(*)
          real(c_double), value :: undef
+      end function
+      integer(c_int) function geosrad_sw_update_surface_dev(ctx, stream, ncol, lm, undef, fin, fout) bind(C, name='geosrad_sw_update_surface_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm
+         real(c_double), value :: undef
+         type(c_ptr), intent(in) :: fin(*), fout(*)
       end function
       integer(c_int) function geosrad_sw_driver_rrtmg_dev(ctx, stream, ncol, lm, nb_aer, fin, consts, iceflgsw, liqflgsw, sc, dist, isolvar, &
             dyofyr, include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, fout) bind(C, name='geosrad_sw_driver_rrtmg_dev')
@@ -256,6 +269,15 @@ contains
       bo = merge(1_c_int, 0_c_int, band_output)
       if (geosrad_lw_update_bands_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), bo, real(wavenum1,c_double), real(wavenum2,c_double), &
             real(undef,c_double), tsinst, ts_int, olrb_int, dolrb_int, olrb_exp, tbrb_exp) /= 0) call geosrad_fail('Update_Flx (band OLR)')
+   end subroutine
+
+   ! 2-D block of UPDATE_EXPORT (GEOS_SolarGridComp.F90:7403-7533): albedo exports, ALBEDO, incident and surface fluxes
+   subroutine sw_update_surface(ncol, lm, undef, fin, fout)
+      integer, intent(in) :: ncol, lm
+      real, intent(in) :: undef
+      type(c_ptr), intent(in) :: fin(SWS_NIN), fout(SWS_NOUT)
+      if (geosrad_sw_update_surface_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), real(undef,c_double), fin, fout) /= 0) &
+         call geosrad_fail('UPDATE_EXPORT (surface)')
    end subroutine
 
    ! RRTMG branch of SORADCORE (GEOS_SolarGridComp.F90:6113-6450) on the packed daytime columns

@@ -72,3 +72,9 @@ def swd_consts(**over):
 # rrlw_wvn: band limits of RRTMG_LW [cm-1] (LW/modules/rrlw_wvn.F90, set in rrtmg_lw_init.F90)
 LW_WAVENUM1 = [10., 350., 500., 630., 700., 820., 980., 1080., 1180., 1390., 1480., 1800., 2080., 2250., 2380., 2600.]
 LW_WAVENUM2 = [350., 500., 630., 700., 820., 980., 1080., 1180., 1390., 1480., 1800., 2080., 2250., 2380., 2600., 3250.]
+
+# 2-D block of UPDATE_EXPORT (SOL:7403-7533), GEOSRAD_SWS_*
+SWS_IN = ["SLR", "ZTH", "ALBVF", "ALBVR", "ALBNF", "ALBNR", "DRUVRN", "DFUVRN", "DRPARN", "DFPARN", "DRNIRN", "DFNIRN", "FSWN", "FSCN", "FSWNAN",
+          "FSCNAN"]
+SWS_OUT = ["ALBVF_X", "ALBVR_X", "ALBNF_X", "ALBNR_X", "ALBEDO", "SLRTP", "DRUVR", "DFUVR", "DRPAR", "DFPAR", "DRNIR", "DFNIR", "DRNUVR", "DRNPAR",
+           "DRNNIR", "SLRSF", "SLRSFC", "SLRSFNA", "SLRSFCNA", "SLRSUF", "SLRSUFC", "SLRSUFNA", "SLRSUFCNA"]

@@ -386,6 +386,19 @@ enum { GEOSRAD_SWU_FSW, GEOSRAD_SWU_FSC, GEOSRAD_SWU_FSWNA, GEOSRAD_SWU_FSCNA, G
 int geosrad_sw_update_export_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, int nbands, const void *const *in,
                                  void *const *out);
 
+/* geosrad_sw_update_surface_dev: the 2-D block of UPDATE_EXPORT above the flux part (GEOS_SolarGridComp.F90:7403-7533): the four
+ * albedo exports (import where SLR > 0, else MAPL_UNDEF), the total surface albedo ALB / ALBEDO (:7458-7465), the incident and
+ * surface fluxes SLRTP, DR/DF UVR PAR NIR, the normal-incidence DRN*, SLRSF*, SLRSUF* (with SLN = SLR / ZTH where ZTH > 0, :6877-6881).
+ * in: (ncol) fields, FSWN / FSCN / FSWNAN / FSCNAN (ncol,0:LM) (the last three only for the exports that read them). */
+enum { GEOSRAD_SWS_SLR, GEOSRAD_SWS_ZTH, GEOSRAD_SWS_ALBVF, GEOSRAD_SWS_ALBVR, GEOSRAD_SWS_ALBNF, GEOSRAD_SWS_ALBNR, GEOSRAD_SWS_DRUVRN,
+       GEOSRAD_SWS_DFUVRN, GEOSRAD_SWS_DRPARN, GEOSRAD_SWS_DFPARN, GEOSRAD_SWS_DRNIRN, GEOSRAD_SWS_DFNIRN, GEOSRAD_SWS_FSWN, GEOSRAD_SWS_FSCN,
+       GEOSRAD_SWS_FSWNAN, GEOSRAD_SWS_FSCNAN, GEOSRAD_SWS_NIN };
+enum { GEOSRAD_SWS_ALBVF_X, GEOSRAD_SWS_ALBVR_X, GEOSRAD_SWS_ALBNF_X, GEOSRAD_SWS_ALBNR_X, GEOSRAD_SWS_ALBEDO, GEOSRAD_SWS_SLRTP,
+       GEOSRAD_SWS_DRUVR, GEOSRAD_SWS_DFUVR, GEOSRAD_SWS_DRPAR, GEOSRAD_SWS_DFPAR, GEOSRAD_SWS_DRNIR, GEOSRAD_SWS_DFNIR, GEOSRAD_SWS_DRNUVR,
+       GEOSRAD_SWS_DRNPAR, GEOSRAD_SWS_DRNNIR, GEOSRAD_SWS_SLRSF, GEOSRAD_SWS_SLRSFC, GEOSRAD_SWS_SLRSFNA, GEOSRAD_SWS_SLRSFCNA,
+       GEOSRAD_SWS_SLRSUF, GEOSRAD_SWS_SLRSUFC, GEOSRAD_SWS_SLRSUFNA, GEOSRAD_SWS_SLRSUFCNA, GEOSRAD_SWS_NOUT };
+int geosrad_sw_update_surface_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, double undef, const void *const *in, void *const *out);
+
 /* geosrad_rad_tendencies_dev: the parent's heating rates (GEOS_RadiationGridComp.F90:798-819). */
 enum { GEOSRAD_RT_PLE, GEOSRAD_RT_FLW, GEOSRAD_RT_FSW, GEOSRAD_RT_FLWCLR, GEOSRAD_RT_FSWCLR, GEOSRAD_RT_FSWNA, GEOSRAD_RT_FLA,
        GEOSRAD_RT_FSCNA, GEOSRAD_RT_DSFDTS, GEOSRAD_RT_SFCEM, GEOSRAD_RT_TRD, GEOSRAD_RT_NIN };

@@ -446,3 +446,60 @@ def test_update_flx_band_olr_and_brightness_temperature(gpu_ctx, rk):
         tbr = (alT * np.float64(wnmid) / np.log(bigC * np.float64(wn3) / bmean + 1.0)).astype(dt)
         np.testing.assert_allclose(got_t[ib], tbr, rtol=float(np.finfo(dt).eps), atol=0)
         assert (tbr > 20).all() and (tbr < 2000).all() and tbr.std() > 1
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_update_export_surface_block(gpu_ctx, rk):
+    """2-D block of UPDATE_EXPORT (SOL:7403-7533) against the reference's statements in numpy (same kind, same order): bitwise; night
+    columns (SLR = 0) give MAPL_UNDEF albedos and zero surface fluxes; exports not associated stay untouched."""
+    import torch
+    ctx = gpu_ctx[rk]; dt = ctx.dtype
+    n, lm = 3000, 72
+    rng = np.random.default_rng(21)
+    U = lambda lo, hi, *s: rng.uniform(lo, hi, s).astype(dt)
+    st = {"SLR": U(0, 1300, n), "ZTH": U(-0.2, 1.0, n), "ALBVF": U(0.02, 0.5, n), "ALBVR": U(0.02, 0.5, n), "ALBNF": U(0.02, 0.5, n),
+          "ALBNR": U(0.02, 0.5, n), "FSWN": U(0, 1, lm + 1, n), "FSCN": U(0, 1, lm + 1, n), "FSWNAN": U(0, 1, lm + 1, n), "FSCNAN": U(0, 1, lm + 1, n)}
+    for k in G.SWS_IN[6:12]:
+        st[k] = U(0, 0.2, n)
+    night = rng.uniform(0, 1, n) < 0.4
+    st["SLR"][night] = 0
+    st["FSWN"][lm][rng.uniform(0, 1, n) < 0.05] = 2.0          # 1 - FSWN/sum < .01 -> clamped; also exercises the 0.9 cap below
+    st["FSWN"][lm][rng.uniform(0, 1, n) < 0.05] = 0.0
+    dark = rng.uniform(0, 1, n) < 0.05
+    for k in G.SWS_IN[6:12]:
+        st[k][dark] = 0                                        # no surface flux at all: ALB undefined
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in st.items()}
+    want = [k for k in G.SWS_OUT if k not in ("DFPAR", "SLRSUFNA")]
+    for k in want:
+        t[k] = torch.full((n,), -9.0, dtype=t["SLR"].dtype, device="cuda")
+    undef = G.MAPL["UNDEF"]
+    ctx.sw_update_surface_dev(_stream(), n, lm, undef, {k: v.data_ptr() for k, v in t.items()})
+    ctx.check(_stream())
+    slr = st["SLR"]; ud = dt(undef); one = dt(1.0)
+    d = [st[k] for k in G.SWS_IN[6:12]]
+    sum6 = d[0] + d[1] + d[2] + d[3] + d[4] + d[5]
+    ref = {}
+    for k in ("ALBVF", "ALBVR", "ALBNF", "ALBNR"):
+        ref[k + "_X"] = np.where(slr > 0, st[k] * one, ud)
+    ok = (slr > 0) & (sum6 > 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x = one - st["FSWN"][lm] / sum6
+        alb = np.where(ok, np.minimum(np.maximum(x, dt(.01)), dt(0.9)), ud).astype(dt)
+        ref["ALBEDO"] = alb
+        ref["SLRTP"] = slr
+        for k, nm in enumerate(("DRUVR", "DFUVR", "DRPAR", "DFPAR", "DRNIR", "DFNIR")):
+            ref[nm] = d[k] * slr
+        zth = np.maximum(st["ZTH"], dt(0.0))
+        sln = np.where(zth > 0, slr / np.where(zth > 0, zth, one), dt(0.0)).astype(dt)
+        ref["DRNUVR"] = d[0] * sln; ref["DRNPAR"] = d[2] * sln; ref["DRNNIR"] = d[4] * sln
+        ref["SLRSF"] = sum6 * slr
+        defd = alb != ud
+        for nm, f in (("SLRSFC", "FSCN"), ("SLRSFNA", "FSWNAN"), ("SLRSFCNA", "FSCNAN")):
+            ref[nm] = np.where(defd, (st[f][lm] * slr) / (one - alb), dt(0.0)).astype(dt)
+        ref["SLRSUF"] = alb * sum6 * slr
+        for nm, f in (("SLRSUFC", "FSCN"), ("SLRSUFNA", "FSWNAN"), ("SLRSUFCNA", "FSCNAN")):
+            ref[nm] = np.where(defd, alb * (st[f][lm] / (one - alb)) * slr, dt(0.0)).astype(dt)
+    for k in want:
+        assert ref[k].dtype == dt, k
+        np.testing.assert_array_equal(t[k].cpu().numpy(), ref[k], err_msg=k)
+    assert (ref["ALBEDO"] == ud).sum() > n // 3 and (ref["ALBEDO"] == dt(.01)).any() and (ref["ALBEDO"] == dt(0.9)).any()
