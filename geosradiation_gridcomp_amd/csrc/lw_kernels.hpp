@@ -44,6 +44,38 @@ template <typename T> GR_DEV void stg(T *base, uint32_t byteoff, T v)
 {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byteoff) = v;
 }
+// streaming variants for scratch that is written once and read once much later (parked cells): non-temporal, so that it does not
+// displace the k-distribution rows and look-up tables from the caches
+template <typename T> GR_DEV T ldg_nt(const T *base, uint32_t byteoff)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byteoff));
+}
+template <typename T> GR_DEV void stg_nt(T *base, uint32_t byteoff, T v)
+{
+    __builtin_nontemporal_store(v, reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byteoff));
+}
+typedef float gr_v2f __attribute__((ext_vector_type(2)));
+typedef double gr_v2d __attribute__((ext_vector_type(2)));
+template <> GR_DEV float2 ldg_nt<float2>(const float2 *base, uint32_t byteoff)
+{
+    const gr_v2f t = __builtin_nontemporal_load(reinterpret_cast<const gr_v2f *>(reinterpret_cast<const char *>(base) + byteoff));
+    float2 r; r.x = t.x; r.y = t.y; return r;
+}
+template <> GR_DEV double2 ldg_nt<double2>(const double2 *base, uint32_t byteoff)
+{
+    const gr_v2d t = __builtin_nontemporal_load(reinterpret_cast<const gr_v2d *>(reinterpret_cast<const char *>(base) + byteoff));
+    double2 r; r.x = t.x; r.y = t.y; return r;
+}
+template <> GR_DEV void stg_nt<float2>(float2 *base, uint32_t byteoff, float2 v)
+{
+    gr_v2f t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<gr_v2f *>(reinterpret_cast<char *>(base) + byteoff));
+}
+template <> GR_DEV void stg_nt<double2>(double2 *base, uint32_t byteoff, double2 v)
+{
+    gr_v2d t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<gr_v2d *>(reinterpret_cast<char *>(base) + byteoff));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // k_validate_pwv: one thread per column.
@@ -1118,8 +1150,8 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
 #pragma unroll
                 for (int j = 0; j < W; j++)
                     if (j < npend) {
-                        stg(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
-                        if (CLD && (pmask2 >> j) & 1u) stg(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
+                        stg_nt(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
+                        if (CLD && (pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
                     }
             }
             npend = 0; pmask2 = 0;
@@ -1156,13 +1188,13 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 }
                 if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
                 if (DEFER) { pend1[j].x = atot; pend1[j].y = bbutot; poff[j] = scell; npend = j + 1; }
-                else { R2 sv; sv.x = atot; sv.y = bbutot; stg(s1_b, scell * (uint32_t)sizeof(R2), sv); }
+                else { R2 sv; sv.x = atot; sv.y = bbutot; stg_nt(s1_b, scell * (uint32_t)sizeof(R2), sv); }
                 dsum = dsum + sumfac * rad[g];
                 if (CLD && ccol) {
                     if (diverge) {
                         radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
                         if (DEFER) { pend2[j].x = agas; pend2[j].y = bbugas; pmask2 |= 1u << j; }
-                        else { R2 sg; sg.x = agas; sg.y = bbugas; stg(s2_b, scell * (uint32_t)sizeof(R2), sg); }
+                        else { R2 sg; sg.x = agas; sg.y = bbugas; stg_nt(s2_b, scell * (uint32_t)sizeof(R2), sg); }
                     } else {
                         radc[g] = rad[g];
                     }
@@ -1253,12 +1285,12 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 }
                 rad[g] = rad[g] + (bbd - rad[g]) * atot;
                 R2 sv; sv.x = atot; sv.y = bbutot;
-                stg(s1_b, scell * (uint32_t)sizeof(R2), sv);
+                stg_nt(s1_b, scell * (uint32_t)sizeof(R2), sv);
                 dsum = dsum + sumfac * rad[g];
                 if (CLD) {
                     const R rc = radc[g] + (bbdgas - radc[g]) * agas;
                     radc[g] = diverge ? rc : rad[g];
-                    if (wdv) { R2 sg; sg.x = agas; sg.y = bbugas; stg(s2_b, scell * (uint32_t)sizeof(R2), sg); }
+                    if (wdv) { R2 sg; sg.x = agas; sg.y = bbugas; stg_nt(s2_b, scell * (uint32_t)sizeof(R2), sg); }
                     dcsum = dcsum + sumfac * radc[g];
                 }
                 if (lay == 0) {
@@ -1285,8 +1317,8 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
 #pragma unroll
     for (int j = 0; j < W; j++)
         if (j < npend) {
-            stg(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
-            if (CLD && (pmask2 >> j) & 1u) stg(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
+            stg_nt(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
+            if (CLD && (pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
         }
     // TOA downward flux is zero (level nlay); written so the reduce kernel can sum unconditionally
     PART(0, nlay, 0);
@@ -1307,11 +1339,11 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
         usum = 0; ucsum = 0; dusum = 0; ducsum = 0;
         R2 sv[NG], sg[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) sv[g] = ldg(s1_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
+        for (int g = 0; g < NG; g++) sv[g] = ldg_nt(s1_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
         if (CLD && lay <= wtop) {
             // (lanes that have no pair of their own here read what happens to be there and do not use it)
 #pragma unroll
-            for (int g = 0; g < NG; g++) sg[g] = ldg(s2_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
+            for (int g = 0; g < NG; g++) sg[g] = ldg_nt(s2_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
         } else {
 #pragma unroll
             for (int g = 0; g < NG; g++) sg[g] = sv[g];

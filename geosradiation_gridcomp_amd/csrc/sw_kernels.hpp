@@ -623,8 +623,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                     }
                     tdbt[g] = dbt * tdbt[g]; ztdn[g] = zt; prdnd[g] = pr;
                 }
-                stg(CELL(0), ct4, ref); stg(CELL(1), ct4, refd); stg(CELL(2), ct4, tra); stg(CELL(3), ct4, trad);
-                stg(CELL(4), ct4, dbt); stg(CELL(6), ct4, ztdn[g]); stg(CELL(7), ct4, prdnd[g]);
+                stg_nt(CELL(0), ct4, ref); stg_nt(CELL(1), ct4, refd); stg_nt(CELL(2), ct4, tra); stg_nt(CELL(3), ct4, trad);
+                stg_nt(CELL(4), ct4, dbt); stg_nt(CELL(6), ct4, ztdn[g]); stg_nt(CELL(7), ct4, prdnd[g]);
                 const R tdbt_clear = tdbt[g];
                 bool cellcld = false;
                 R tc = 0;
@@ -633,7 +633,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 // same inputs): nothing is computed or parked for it there; the sign bit of the parked clear-sky T_dir^cum tells
                 // sweep B from which level on the total sky has values of its own.
                 const bool divg = CLD && ccol && (((dmask >> g) & 1u) || cellcld);
-                stg(CELL(5), ct4, divg ? -tdbt_clear : tdbt_clear);
+                stg_nt(CELL(5), ct4, divg ? -tdbt_clear : tdbt_clear);
                 if (CLD && ccol && !divg) { tdbtT[g] = tdbt[g]; ztdnT[g] = ztdn[g]; prdndT[g] = prdnd[g]; }
                 if (divg) {
                     dmask |= 1u << g;
@@ -648,8 +648,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                         dbt = f_exp<R>(-t2 * rmu0);
                         cmask |= 1u << g;
                         // total-sky layer properties are parked for cloudy cells only (elsewhere they equal the clear-sky ones)
-                        stg(CELL(8), ct4, ref); stg(CELL(9), ct4, refd); stg(CELL(10), ct4, tra); stg(CELL(11), ct4, trad);
-                        stg(CELL(12), ct4, dbt);
+                        stg_nt(CELL(8), ct4, ref); stg_nt(CELL(9), ct4, refd); stg_nt(CELL(10), ct4, tra); stg_nt(CELL(11), ct4, trad);
+                        stg_nt(CELL(12), ct4, dbt);
                     }
                     R zt, pr;
                     if (jk == 0) { zt = tra; pr = refd; }
@@ -660,7 +660,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                     }
                     tdbtT[g] = dbt * tdbtT[g]; ztdnT[g] = zt; prdndT[g] = pr;
                     // the sign bit of the parked T_dir^cum (>= 0) carries "this layer is cloudy" to sweep B
-                    stg(CELL(13), ct4, cellcld ? -tdbtT[g] : tdbtT[g]); stg(CELL(14), ct4, ztdnT[g]); stg(CELL(15), ct4, prdndT[g]);
+                    stg_nt(CELL(13), ct4, cellcld ? -tdbtT[g] : tdbtT[g]); stg_nt(CELL(14), ct4, ztdnT[g]); stg_nt(CELL(15), ct4, prdndT[g]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -725,8 +725,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 if (g >= NG) continue;
                 const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
                 const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-                ref[j] = ldg(CELL(0), c4); refd[j] = ldg(CELL(1), c4); tra[j] = ldg(CELL(2), c4); trad[j] = ldg(CELL(3), c4); dbt[j] = ldg(CELL(4), c4);
-                if (jk > 0) { tbc[j] = ldg(CELL(5), u4); ztc[j] = ldg(CELL(6), u4); prc[j] = ldg(CELL(7), u4); }
+                ref[j] = ldg_nt(CELL(0), c4); refd[j] = ldg_nt(CELL(1), c4); tra[j] = ldg_nt(CELL(2), c4); trad[j] = ldg_nt(CELL(3), c4); dbt[j] = ldg_nt(CELL(4), c4);
+                if (jk > 0) { tbc[j] = ldg_nt(CELL(5), u4); ztc[j] = ldg_nt(CELL(6), u4); prc[j] = ldg_nt(CELL(7), u4); }
                 else { tbc[j] = 1; ztc[j] = 1; prc[j] = 0; }
             }
 #pragma unroll
@@ -748,8 +748,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 if (g >= NG) continue;
                 const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
                 const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-                if (wcm) { refT[j] = ldg(CELL(8), c4); refdT[j] = ldg(CELL(9), c4); traT[j] = ldg(CELL(10), c4); tradT[j] = ldg(CELL(11), c4); dbtT[j] = ldg(CELL(12), c4); }
-                if (wdv) { tbT[j] = ldg(CELL(13), u4); ztT[j] = ldg(CELL(14), u4); prT[j] = ldg(CELL(15), u4); }
+                if (wcm) { refT[j] = ldg_nt(CELL(8), c4); refdT[j] = ldg_nt(CELL(9), c4); traT[j] = ldg_nt(CELL(10), c4); tradT[j] = ldg_nt(CELL(11), c4); dbtT[j] = ldg_nt(CELL(12), c4); }
+                if (wdv) { tbT[j] = ldg_nt(CELL(13), u4); ztT[j] = ldg_nt(CELL(14), u4); prT[j] = ldg_nt(CELL(15), u4); }
             }
 #pragma unroll
             for (int j = 0; j < GC; j++) {
@@ -792,7 +792,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
             const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
             const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
             const R zi = zinc[g] * prmu0;
-            R ref = ldg(CELL(0), c4), refd = ldg(CELL(1), c4), tra = ldg(CELL(2), c4), trad = ldg(CELL(3), c4), dbt = ldg(CELL(4), c4);
+            R ref = ldg_nt(CELL(0), c4), refd = ldg_nt(CELL(1), c4), tra = ldg_nt(CELL(2), c4), trad = ldg_nt(CELL(3), c4), dbt = ldg_nt(CELL(4), c4);
             R tbc, ztc, prc;
             bool ldiv = false;
             {
@@ -801,7 +801,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 const R pd = refd + trad * trad * prupd[g] * zrj;
                 prup[g] = pu; prupd[g] = pd;
                 if (jk > 0) {
-                    tbc = ldg(CELL(5), u4); ztc = ldg(CELL(6), u4); prc = ldg(CELL(7), u4);
+                    tbc = ldg_nt(CELL(5), u4); ztc = ldg_nt(CELL(6), u4); prc = ldg_nt(CELL(7), u4);
                     if (CLD) { ldiv = __builtin_signbit(tbc); tbc = ldiv ? -tbc : tbc; }
                 } else { tbc = 1; ztc = 1; prc = 0; ldiv = false; }
                 const R zr = f_rcp<R>((R)1. - prc * pd);
@@ -810,7 +810,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
             }
             if (CLD && ccol) {
                 if (cmask & (1u << g)) {
-                    ref = ldg(CELL(8), c4); refd = ldg(CELL(9), c4); tra = ldg(CELL(10), c4); trad = ldg(CELL(11), c4); dbt = ldg(CELL(12), c4);
+                    ref = ldg_nt(CELL(8), c4); refd = ldg_nt(CELL(9), c4); tra = ldg_nt(CELL(10), c4); trad = ldg_nt(CELL(11), c4); dbt = ldg_nt(CELL(12), c4);
                 }
                 const R zrj = f_rcp<R>((R)1. - prupdT[g] * refd);
                 const R pu = ref + (trad * ((tra - dbt) * prupdT[g] + dbt * prupT[g])) * zrj;
@@ -818,7 +818,7 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
                 prupT[g] = pu; prupdT[g] = pd;
                 R tb = tbc, zt = ztc, pr = prc;              // above the sub-column's highest cloud: the clear-sky values
                 if (ldiv) {
-                    tb = ldg(CELL(13), u4); zt = ldg(CELL(14), u4); pr = ldg(CELL(15), u4);
+                    tb = ldg_nt(CELL(13), u4); zt = ldg_nt(CELL(14), u4); pr = ldg_nt(CELL(15), u4);
                     if (__builtin_signbit(tb)) { cnext |= 1u << g; tb = -tb; }
                 }
                 const R zr = f_rcp<R>((R)1. - pr * pd);
