@@ -53,7 +53,7 @@ template <> GR_DEV double gr_log10<double>(double x) { return log10(x); }
 
 // ---------------------------------------------------------------------------------------------------
 // k_chou_prep: lane = column; absorber amounts and scaled quantities of every layer (irrad.F90:381-453), written as the
-// column's record.  Negative inputs raise an error bit (the reference has no input assertions here).
+// column's record.  (Like the reference, irrad has no input assertions.)
 // ---------------------------------------------------------------------------------------------------
 // The records are column-major ([column][field][level]: k_chou_bands reads a column's fields with lanes = levels), the inputs
 // are level-major with the column index fastest: the transposition goes through an LDS tile of 64 columns x 8 (fp64: 4) levels, so that

@@ -403,7 +403,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         // Oreopoulos et al. (2012) defaults (cloud_subcol_gen.F90:51-59)
         const double adl[4] = {1.4315, 2.1219, 7., -25.584}, rdl[4] = {0.72192, 0.78996, 8.5, 40.404};
         for (int i = 0; i < 4; i++) { h_T.aam[i] = (R)(sizeof(R) == 4 ? (float)adl[i] : adl[i]); h_T.ram[i] = (R)(sizeof(R) == 4 ? (float)rdl[i] : rdl[i]); }
-        return GEOSRAD_OK;
+        // the McICA kernels of the SW solver and of the stand-alone generator read aam / ram / xcw from d_T: it must hold the
+        // defaults (and a null xcw) even when neither the LW tables, an inhomogeneity table nor correlation lengths are ever set
+        return sync_T();
     }
 
     int sync_T()
@@ -1175,7 +1177,10 @@ template <typename R> struct Ctx : geosrad_ctx {
         uint32_t e2[2] = {0, 0};
         HIPCHK(hipMemcpy(e2, d_err, 8, hipMemcpyDeviceToHost));
         if (!e2[0] && !e2[1]) return GEOSRAD_OK;
-        HIPCHK(hipMemset(d_err, 0, 8));
+        // slot 0 = RRTMG_LW (+ McICA), slot 1 = RRTMG_SW; the Chou schemes have no input assertions (neither has the reference).
+        // Only the slot that is reported is cleared: with the two solvers on two streams the other one's flag stays up for the
+        // check of its own stream.
+        HIPCHK(hipMemset(d_err + (e2[1] ? 1 : 0), 0, 4));
         if (e2[1]) {   // RRTMG_SW input assertions (SW/rrtmg_sw_rad.F90:365-383)
             static const char *SW_NEG_NAMES[12] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cld", "ciwp", "clwp", "rei", "rel"};
             for (int k = 0; k < 12; k++)
@@ -2018,6 +2023,26 @@ int geosrad_load_inhomogeneity(geosrad_ctx *c, int ih, const char *path)
     return rc ? rc : c->set_inhomogeneity(ih, buf.data(), buf.size());
 }
 int geosrad_set_corr_lengths(geosrad_ctx *c, const double *adl, const double *rdl) { return c ? c->set_corr(adl, rdl) : GEOSRAD_EINVAL; }
+
+// Host-side copy of one named real array of a GRTB coefficient file (no context, no device): the Fortran shim keeps the xcw table
+// on the host as well, because the reference's public zcw_lookup (cloud_condensate_inhomogeneity.F90:86-124) is a host function
+// that the GridComps import for their RRTMGP branch.
+int geosrad_read_table(const char *path, const char *name, int real_kind, void *dst, size_t count)
+{
+    if (!path || !name || !dst || (real_kind != 4 && real_kind != 8)) return GEOSRAD_EINVAL;
+    FILE *f = fopen(path, "rb");
+    if (!f) return GEOSRAD_ETABLE;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<char> buf(n > 0 ? (size_t)n : 0);
+    const size_t got = n > 0 ? fread(buf.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    Blob B;
+    if (got != buf.size() || !B.parse(buf.data(), buf.size())) return GEOSRAD_ETABLE;
+    auto it = B.e.find(name);
+    if (it == B.e.end() || it->second.kind != real_kind || it->second.count != count) return GEOSRAD_ETABLE;
+    memcpy(dst, it->second.data, count * (size_t)real_kind);
+    return GEOSRAD_OK;
+}
 
 
 int geosrad_set_tables_sw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_sw(blob, n) : GEOSRAD_EINVAL; }

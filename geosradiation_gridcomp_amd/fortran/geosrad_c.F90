@@ -7,7 +7,7 @@ module geosrad_c
    private
    public :: geosrad_ctx_handle, geosrad_fail, geosrad_warn, geosrad_data_path, geosrad_load_tables_sw, geosrad_rrtmg_sw, geosrad_load_tables_chou_lw, geosrad_load_tables_chou_sw, geosrad_irrad, geosrad_sorad
    public :: geosrad_create, geosrad_destroy, geosrad_last_error, geosrad_load_tables_lw, geosrad_load_inhomogeneity
-   public :: geosrad_set_corr_lengths, geosrad_rrtmg_lw, geosrad_mcica, geosrad_clearcounts
+   public :: geosrad_set_corr_lengths, geosrad_rrtmg_lw, geosrad_mcica, geosrad_clearcounts, geosrad_read_table
 
    type(c_ptr), save :: ctx = c_null_ptr
 
@@ -75,6 +75,10 @@ module geosrad_c
       end function
       integer(c_int) function geosrad_load_inhomogeneity(ctx, ih, path) bind(C, name='geosrad_load_inhomogeneity')
          import; type(c_ptr), value :: ctx; integer(c_int), value :: ih; character(kind=c_char), intent(in) :: path(*)
+      end function
+      integer(c_int) function geosrad_read_table(path, name, real_kind, dst, count) bind(C, name='geosrad_read_table')
+         import; character(kind=c_char), intent(in) :: path(*), name(*); integer(c_int), value :: real_kind
+         type(c_ptr), value :: dst; integer(c_size_t), value :: count
       end function
       integer(c_int) function geosrad_set_corr_lengths(ctx, adl, rdl) bind(C, name='geosrad_set_corr_lengths')
          import; type(c_ptr), value :: ctx; real(c_double), intent(in) :: adl(4), rdl(4)

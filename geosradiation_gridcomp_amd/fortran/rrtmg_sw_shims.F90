@@ -94,14 +94,21 @@ contains
       real, intent(out), target :: fswband(ncol,nbndsw)
       real, intent(out), target, dimension(ncol) :: cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp
       logical, intent(in) :: do_drfband
-      real, intent(inout), target, dimension(ncol,nbndsw) :: drband, dfband
+      ! exactly the reference's dummies (rrtmg_sw_rad.F90:355): GEOS passes DRBAND / DFBAND disassociated unless SOLAR_TO_OBIO is
+      ! set, and then as the non-contiguous section ptr2(1:Num2do,:) (GEOS_SolarGridComp.F90:778,4148-4151,6385)
+      real, intent(inout), dimension(:,:), pointer :: drband, dfband
       real, intent(in), optional, target :: bndscl(nbndsw), indsolvar(2)
       real, intent(in), optional :: solcycfrac
       integer, intent(out), optional :: RC
       integer(c_int), target :: cc(ncol,4)
       integer(c_int) :: st
-      type(c_ptr) :: pb, pi
-      pb = c_null_ptr; pi = c_null_ptr
+      type(c_ptr) :: pb, pi, pdr, pdf
+      real, allocatable, target :: zdr(:,:), zdf(:,:)       ! contiguous (ncol,nbndsw) images of the pointer targets
+      pb = c_null_ptr; pi = c_null_ptr; pdr = c_null_ptr; pdf = c_null_ptr
+      if (do_drfband) then                                   ! the pointers are touched only in this case, like the reference
+         allocate(zdr(ncol,nbndsw), zdf(ncol,nbndsw))
+         pdr = c_loc(zdr); pdf = c_loc(zdf)
+      end if
       if (present(bndscl)) pb = c_loc(bndscl)
       if (present(indsolvar)) pi = c_loc(indsolvar)
       st = geosrad_rrtmg_sw(geosrad_ctx_handle(), int(rpart,c_int), int(ncol,c_int), int(nlay,c_int), real(scon,c_double), &
@@ -113,8 +120,11 @@ contains
          c_loc(swuflx), c_loc(swdflx), c_loc(swuflxc), c_loc(swdflxc), &
          c_loc(nirr), c_loc(nirf), c_loc(parr), c_loc(parf), c_loc(uvrr), c_loc(uvrf), c_loc(fswband), &
          c_loc(cotdtp), c_loc(cotdhp), c_loc(cotdmp), c_loc(cotdlp), c_loc(cotntp), c_loc(cotnhp), c_loc(cotnmp), c_loc(cotnlp), &
-         merge(1_c_int, 0_c_int, do_drfband), c_loc(drband), c_loc(dfband), pb, pi)
+         merge(1_c_int, 0_c_int, do_drfband), pdr, pdf, pb, pi)
       clearCounts = cc
+      if (do_drfband .and. st == 0) then
+         drband(1:ncol,1:nbndsw) = zdr; dfband(1:ncol,1:nbndsw) = zdf
+      end if
       ! the reference reports failures through MAPL's RC convention (_FAIL / _RETURN(_SUCCESS), rrtmg_sw_rad.F90:365-383)
       if (present(RC)) then
          RC = st

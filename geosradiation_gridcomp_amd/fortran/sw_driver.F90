@@ -12,7 +12,8 @@ program sw_driver
    real(4) :: scon4
    real(4), allocatable :: buf(:)
    real, allocatable, dimension(:,:) :: play, plev, tlay, h2o, o3, co2, ch4, o2, cld, ciwp, clwp, rei, rel, zm, &
-      swuflx, swdflx, swuflxc, swdflxc, fswband, drband, dfband
+      swuflx, swdflx, swuflxc, swdflxc, fswband
+   real, pointer, dimension(:,:) :: drband, dfband            ! pointers, as in SORADCORE (GEOS_SolarGridComp.F90:6385)
    real, allocatable, dimension(:) :: coszen, alat, asdir, asdif, aldir, aldif, nirr, nirf, parr, parf, uvrr, uvrf, &
       c1, c2, c3, c4, c5, c6, c7, c8
    real, allocatable, dimension(:,:,:) :: tauaer, ssaaer, asmaer

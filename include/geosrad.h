@@ -87,6 +87,10 @@ int geosrad_set_inhomogeneity(geosrad_ctx *ctx, int ih, const void *xcw_blob, si
 int geosrad_load_inhomogeneity(geosrad_ctx *ctx, int ih, const char *path);
 /* adl = (am1, am2, am30, am4) cloud presence, rdl = same for condensate; NULL keeps the current value */
 int geosrad_set_corr_lengths(geosrad_ctx *ctx, const double *adl, const double *rdl);
+/* host copy of one named real array of a *.grtb coefficient file; needs neither a context nor a device.  The Fortran shim uses
+ * it for the xcw table behind the reference's host function zcw_lookup (cloud_condensate_inhomogeneity.F90:86-124), which
+ * GEOS_IrradGridComp.F90:1472 / GEOS_SolarGridComp.F90:3346 import.  count = number of reals expected (checked). */
+int geosrad_read_table(const char *path, const char *name, int real_kind, void *dst, size_t count);
 
 /* ---- RRTMG_LW --------------------------------------------------------------------------------------
  * Argument names, order, units and meaning are those of rrtmg_lw (rrtmg_lw_rad.F90:15-201).

@@ -141,6 +141,14 @@ def zcw_lookup(cdf, sigma, kind="r4"):
     return z
 
 
+def corr_lengths(alat, doy, kind="r4"):
+    """correlation_length_cloud_fraction / _condensate (cloud_subcol_gen.F90:491-542) -> (adl, rdl) in metres."""
+    dt = dtype_of(kind)
+    a = _c(alat, dt); adl = np.zeros_like(a); rdl = np.zeros_like(a)
+    lib(kind).ref_corr_lengths(ctypes.c_int(a.size), ctypes.c_int(int(doy)), _p(a), _p(adl), _p(rdl))
+    return adl, rdl
+
+
 def lw_cldprmc(cldy, ciwpmc, clwpmc, reice, reliq, iceflag=3, liqflag=1, kind="r4"):
     """cldprmc (rrtmg_lw_cldprmc.F90:24).  cldy etc. numpy (ncol, 140, nlay); reice/reliq numpy (nlay, ncol)."""
     L = lib(kind)

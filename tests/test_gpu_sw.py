@@ -198,3 +198,36 @@ def test_sw_full_size_properties(gpu_ctx):
     same = (p["clearCounts"][:, :32] == r["clearCounts"]).all(axis=0)
     for k in ("swuflx", "swdflx"):
         assert (np.abs(p[k][:, :32].astype(np.float64) - r[k]) <= 10 * flux_tol(4, r["swdflx"][72]))[:, same].all()
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_fresh_context_with_sw_tables_only(rk):
+    """A context that never saw rrtmg_lw_ini, set_inhomogeneity or initialize_cloud_subcol_gen (fortran/sw_driver.F90 with ih = 0
+    is that case) must still run McICA on the default decorrelation parameters and a null xcw table: cloudy columns against the
+    oracle, and the stand-alone generator on a context with no tables at all against the reference-pinned one."""
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import Context
+    from oracle import clib
+    kind = _kind(rk)
+    inp = synth.make_columns(64, 72, start=7100, aerosol=True, cloudy_frac=1.0)
+    clib.set_inhomogeneity(0, kind)
+    ctx = Context(rk, tables=False)
+    try:
+        cl, ci, cw = ctx.generate_stochastic_clouds(64, 112, 72, inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"],
+                                                    inp["ciwp"], inp["clwp"], 1e-20, seed_order=(4, 3, 2, 1))
+        rl, ri, rw = clib.mcica(inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"], inp["ciwp"], inp["clwp"], 112,
+                                seed_order=(4, 3, 2, 1), prec=kind)
+        flips = int((cl != rl.astype(np.int32)).sum())
+        assert flips == 0 if rk == 8 else flips <= 1e-5 * cl.size, flips
+        assert cl.sum() > 0.05 * cl.size            # really cloudy: an all-zero alpha (random overlap) or a wild xcw would show here
+        ctx.rrtmg_sw_ini()
+        g = ctx.rrtmg_sw_columns(inp, iaer=10)
+    finally:
+        ctx.close()
+    o = clib.rrtmg_sw(inp, prec=kind, iaer=10)
+    same = (g["clearCounts"] == o["clearCounts"]).all(axis=0)
+    assert same.all() if rk == 8 else same.mean() >= 0.95
+    tol = flux_tol(rk, o["swdflx"][72])
+    for k in SWFLUX:
+        err = (np.abs(g[k].astype(np.float64) - o[k].astype(np.float64)) / tol)[..., same]
+        assert err.max() <= (1.0 if rk == 8 else 10.0), (k, err.max())

@@ -75,3 +75,42 @@ def test_synth_is_shardable_and_valid():
         assert a[k].min() >= 0
     assert 2.5 <= a["rel"].min() and a["rel"].max() <= 60 and 5 <= a["rei"].min() and a["rei"].max() <= 140
     assert a["cldf"].max() == 1.0 and 0.3 < (a["cldf"].max(axis=0) > 0).mean() < 0.9
+
+
+@pytest.mark.parametrize("kind", ["r4", "r8"])
+@pytest.mark.parametrize("ih", [0, 1, 2])
+def test_fortran_host_functions_match_reference(tmp_path, kind, ih):
+    """The McICA host functions the unchanged GridComps import from the shim modules (zcw_lookup, correlation_length_cloud_fraction,
+    correlation_length_condensate; GEOS_IrradGridComp.F90:1472-1474) against the reference's own Fortran, bit for bit.  No device."""
+    import subprocess
+    from oracle import reflib
+    fdir = os.path.join(ROOT, "geosradiation_gridcomp_amd", "fortran")
+    exe = os.path.join(fdir, "bin", f"hostfn_driver_{kind}")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/flang") and not os.path.exists(exe):
+        pytest.skip("no Fortran compiler")
+    if not reflib.available(kind):
+        pytest.skip("oracle/_ref not built")
+    _lib.build()
+    subprocess.check_call(["make", "-s", "-C", fdir, f"bin/hostfn_driver_{kind}"], stderr=subprocess.DEVNULL)
+    dt = np.float32 if kind == "r4" else np.float64
+    rng = np.random.default_rng(5 + ih)
+    n = 4096
+    cdf = rng.uniform(0, 1, n).astype(dt); cdf[:4] = [0, 1, 0.5, 1e-7]
+    sigma = rng.uniform(0.0, 4.0, n).astype(dt)         # beyond both table edges (40 sigma - 3 in [1, 139])
+    alat = rng.uniform(-np.pi / 2, np.pi / 2, n).astype(dt)
+    for doy in (17, 181, 182, 300):
+        fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+        with open(fin, "wb") as f:
+            np.array([ih, doy, n], dtype=np.int32).tofile(f)
+            cdf.tofile(f); sigma.tofile(f); alat.tofile(f)
+        env = dict(os.environ, GEOSRAD_DATA=_lib.DATA)
+        subprocess.check_call([exe, str(fin), str(fout)], env=env)
+        z, adl, rdl = np.fromfile(fout, dtype=dt).reshape(3, n)
+        reflib.set_inhomogeneity(0, kind); reflib.set_inhomogeneity(ih, kind)
+        zr = reflib.zcw_lookup(cdf, sigma, kind)
+        ar, rr = reflib.corr_lengths(alat, doy, kind)
+        reflib.set_inhomogeneity(0, kind)
+        np.testing.assert_array_equal(z, zr)
+        np.testing.assert_array_equal(adl, ar)
+        np.testing.assert_array_equal(rdl, rr)
+        assert (z == 1).all() if ih == 0 else z.std() > 0.1
