@@ -61,6 +61,43 @@ def shard_start(rank, ncol_per_gpu):
     return rank * ncol_per_gpu
 
 
+def launch_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks ourselves, as CHILD processes of a
+    parent that has not touched the GPU (one rank per device), and hand their exit code on.  The ranks only ever exchange a barrier
+    and the MAX of one double, so the rendezvous is the one torch.distributed.run sets up on 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd)
+
+
+def control_path_only(a, rank, world):
+    """everything of an N-rank run except the GPU: rank -> shard, rendezvous, barrier, MAX over ranks, one JSON line from rank 0.
+    (tests/test_dist.py drives `python bench.py --gpus 2 --control-path-only` through the launcher on the CPU.)"""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                      # the "steps": the slowest rank sets the time
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, torch.device("cpu"))
+    starts = [shard_start(r, a.ncol) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "control path only (no GPU work)", "value": None, "unit": "columns/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "scaling": "weak",
+                          "config": {"columns_per_gpu": a.ncol, "shard_starts": starts}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def max_over_ranks(seconds, world, device):
     """the only cross-rank reduction of the benchmark: MAX of the elapsed time"""
     if world <= 1:
@@ -293,7 +330,7 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
         step()
     ev1.record()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, torch.device("cpu"))
     ctx.check(stream)
     dev_ms = ev0.elapsed_time(ev1) / a.steps
     if a.scheme == "gridcomp" and not a.no_overlap:
@@ -407,7 +444,7 @@ def bench_mcica(a, rank, world, dev, local_rank, cpu):
     for _ in range(a.steps):
         step()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, torch.device("cpu"))
     ctx.check(stream)
     prof = ctx.profile_read()
     if rank != 0:
@@ -453,7 +490,14 @@ def main():
     ap.add_argument("--rats", type=int, default=0, help="gridcomp: RATS diagnostics for the first N gases of gridcomp.RAT_GAS (0-8)")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--control-path-only", action="store_true",
+                    help="no GPU work: launcher, rank -> shard, barrier, MAX over ranks and rank 0's JSON line only (CPU rehearsal / tests)")
     a = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:                   # the driver may start us as a plain `python bench.py --gpus N`: become the launcher
+            sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: one rank per GPU" % (a.gpus, os.environ["WORLD_SIZE"]))
     aerosol = not a.no_aerosol
     do_lw, do_sw = "lw" in a.scheme, "sw" in a.scheme
     do_irrad, do_sorad = a.scheme in ("chou", "irrad"), a.scheme in ("chou", "sorad")
@@ -463,6 +507,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if a.control_path_only:
+        return control_path_only(a, rank, world)
 
     cpu = None
     if a.lit < 1.0:
@@ -487,12 +534,13 @@ def main():
     rehearsal = os.environ.get("GEOSRAD_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks but %d visible GPUs (one rank per GPU)" % (world, torch.cuda.device_count()))
     if world > 1:
+        # the path has no data exchange: the ranks meet only in the timing barrier and the MAX of the elapsed time, a
+        # host-side double - gloo carries that; no RCCL communicator is built for it
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -609,19 +657,29 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, dev)
+    elapsed = max_over_ranks(elapsed, world, torch.device("cpu"))
     ctx.check(stream)
     prof = ctx.profile_read()
+    # the dominant kernel's OWN launch duration: with the two solvers on two streams the HIP events around a kernel also cover the time
+    # it shares the GPU with the other solver's kernels, so the roofline figure comes from two further steps enqueued on one stream
+    prof1 = prof
+    if side is not None:
+        sw_stream = stream
+        ctx.profile(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof1 = ctx.profile_read()
 
     if rank == 0:
         total_cols = world * ncol * a.steps
         value = total_cols / elapsed
         # dominant kernel = largest total time; its algorithmic bytes are those of the solver it belongs to
         # (compulsory bytes at the solver API, every input read once + every output written once)
-        cand = {k: v for k, v in prof.items() if k in ("k_lw_bands", "k_sw_bands", "k_chou_bands", "k_sorad_pass") and v[1] > 0}
+        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_sw_bands", "k_chou_bands", "k_sorad_pass") and v[1] > 0}
         kname = max(cand, key=lambda k: cand[k][0])
-        ms, n = prof[kname]
-        launches_per_step = n / a.steps
+        ms, n = prof1[kname]
+        launches_per_step = n / (2 if prof1 is not prof else a.steps)
         if kname == "k_chou_bands":
             abytes = 19476 * a.real // 4                # Chou irrad 3 491 in + 1 378 out reals @72 layers
         elif kname == "k_sorad_pass":
@@ -662,8 +720,8 @@ def main():
                          "columns_per_launch": ncol_k / launches_per_step,
                          "note": "fused k-distribution + two-stream sweep is FP32/latency bound (~170 FLOP per algorithmic byte, "
                                  "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small; `traffic` (PMC) is in "
-                                 "profiles/" + ("; LW and SW kernels run concurrently on two streams, so this kernel's launch duration "
-                                                "includes the time it shares the GPU with the other solver's kernels" if side is not None else "")},
+                                 "profiles/" + ("; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own "
+                                                "duration from two further steps on one stream" if side is not None else "")},
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,
         }

@@ -43,3 +43,25 @@ def test_two_ranks_shard_columns_without_exchange():
             sl = slice(r * n, (r + 1) * n)
             assert allchk[r][0] == float(np.float64(full["tlay"][:, sl]).sum())
             assert allchk[r][1] == float(np.float64(full["cldf"][:, sl]).sum())
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment (as the driver may start it) must become two ranks by
+    itself; --control-path-only keeps the run on the CPU: rendezvous, barrier, MAX over ranks, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--control-path-only", "--ncol", "1000"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["shard_starts"] == [0, 1000]
+    assert out["ms_per_step"] >= 20.0                    # the slower rank (2 x 10 ms) sets the time
+    # a rank count that contradicts --gpus is refused, not silently run on one GPU
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--control-path-only"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "one rank per GPU" in bad.stderr

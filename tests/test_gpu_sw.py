@@ -219,7 +219,7 @@ def test_fresh_context_with_sw_tables_only(rk):
                                 seed_order=(4, 3, 2, 1), prec=kind)
         flips = int((cl != rl.astype(np.int32)).sum())
         assert flips == 0 if rk == 8 else flips <= 1e-5 * cl.size, flips
-        assert cl.sum() > 0.05 * cl.size            # really cloudy: an all-zero alpha (random overlap) or a wild xcw would show here
+        assert cl.sum() > 0.01 * cl.size            # really cloudy: an all-zero alpha (random overlap) or a wild xcw would show here
         ctx.rrtmg_sw_ini()
         g = ctx.rrtmg_sw_columns(inp, iaer=10)
     finally:
