@@ -89,6 +89,27 @@ def main_sw():
         print(name, os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
+# LW cldprmc with the ice parameterisations GEOS does not default to (rrtmg_lw_cldprmc.F90:138-226,270-316): one batch of cloudy
+# columns, the fluxes of the reference for each iceflag (the generator keeps rei inside every parameterisation's valid range)
+ICE_KW = dict(ncol=16, nlay=72, aerosol=True, cloudy_frac=1.0, start=4400)
+ICE_FLAGS = (0, 1, 2, 4)
+
+
+def main_iceflags():
+    inp = synth.make_columns(**ICE_KW)
+    out = {"kw_json": np.array(repr(ICE_KW)), "ih": np.int32(1)}
+    for kind in ("r4", "r8"):
+        reflib.set_inhomogeneity(1, kind)
+        for ice in ICE_FLAGS:
+            r = reflib.rrtmg_lw(inp, kind, iceflg=ice)
+            for k in FLUX:
+                out[f"{kind}_ice{ice}_{k}"] = r[k]
+            out[f"{kind}_ice{ice}_clearCounts"] = r["clearCounts"]
+        reflib.set_inhomogeneity(0, kind)
+    np.savez_compressed(os.path.join(HERE, "lw_iceflags_72.npz"), **out)
+    print("lw_iceflags_72", os.path.getsize(os.path.join(HERE, "lw_iceflags_72.npz")))
+
+
 def main():
     for name, (kw, ih, bo) in CASES.items():
         inp = synth.make_columns(**kw)
@@ -120,7 +141,11 @@ def main():
 
 if __name__ == "__main__":
     import sys
+    if "ice" in sys.argv[1:]:
+        main_iceflags()
+        sys.exit(0)
     if "sw" not in sys.argv[1:]:
         main()
+        main_iceflags()
     if "lw" not in sys.argv[1:]:
         main_sw()

@@ -42,6 +42,24 @@ def test_fluxes_match_reference_golden(gpu_ctx, name, rk):
         assert np.abs(o["dolrb_dTs"] - g[f"{kind}_dolrb_dTs"]).max() <= TOL_DFDT[rk]
 
 
+@pytest.mark.parametrize("ice", [0, 1, 2, 4])
+@pytest.mark.parametrize("rk", [8, 4])
+def test_cldprmc_iceflags_match_reference_golden(gpu_ctx, rk, ice):
+    """LW cldprmc's ice parameterisations other than the GEOS default (rrtmg_lw_cldprmc.F90:138-226,270-316) against the reference's
+    own fluxes (tests/golden/lw_iceflags_72.npz)."""
+    ctx = gpu_ctx[rk]
+    inp, g, ih = load_golden("lw_iceflags_72")
+    kind = _kind(rk)
+    ctx.set_inhomogeneity(ih)
+    o = ctx.rrtmg_lw_columns(inp, iceflg=ice)
+    ctx.set_inhomogeneity(0)
+    for k in FLUX:
+        tol = TOL_DFDT[rk] if "dTs" in k else TOL_FLUX[rk]
+        err = np.abs(o[k].astype(np.float64) - g[f"{kind}_ice{ice}_{k}"].astype(np.float64)).max()
+        assert err <= tol, (k, err)
+    assert np.abs(o["clearCounts"] - g[f"{kind}_ice{ice}_clearCounts"]).max() <= (0 if rk == 8 else 1)
+
+
 @pytest.mark.parametrize("name", ["lw_aer_72", "lw_cloudy_ih2_137"])
 @pytest.mark.parametrize("rk", [8, 4])
 def test_taumol_intermediates_match_reference(gpu_ctx, name, rk):

@@ -72,3 +72,20 @@ def test_oracle_matches_live_reference(kind):
     reflib.set_inhomogeneity(1, kind); clib.set_inhomogeneity(1, kind)
     np.testing.assert_array_equal(clib.zcw_lookup(z, s, kind), reflib.zcw_lookup(z, s, kind))
     reflib.set_inhomogeneity(0, kind); clib.set_inhomogeneity(0, kind)
+
+
+@pytest.mark.parametrize("kind", ["r4", "r8"])
+@pytest.mark.parametrize("ice", [0, 1, 2, 4])
+def test_oracle_cldprmc_iceflags_match_golden_bitwise(kind, ice):
+    """LW cldprmc with the ice parameterisations other than GEOS's default 3 (rrtmg_lw_cldprmc.F90:138-226,270-316): fluxes of the
+    reference itself for iceflag 0, 1, 2, 4 (tests/golden/lw_iceflags_72.npz, made by running oracle/_ref)."""
+    inp, g, ih = load_golden("lw_iceflags_72")
+    clib.set_inhomogeneity(ih, kind)
+    o = clib.rrtmg_lw(inp, kind, iceflg=ice)
+    clib.set_inhomogeneity(0, kind)
+    assert o["rc"] == 0
+    for k in FLUX:
+        np.testing.assert_array_equal(o[k], g[f"{kind}_ice{ice}_{k}"], err_msg=k)
+    np.testing.assert_array_equal(o["clearCounts"], g[f"{kind}_ice{ice}_clearCounts"])
+    if ice != 0:     # the parameterisations really differ on these columns
+        assert np.abs(g[f"{kind}_ice{ice}_uflx"] - g[f"{kind}_ice0_uflx"]).max() > 0.05
