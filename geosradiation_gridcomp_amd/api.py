@@ -225,6 +225,22 @@ class Context:
         self._chk(rc)
         return taug, taur, ssi
 
+    def rrtmg_sw_cldprmc(self, inp, iceflg=3, liqflg=1):
+        """(taucmc, ssacmc, asmcmc) numpy (ncol,112,nlay) == Fortran (nlay,112,ncol): the cloud optics of the solver's own McICA
+        sub-columns as the reference's cldprmc_sw leaves them."""
+        dt = self.dtype
+        nlay, ncol = inp["play"].shape
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        a = {k: c(inp[k]) for k in ["play", "plev", "tlay", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat"] + _SW_GAS}
+        o = [np.zeros((ncol, NGPTSW, nlay), dtype=dt) for _ in range(3)]
+        ci = ctypes.c_int
+        rc = self.L.geosrad_rrtmg_sw_cldprmc(self.h, ci(ncol), ci(nlay), _p(a["play"]), _p(a["plev"]), _p(a["tlay"]),
+                                             *[_p(a[k]) for k in _SW_GAS], ci(iceflg), ci(liqflg), _p(a["cldf"]), _p(a["ciwp"]),
+                                             _p(a["clwp"]), _p(a["rei"]), _p(a["rel"]), ci(int(inp["dyofyr"])), _p(a["zm"]),
+                                             _p(a["alat"]), ci(int(inp["cloudLM"])), ci(int(inp["cloudMH"])), *[_p(x) for x in o])
+        self._chk(rc)
+        return o
+
     def rrtmg_sw_dev(self, stream, ncol, nlay, scon, adjes, isolvar, ptr, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx=0,
                      do_drfband=False, bndscl=None, indsolvar=None, rpart=4):
         """`ptr`: dict name -> device address (int) for every argument array of rrtmg_sw (inputs and outputs)."""

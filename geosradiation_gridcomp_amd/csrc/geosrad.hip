@@ -1496,6 +1496,9 @@ template <typename R> struct Ctx : geosrad_ctx {
                                    (const SwDev<R> *)d_S);
                 span_end(st);
             }
+            if (dbg && dbg[3])       // cldprmc_sw stage dump (6-entry dbg of geosrad_rrtmg_sw_cldprmc)
+                hipLaunchKernelGGL(k_sw_dump_cldprmc<R>, dim3(gx, nlay), blk, 0, st, A, (R *)dbg[3] + (size_t)c0 * NG_SW * nlay,
+                                   (R *)dbg[4] + (size_t)c0 * NG_SW * nlay, (R *)dbg[5] + (size_t)c0 * NG_SW * nlay);
             span_begin(8, st);
             if (dbg) {
                 hipLaunchKernelGGL((k_sw_bands<R, true, true>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
@@ -1559,8 +1562,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         }
         for (int k = 0; k < SO_NOUT; k++) outo[k] = take(outsz[k]);
         const size_t cco = take((size_t)ncol * 4 * sizeof(int32_t) / sizeof(R) + 4);
-        size_t dbgo[3] = {0, 0, 0};
+        size_t dbgo[6] = {0, 0, 0, 0, 0, 0};
         if (dbg) { dbgo[0] = take(cl * NG_SW); dbgo[1] = take(cl * NG_SW); dbgo[2] = take((size_t)ncol * NG_SW); }
+        if (dbg && dbg[3]) { dbgo[3] = take(cl * NG_SW); dbgo[4] = take(cl * NG_SW); dbgo[5] = take(cl * NG_SW); }
         int rc = ensure_io(off);
         if (rc) return rc;
         const void *din[S_NIN]; void *dout[SO_NOUT];
@@ -1569,7 +1573,8 @@ template <typename R> struct Ctx : geosrad_ctx {
             if (din[k]) HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
         }
         for (int k = 0; k < SO_NOUT; k++) dout[k] = (out[k] || k < SO_DRBAND) ? d_io + outo[k] : nullptr;
-        void *ddbg[3] = {d_io + dbgo[0], d_io + dbgo[1], d_io + dbgo[2]};
+        void *ddbg[6] = {d_io + dbgo[0], d_io + dbgo[1], d_io + dbgo[2], nullptr, nullptr, nullptr};
+        if (dbg && dbg[3]) for (int k = 3; k < 6; k++) ddbg[k] = d_io + dbgo[k];
         rc = sw_dev(stream, ncol, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
                     (int32_t *)(d_io + cco), dout, do_drfband, bndscl, indsolvar, dbg ? ddbg : nullptr);
         if (rc) return rc;
@@ -1585,6 +1590,8 @@ template <typename R> struct Ctx : geosrad_ctx {
             HIPCHK(hipMemcpyAsync(dbg[0], ddbg[0], cl * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(dbg[1], ddbg[1], cl * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(dbg[2], ddbg[2], (size_t)ncol * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
+            if (dbg[3])
+                for (int k = 3; k < 6; k++) HIPCHK(hipMemcpyAsync(dbg[k], ddbg[k], cl * NG_SW * sizeof(R), hipMemcpyDeviceToHost, stream));
         }
         HIPCHK(hipStreamSynchronize(stream));
         return GEOSRAD_OK;
@@ -2119,8 +2126,35 @@ int geosrad_rrtmg_sw_taumol(geosrad_ctx *c, int ncol, int nlay, double scon, int
     void *cotdtp = q, *cotdhp = q + cn, *cotdmp = q + 2 * cn, *cotdlp = q + 3 * cn, *cotntp = q + 4 * cn, *cotnhp = q + 5 * cn,
          *cotnmp = q + 6 * cn, *cotnlp = q + 7 * cn, *drband = nullptr, *dfband = nullptr;
     SW_PACK();
-    void *dbg[3] = {taug, taur, ssi};
+    void *dbg[6] = {taug, taur, ssi, nullptr, nullptr, nullptr};
     return c->sw_host(ncol, nlay, scon, 1.0, isolvar, in, 3, 1, 1, 0, 1, 2, 0, cc.data(), out, 0, bndscl, indsolvar, dbg);
+}
+
+int geosrad_rrtmg_sw_cldprmc(geosrad_ctx *c, int ncol, int nlay, const void *play, const void *plev, const void *tlay, const void *h2ovmr,
+                             const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr, int iceflgsw, int liqflgsw,
+                             const void *cld, const void *ciwp, const void *clwp, const void *rei, const void *rel, int dyofyr,
+                             const void *zm, const void *alat, int cloudLM, int cloudMH, void *taucmc, void *ssacmc, void *asmcmc)
+{
+    if (!c || !taucmc || !ssacmc || !asmcmc || ncol <= 0 || nlay <= 0) return GEOSRAD_EINVAL;
+    // the solver's own McICA + cldprmc_sw on these columns (overhead sun, black surface, no aerosol); fluxes are discarded
+    const size_t esz = (size_t)c->real_kind;
+    const size_t cv = (size_t)ncol * (nlay + 1) * esz, cn = (size_t)ncol * esz, cg = (size_t)ncol * nlay * NG_SW * esz;
+    std::vector<char> zero(cn, 0), one(cn, 0), scratch(4 * cv + cn * (6 + 14 + 8) + 2 * cg + cn * NG_SW);
+    for (size_t i = 0; i < (size_t)ncol; i++) { if (esz == 4) ((float *)one.data())[i] = 1.f; else ((double *)one.data())[i] = 1.; }
+    std::vector<int32_t> cc((size_t)ncol * 4);
+    const void *tauaer = nullptr, *ssaaer = nullptr, *asmaer = nullptr, *coszen = one.data(), *asdir = zero.data(), *asdif = zero.data(),
+               *aldir = zero.data(), *aldif = zero.data();
+    char *s = scratch.data();
+    void *swuflx = s, *swdflx = s + cv, *swuflxc = s + 2 * cv, *swdflxc = s + 3 * cv;
+    char *q = s + 4 * cv;
+    void *nirr = q, *nirf = q + cn, *parr = q + 2 * cn, *parf = q + 3 * cn, *uvrr = q + 4 * cn, *uvrf = q + 5 * cn, *fswband = q + 6 * cn;
+    q += 20 * cn;
+    void *cotdtp = q, *cotdhp = q + cn, *cotdmp = q + 2 * cn, *cotdlp = q + 3 * cn, *cotntp = q + 4 * cn, *cotnhp = q + 5 * cn,
+         *cotnmp = q + 6 * cn, *cotnlp = q + 7 * cn, *drband = nullptr, *dfband = nullptr;
+    q += 8 * cn;
+    SW_PACK();
+    void *dbg[6] = {q, q + cg, q + 2 * cg, taucmc, ssacmc, asmcmc};
+    return c->sw_host(ncol, nlay, 1361.0, 1.0, 0, in, iceflgsw, liqflgsw, dyofyr, 0, cloudLM, cloudMH, 0, cc.data(), out, 0, nullptr, nullptr, dbg);
 }
 
 int geosrad_set_tables_chou_lw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_chou_lw(blob, n) : GEOSRAD_EINVAL; }

@@ -871,6 +871,28 @@ __host__ __device__ constexpr int sw_band_ng(int jb)
     return ng[jb - 16];
 }
 
+// Stage dump for the tests: the McICA cloud optics (delta-scaled tau, omega, g) of every (layer, g-point, column) cell in the
+// reference's layout, Fortran (nlay,112,ncol), as cldprmc_sw leaves them (SW/rrtmg_sw_cldprmc.F90:311-392: 0, 1, 0 in clear cells).
+// k_mcica<2> only writes the planes of layers with cloud fraction in cloudy columns; everything else is the default.
+template <typename R>
+__global__ void __launch_bounds__(256) k_sw_dump_cldprmc(SwArgs<R> A, R *__restrict__ taucmc, R *__restrict__ ssacmc, R *__restrict__ asmcmc)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, lay = blockIdx.y;
+    if (col >= A.ncol) return;
+    const int n = A.ncol, nlay = A.nlay, pc = A.perm[col];
+    const bool written = col >= *A.nclear && A.cld[(size_t)lay * A.ld + pc] > 0;
+    for (int jb = 16; jb <= 29; jb++) {
+        const int g0 = sw_band_g0(jb), ng = sw_band_ng(jb);
+        for (int g = 0; g < ng; g++) {
+            const size_t w = (size_t)g0 * nlay * n + ((size_t)lay * ng + g) * n + col;
+            const size_t o = ((size_t)pc * NG_SW + (g0 + g)) * nlay + lay;
+            taucmc[o] = written ? A.taucmc[w] : (R)0;
+            ssacmc[o] = written ? A.ssacmc[w] : (R)1;
+            asmcmc[o] = written ? A.asmcmc[w] : (R)0;
+        }
+    }
+}
+
 template <typename R, bool CLD, bool DBG>
 __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? 2 : 1)) k_sw_bands(SwArgs<R> A, SwDev<R> T, SwSolar<R> SV)
 {

@@ -199,6 +199,14 @@ int geosrad_rrtmg_sw_taumol(geosrad_ctx *ctx, int ncol, int nlay, double scon, i
                             const void *play, const void *plev, const void *tlay,
                             const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
                             const void *bndscl, const void *indsolvar, void *taug, void *taur, void *ssi);
+/* Debug / test hook: the McICA cloud optics of the solver's own sub-columns - delta-scaled optical depth, single-scattering
+ * albedo and asymmetry parameter, Fortran (nlay,112,ncol), as the reference's cldprmc_sw leaves taucmc, ssacmc, asmcmc
+ * (SW/rrtmg_sw_cldprmc.F90:36-418; 0, 1, 0 in clear cells); host pointers. */
+int geosrad_rrtmg_sw_cldprmc(geosrad_ctx *ctx, int ncol, int nlay, const void *play, const void *plev, const void *tlay,
+                             const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
+                             int iceflgsw, int liqflgsw, const void *cld, const void *ciwp, const void *clwp, const void *rei,
+                             const void *rel, int dyofyr, const void *zm, const void *alat, int cloudLM, int cloudMH,
+                             void *taucmc, void *ssacmc, void *asmcmc);
 
 /* ---- Chou-Suarez longwave ------------------------------------------------------------------------------
  * irrad (GEOSirrad_GridComp/irrad.F90:27-35), same argument order (the logical `trace` as int).  Layers from the TOP down

@@ -1,0 +1,70 @@
+"""GPU, BASELINE.json's large configurations at full per-GPU size (pytest -m gpu), checked through size-independent properties and
+against the oracle on a few of the columns:
+  configs[4]: C720 tile / 8 GPUs = 388 800 columns x 137 layers.  The RRTMGP source and coefficient files are not in the reference
+              repository, so the RRTMG kernels run this size as the HBM-pressure / deep-atmosphere stand-in.
+  configs[2]: 100 000 columns through the Chou-Suarez pair irrad + sorad in ONE launch each (tests/test_gpu_chou.py)."""
+import numpy as np
+import pytest
+from tests.conftest import sub_columns
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile(inp, times):
+    ncol = inp["play"].shape[-1]
+    return {k: (np.ascontiguousarray(np.concatenate([v] * times, axis=-1)) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v)
+            for k, v in inp.items()}
+
+
+def test_c720_share_137_layers(gpu_ctx):
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    ctx = gpu_ctx[4]
+    base_n, times, nlay = 24_300, 16, 137
+    n = base_n * times                                   # 388 800 = 6 * 720^2 / 8
+    base = synth.make_columns(base_n, nlay, start=720_000, cloudy_frac=0.6, aerosol=True)
+    inp = _tile(base, times)                             # columns are independent: a tiled batch exercises the size, not new physics
+    assert inp["play"].shape == (nlay, n)
+    ctx.set_inhomogeneity(1)
+    ctx.set_chunk(65_536)                                # 6 batches: workspace for 65 536 columns, results independent of the batching
+    try:
+        lw = ctx.rrtmg_lw_columns(inp)
+        sw = ctx.rrtmg_sw_columns(inp, iaer=10, normFlx=1)
+        # the same columns alone, default batching: bitwise (a column never depends on its batch or its neighbours)
+        ctx.set_chunk(131_072)
+        sl = slice(5 * base_n + 1234, 5 * base_n + 1234 + 321)
+        shard = {k: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == n else v) for k, v in inp.items()}
+        lw1 = ctx.rrtmg_lw_columns(shard)
+        sw1 = ctx.rrtmg_sw_columns(shard, iaer=10, normFlx=1)
+    finally:
+        ctx.set_chunk(131_072)
+        ctx.set_inhomogeneity(0)
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "clearCounts"):
+        assert np.isfinite(lw[k]).all(), k
+        np.testing.assert_array_equal(lw1[k], lw[k][..., sl], err_msg=k)
+    for k in ("swuflx", "swdflx", "swuflxc", "swdflxc", "fswband", "clearCounts"):
+        assert np.isfinite(sw[k]).all(), k
+        np.testing.assert_array_equal(sw1[k], sw[k][..., sl], err_msg=k)
+    # tiles are copies of one another
+    for t in (1, 7, 15):
+        np.testing.assert_array_equal(lw["uflx"][:, t * base_n:(t + 1) * base_n], lw["uflx"][:, :base_n])
+        np.testing.assert_array_equal(sw["swdflx"][:, t * base_n:(t + 1) * base_n], sw["swdflx"][:, :base_n])
+    # physics that needs no oracle
+    clear = ~(inp["cldf"] > 0).any(axis=0)
+    np.testing.assert_array_equal(lw["uflx"][:, clear], lw["uflxc"][:, clear])
+    np.testing.assert_array_equal(sw["swuflx"][:, clear], sw["swuflxc"][:, clear])
+    assert (lw["clearCounts"][:, clear] == 140).all() and (sw["clearCounts"][:, clear] == 112).all()
+    assert (lw["dflx"][nlay] == 0).all() and (lw["uflx"][nlay] > 50).all() and (lw["uflx"][nlay] < 450).all()
+    np.testing.assert_allclose(sw["swdflx"][nlay], 1.0, rtol=2e-6)            # normalised fluxes: TOA down = 1
+    net = sw["swdflx"].astype(np.float64) - sw["swuflx"]
+    assert ((np.diff(net, axis=0) < -1e-3).any(axis=0)).mean() <= 1e-3        # the atmosphere only absorbs (fp32 singularity aside)
+    # spot parity against the oracle (LW: pinned to the reference) on 12 of the columns
+    s12 = sub_columns(shard, 12)
+    clib.set_inhomogeneity(1, "r4")
+    r = clib.rrtmg_lw(s12, "r4"); q = clib.rrtmg_sw(s12, prec="r4", iaer=10, normFlx=1)
+    clib.set_inhomogeneity(0, "r4")
+    for k in ("uflx", "dflx", "uflxc", "dflxc"):
+        assert np.abs(lw1[k][:, :12].astype(np.float64) - r[k]).max() <= 2e-3, k
+    same = (sw1["clearCounts"][:, :12] == q["clearCounts"]).all(axis=0)
+    for k in ("swuflx", "swdflx"):
+        assert (np.abs(sw1[k][:, :12].astype(np.float64) - q[k]) <= 5e-3)[:, same].all(), k
