@@ -107,7 +107,15 @@ def test_sorad_properties(gpu_ctx):
     p = ctx.sorad_columns(sub, do_drfband=True)
     for k in SO_KEYS:
         np.testing.assert_array_equal(p[k], a[k][..., 1000:1300], err_msg=k)
-    # consistent with RRTMG_SW on the same profiles: clear-sky planetary albedo (different spectral grids and aerosol bands)
-    r = ctx.rrtmg_sw_columns(inp, normFlx=1, iaer=10)
-    d = np.abs(a["flcu"][0] - r["swuflxc"][-1])
-    assert d.max() < 0.08 and np.median(d) < 0.02
+    # consistent with RRTMG_SW on the same profiles: clear-sky planetary albedo.  The two schemes see the aerosols on different
+    # spectral grids (8 Chou bands, 14 RRTMG bands); synth draws every band's optical depth independently, so at low sun (slant path
+    # 1/mu0 up to 20) the schemes are handed different aerosol columns in the same part of the spectrum - that, not the schemes, was
+    # the 0.055 outlier of round 1 (column with mu0 = 0.07; tests/test_oracle_chou.py::test_sorad_vs_rrtmg_sw_aerosol_spectral_consistency).
+    # With spectrally flat aerosols the difference is the clear-sky scheme difference itself (<= 0.02 of the insolation, fp64).
+    flat = dict(inp)
+    for k in ("tauaer_sw", "ssaaer_sw", "asmaer_sw"):
+        flat[k] = np.ascontiguousarray(np.repeat(inp[k][3:4], 14, axis=0))
+    af = ctx.sorad_columns(synth.chou_sw_inputs(flat, aerosol=True))
+    r = ctx.rrtmg_sw_columns(flat, normFlx=1, iaer=10)
+    d = np.abs(af["flcu"][0] - r["swuflxc"][-1])
+    assert d.max() < 0.03 and np.median(d) < 0.012, (d.max(), np.median(d))

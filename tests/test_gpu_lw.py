@@ -406,3 +406,34 @@ def test_standalone_generator_full_size_is_batch_independent(gpu_ctx):
         torch.cuda.empty_cache()
     finally:
         ctx.set_inhomogeneity(0)
+
+
+def test_fp32_discrete_flip_rate(gpu_ctx):
+    """SURVEY 7 hard part 1: the fp32 instantiation cannot be bit-identical to the reference's r4 build where a DISCRETE decision hangs
+    on the last bit of a transcendental (ocml vs libm).  The McICA decisions are the ones with visible consequences (`cdf2 < alpha`,
+    `cdf2 < rcorr` with alpha, rcorr = exp(-dz/L), cloud_subcol_gen.F90:314-321,411,424): measured here over 2 000 cloudy columns
+    against the reference-pinned r4 oracle, for both seedings, and bounded.  (fp64: zero flips, asserted in
+    test_mcica_generator_matches_reference.)"""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    ctx = gpu_ctx[4]
+    n = 2000
+    inp = synth.make_columns(n, 72, start=250_000, cloudy_frac=1.0)
+    ctx.set_inhomogeneity(1); clib.set_inhomogeneity(1, "r4")
+    try:
+        for nsub, so in ((140, (1, 2, 3, 4)), (112, (4, 3, 2, 1))):
+            cl, ci, cw = ctx.generate_stochastic_clouds(n, nsub, 72, inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"],
+                                                        inp["ciwp"], inp["clwp"], 1e-20, seed_order=so)
+            rl, ri, rw = clib.mcica(inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"], inp["ciwp"], inp["clwp"], nsub,
+                                    seed_order=so, prec="r4")
+            cells = (inp["cldf"] > 0).sum() * nsub                       # cells in which a decision is taken at all
+            mask_flips = int((cl != rl.astype(np.int32)).sum())
+            same = cl == rl.astype(np.int32)
+            wp_flips = int((np.abs(cw[same] - rw[same]) > 1e-5 * np.maximum(np.abs(rw[same]), 1e-30)).sum()
+                           + (np.abs(ci[same] - ri[same]) > 1e-5 * np.maximum(np.abs(ri[same]), 1e-30)).sum())
+            cols = int((cl != rl.astype(np.int32)).any(axis=(1, 2)).sum())
+            print(f"fp32 flip rate, nsubcol {nsub}: {mask_flips} mask flips and {wp_flips} condensate-rank flips in {cells} cloudy-layer "
+                  f"cells ({mask_flips / cells:.2e}, {wp_flips / cells:.2e}); {cols} of {n} columns have a flipped mask cell")
+            assert mask_flips <= 2e-5 * cells and wp_flips <= 2e-4 * cells and cols <= 0.01 * n
+    finally:
+        ctx.set_inhomogeneity(0); clib.set_inhomogeneity(0, "r4")

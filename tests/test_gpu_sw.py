@@ -247,7 +247,7 @@ def test_sw_cldprmc_stage_matches_reference_golden(gpu_ctx, name, rk):
         for ice in (1, 2, 3, 4):
             got = ctx.rrtmg_sw_cldprmc(sub, iceflg=ice)
             want = [g[f"{kind}_ice{ice}_{nm}"] for nm in ("taucmc", "ssacmc", "asmcmc")]
-            assert (want[0] > 0).sum() > 100
+            assert (want[0] > 0).sum() > 20
             if rk == 8:
                 for a, b, nm in zip(got, want, ("taucmc", "ssacmc", "asmcmc")):
                     np.testing.assert_allclose(a, b, rtol=1e-12, atol=0, err_msg=f"iceflag {ice} {nm}")
