@@ -29,25 +29,30 @@ _lib = None
 
 
 def build(force=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
-    srcs.append(os.path.join(os.path.dirname(HERE), "include", "geosrad.h"))
-    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
-        return SO
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Objects (compiled in parallel, each rebuilt only when one of
+    the files it includes is newer): geosrad.hip three times - fp32 kernels, fp64 kernels, the extern "C" layer - and lw_cols.hip
+    (the on-chip RRTMG_LW band sweeps) twice - fp32, fp64."""
+    inc = os.path.join(os.path.dirname(HERE), "include", "geosrad.h")
+    hpp = {f: os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")}
+    cols_only = {"lw_cols_kernels.hpp"}                       # headers geosrad.hip does not include
+    deps_main = [os.path.join(CSRC, "geosrad.hip"), inc] + [p for f, p in hpp.items() if f not in cols_only]
+    deps_cols = [os.path.join(CSRC, "lw_cols.hip")] + [hpp[f] for f in ("lw_cols_kernels.hpp", "lw_cols.hpp", "lw_kernels.hpp", "lw_device.hpp")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # one source, three objects compiled in parallel: fp32 kernels, fp64 kernels, the extern "C" layer
-    src = os.path.join(CSRC, "geosrad.hip")
     objdir = os.path.join(os.path.dirname(HERE), "build", "obj")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-    jobs = []
-    for part in (4, 8, 0):
-        obj = os.path.join(objdir, f"geosrad_part{part}.o")
-        jobs.append((obj, subprocess.Popen([hipcc, *flags, f"-DGEOSRAD_PART={part}", "-c", src, "-o", obj])))
-    for obj, pr in jobs:
+    units = [("geosrad.hip", part, deps_main) for part in (4, 8, 0)] + [("lw_cols.hip", part, deps_cols) for part in (4, 8)]
+    jobs, objs = [], []
+    for src, part, deps in units:
+        obj = os.path.join(objdir, f"{src[:-4]}_part{part}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            jobs.append(subprocess.Popen([hipcc, *flags, f"-DGEOSRAD_PART={part}", "-c", os.path.join(CSRC, src), "-o", obj]))
+    for pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, pr.args)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _ in jobs], "-o", SO])
+    if jobs or not os.path.exists(SO) or any(os.path.getmtime(SO) < os.path.getmtime(o) for o in objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", SO])
     return SO
 
 

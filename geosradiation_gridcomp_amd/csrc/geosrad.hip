@@ -21,6 +21,7 @@
 #include "chou_kernels.hpp"
 #include "sorad_kernels.hpp"
 #include "gridcomp_kernels.hpp"
+#include "lw_cols.hpp"
 
 using namespace geosrad;
 
@@ -197,6 +198,7 @@ static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vm
 // ---------------------------------------------------------------------------------------------------
 struct geosrad_ctx {
     int device = 0, real_kind = 4, chunk = 131072;
+    bool lw_cols_path = false;      // RRTMG_LW band sweeps: parked cells in HBM (default) | GEOSRAD_LW_PATH=cols: on-chip intermediates
     std::string last_error;
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     // optional per-kernel timing with HIP events recorded on the launch stream (geosrad_profile*)
@@ -723,20 +725,27 @@ template <typename R> struct Ctx : geosrad_ctx {
                 hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
                 span_end(st);
             }
-            span_begin(4, st);
+            auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
+            O.uflx = Q(O_UFLX); O.dflx = Q(O_DFLX); O.uflxc = Q(O_UFLXC); O.dflxc = Q(O_DFLXC);
+            O.duflx_dTs = Q(O_DUFLX); O.duflxc_dTs = Q(O_DUFLXC);
+            O.olrb = (R *)out[O_OLRB]; O.dolrb_dTs = (R *)out[O_DOLRB]; O.col0 = c0;
             const size_t lds = lw_bands_lds_bytes<R>();
-            if (A.dbg_taug) {
+            // band sweeps.  lw_cols: (layer, g-point) intermediates in LDS, fluxes written directly (lw_cols_kernels.hpp);
+            // lw_bands: lane = column with the parked (a, B-up) pairs in HBM + the band reduction (the RATS passes need its per-band
+            // partials, so a call with RATS diagnostics takes that path throughout)
+            const bool cols = lw_cols_path && !(rats && rats->n > 0);
+            span_begin(4, st);
+            if (cols) {
+                hipError_t e = lw_cols_launch<R>(st, A, O, h_T, A.dbg_taug != nullptr);
+                if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("lw_cols_launch: ") + hipGetErrorString(e));
+            } else if (A.dbg_taug) {
                 hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             } else {
                 hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             }
             span_end(st);
-            auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
-            O.uflx = Q(O_UFLX); O.dflx = Q(O_DFLX); O.uflxc = Q(O_UFLXC); O.dflxc = Q(O_DFLXC);
-            O.duflx_dTs = Q(O_DUFLX); O.duflxc_dTs = Q(O_DUFLXC);
-            O.olrb = (R *)out[O_OLRB]; O.dolrb_dTs = (R *)out[O_DOLRB]; O.col0 = c0;
-            span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, A, O); span_end(st);
+            if (!cols) { span_begin(5, st); hipLaunchKernelGGL(k_lw_reduce<R>, dim3(gx, nlay + 1), blk, 0, st, A, O); span_end(st); }
 
             // RATS diagnostics (GEOS_IrradGridComp.F90:3405-3468): the reference calls the whole of rrtmg_lw once more per listed
             // gas with that gas's mixing ratio set to zero and keeps the total-sky uflx, dflx, duflx_dTs of each call.  Nothing
@@ -1988,6 +1997,10 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return GEOSRAD_ENODEV;
     geosrad_ctx *c = real_kind == 4 ? geosrad_new_ctx_f32() : geosrad_new_ctx_f64();
     c->device = device_id; c->real_kind = real_kind;
+    {   // A/B switch for the measurements in profiles/: GEOSRAD_LW_PATH=cols | bands
+        const char *e = getenv("GEOSRAD_LW_PATH");
+        if (e) c->lw_cols_path = !strcmp(e, "cols");
+    }
     int rc = c->init();
     if (rc) { delete c; return rc; }
     *out = c;

@@ -284,22 +284,27 @@ template <typename R> GR_DEV R colamt_nz(const R *__restrict__ vmr, const Layer<
     return c == (R)0 ? (R)1.e-32 * L.coldry : c;
 }
 
-// W consecutive reals of a table row (W = 4 or 2), 16-byte aligned: uniform table base + per-lane byte offset
+// W consecutive reals of a table row (W = 2 or a multiple of 4), 16-byte aligned: uniform table base + per-lane byte offset,
+// 16 bytes per load instruction (the later pieces of a row at immediate offsets from the same address register)
 template <typename R, int W> GR_DEV void ldw(const R *__restrict__ tab, uint32_t byteoff, R (&o)[W])
 {
-    if constexpr (sizeof(R) == 4 && W == 4) {
-        const float4 v = ldg(reinterpret_cast<const float4 *>(tab), byteoff);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    } else if constexpr (sizeof(R) == 4 && W == 2) {
+    if constexpr (sizeof(R) == 4 && W == 2) {
         const float2 v = ldg(reinterpret_cast<const float2 *>(tab), byteoff);
         o[0] = v.x; o[1] = v.y;
-    } else if constexpr (sizeof(R) == 8 && W == 4) {
-        const double2 a = ldg(reinterpret_cast<const double2 *>(tab), byteoff);
-        const double2 b = ldg(reinterpret_cast<const double2 *>(tab), byteoff + 16u);
-        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    } else if constexpr (sizeof(R) == 4) {
+        static_assert(W % 4 == 0, "row pieces are whole 16-byte groups");
+#pragma unroll
+        for (int k = 0; k < W / 4; k++) {
+            const float4 v = ldg(reinterpret_cast<const float4 *>(tab), byteoff + 16u * (uint32_t)k);
+            o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+        }
     } else {
-        const double2 a = ldg(reinterpret_cast<const double2 *>(tab), byteoff);
-        o[0] = a.x; o[1] = a.y;
+        static_assert(W % 2 == 0, "row pieces are whole 16-byte groups");
+#pragma unroll
+        for (int k = 0; k < W / 2; k++) {
+            const double2 a = ldg(reinterpret_cast<const double2 *>(tab), byteoff + 16u * (uint32_t)k);
+            o[2 * k] = a.x; o[2 * k + 1] = a.y;
+        }
     }
 }
 // byte offset of row r (0-based) of a [rows][S] table, columns go..go+W-1
