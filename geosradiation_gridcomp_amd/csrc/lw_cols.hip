@@ -43,7 +43,8 @@ template <typename R> hipError_t lw_cols_launch(hipStream_t st, const LwArgs<R> 
 #else
     if (C == CMAX) return lwc_launch_c<R, CMAX>(st, A, O, T);
     if (C == CMAX / 2) return lwc_launch_c<R, CMAX / 2>(st, A, O, T);
-    return lwc_launch_c<R, CMIN>(st, A, O, T);
+    if (C == CMIN) return lwc_launch_c<R, CMIN>(st, A, O, T);
+    return lwc_launch_c<R, (CMAX / 4 > 0 ? CMAX / 4 : 1)>(st, A, O, T);
 #endif
 }
 

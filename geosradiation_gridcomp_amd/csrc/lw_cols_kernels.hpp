@@ -26,26 +26,30 @@ namespace geosrad {
 
 template <bool CLD> struct LwcK { static constexpr int GR = CLD ? 4 : 8, NST = CLD ? 2 : 1, NPL = 3 * NST; };
 
-// LDS plane stride (reals) of one g-point's [layer][column] plane: padded so that the planes of consecutive g-points start C banks
-// apart - the sweep wave (lanes = column fastest, then g-point) then reads 32 different banks per half-wave
-__host__ __device__ constexpr int lwc_plane_stride(int nlay, int C)
-{
-    return nlay * C + ((C - (nlay * C) % 32) % 32 + 32) % 32;
-}
-// one plane buffer (reals): NPL x GR planes, then per (g-point, column): Planck fraction of the lowest layer, upward radiance at the
-// surface per sky, its derivative
+// LDS layout of a plane buffer: [plane][g-point][column][layer], the layers of one (plane, g-point, column) contiguous and padded to
+// LS = 4 x odd reals: the sweep wave (lane i = column + C x g-point, i x LS reals apart) reads four layers per 16-byte access without
+// bank conflicts, and so do the workers (lane = column fastest, then layer) with their 4-byte accesses.  Padding layers hold a zero
+// absorptivity: the recurrences pass through them unchanged.
+__host__ __device__ constexpr int lwc_layer_stride(int nlay) { return 4 * (((nlay + 3) / 4) | 1); }
+// one plane buffer (reals): NPL x GR x C layer runs, then per (g-point, column): Planck fraction of the lowest layer, upward radiance at
+// the surface per sky, its derivative
 template <bool CLD> __host__ __device__ constexpr size_t lwc_buf_reals(int nlay, int C)
 {
-    return (size_t)LwcK<CLD>::NPL * LwcK<CLD>::GR * lwc_plane_stride(nlay, C) + (size_t)LwcK<CLD>::GR * C * (2 + LwcK<CLD>::NST);
+    return (size_t)LwcK<CLD>::NPL * LwcK<CLD>::GR * C * lwc_layer_stride(nlay) + (((size_t)LwcK<CLD>::GR * C * (2 + LwcK<CLD>::NST) + 3) & ~(size_t)3);
 }
+// + (cloudy instantiation) the workers' ten flux totals [10][workers]: touched once per band, they would cost ten registers each
 template <typename R, bool CLD> __host__ __device__ constexpr size_t lwc_lds_bytes(int nlay, int C)
 {
-    return 2 * lwc_buf_reals<CLD>(nlay, C) * sizeof(R);
+    return (2 * lwc_buf_reals<CLD>(nlay, C) + (CLD ? (size_t)10 * ((C * nlay + 63) / 64 * 64) : 0)) * sizeof(R);
 }
 // columns per block: C x nlay workers must fit 576 threads and the two plane buffers 112 KiB of LDS
+#ifndef LWC_CMAX
+#define LWC_CMAX 8
+#endif
 template <typename R> __host__ __device__ constexpr int lwc_columns_per_block(int nlay)
 {
-    return sizeof(R) == 4 ? (nlay <= 72 ? 8 : (nlay <= 144 ? 4 : 2)) : (nlay <= 72 ? 4 : (nlay <= 144 ? 2 : 1));
+    return sizeof(R) == 4 ? (nlay <= 72 ? LWC_CMAX : (nlay <= 144 ? LWC_CMAX / 2 : LWC_CMAX / 4))
+                          : (nlay <= 72 ? LWC_CMAX / 2 : (nlay <= 144 ? LWC_CMAX / 4 : 1));
 }
 constexpr int LWC_MAXT = 640;        // 576 workers + the sweep wave
 
@@ -53,23 +57,23 @@ constexpr int LWC_MAXT = 640;        // 576 workers + the sweep wave
 template <typename R> struct LwcStage { R sumfac; int ib, nvalid; bool band_end; };
 template <typename R> struct LwcAcc { R d, u, u0, du, du0, dc, uc, uc0, duc, duc0; };
 
-#define LWC_CELL(buf, plane, gl, lay_, c_) ((buf) + ((size_t)((plane) * GR + (gl)) * PS + (size_t)(lay_) * C + (c_)))
+#define LWC_CELL(buf, plane, gl, lay_, c_) ((buf) + ((size_t)(((plane) * GR + (gl)) * C + (c_)) * PS + (size_t)(lay_)))
 
 // ---- phase 2: lane = (column c, g-point gl, sky s): down the column, turn at the surface, up again (:245-379) ----------------------
 // planes of sky s: 3s + 0 absorptivity (after the up sweep: d(upward radiance)/dTs), 3s + 1 source down (then: downward radiance at
 // the layer's lower level), 3s + 2 source up (then: upward radiance at the layer's upper level).
-// The sweeps go through the planes in chunks of 8 layers, requested together one chunk ahead of the arithmetic (a step is two
-// dependent operations, an LDS read fifty times that) - ping-pong registers, no copies, no bounds tests in the chunk loop.
+// A lane's layers are contiguous: the sweeps read and write them four at a time (one 16-byte LDS access), two such vectors per
+// step of a ping-pong that requests the next eight layers before it works on the current eight (a step of the recurrence is two
+// dependent operations, an LDS read fifty times that).  No bounds tests: padding layers have zero absorptivity.
+template <typename R> struct alignas(4 * sizeof(R)) LwcVec4 { R v[4]; };
 template <typename R, bool CLD, int C>
 GR_DEV void lwc_sweep(const LwArgs<R> &A, const LwDev<R> &T, R *__restrict__ buf, int PS, int nlay, const LwcStage<R> &st, int c, int gl,
                       int s, int pc)
 {
     using K = LwcK<CLD>;
-    constexpr int GR = K::GR, NST = K::NST, CH = 8;
+    using V4 = LwcVec4<R>;
+    constexpr int GR = K::GR, NST = K::NST;
     if (gl >= st.nvalid) return;
-#ifdef LWC_X_NOSWEEP            // timing experiments only (results are wrong)
-    return;
-#endif
     const bool dudTs = A.dudTs != 0;
     // surface terms of this band (:319-333)
     const R semis = A.emis[(size_t)(st.ib - 1) * A.ld + pc];
@@ -77,84 +81,78 @@ GR_DEV void lwc_sweep(const LwArgs<R> &A, const LwDev<R> &T, R *__restrict__ buf
     const R plankbnd = semis * planck_at<R>(T.totplnk, st.ib, tb);
     const R dplankbnd = dudTs ? semis * planck_at<R>(T.totplnkderiv, st.ib, tb) : (R)0;
     const R reflect = (R)1. - semis;
-    R *const pa = LWC_CELL(buf, 3 * s + 0, gl, 0, c), *const pd = LWC_CELL(buf, 3 * s + 1, gl, 0, c), *const pu = LWC_CELL(buf, 3 * s + 2, gl, 0, c);
-    R *const pf0 = buf + (size_t)K::NPL * GR * PS, *const u0 = pf0 + GR * C, *const dl0 = u0 + NST * GR * C;
-    const int nfull = nlay / CH, nrem = nlay - nfull * CH;
+    V4 *const pa = reinterpret_cast<V4 *>(LWC_CELL(buf, 3 * s + 0, gl, 0, c)), *const pd = reinterpret_cast<V4 *>(LWC_CELL(buf, 3 * s + 1, gl, 0, c)),
+       *const pu = reinterpret_cast<V4 *>(LWC_CELL(buf, 3 * s + 2, gl, 0, c));
+    R *const pf0 = buf + (size_t)K::NPL * GR * C * PS, *const u0 = pf0 + GR * C, *const dl0 = u0 + NST * GR * C;
+    const int nv = (nlay + 3) / 4;           // 4-layer vectors, the last one possibly with padding layers
     R rad = 0;
-    // ---- downward: layers nlay-1 .. 0 ----
-    int l = nlay - 1;
-    for (int i = 0; i < nrem; i++, l--) { rad = rad + (pd[l * C] - rad) * pa[l * C]; pd[l * C] = rad; }
+    // one 4-layer vector of the downward sweep (layers 4v+3 .. 4v) / of the upward sweep (4v .. 4v+3)
+    auto down4 = [&](V4 &a, V4 &b) {
+#pragma unroll
+        for (int i = 3; i >= 0; i--) { rad = rad + (b.v[i] - rad) * a.v[i]; b.v[i] = rad; }
+    };
+    R dl = 0;
+    auto up4 = [&](V4 &a, V4 &b) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { rad = rad + (b.v[i] - rad) * a.v[i]; b.v[i] = rad; if (dudTs) { dl = dl - dl * a.v[i]; a.v[i] = dl; } }
+    };
+    // ---- downward: vectors nv-1 .. 0 ----
     {
-        R xa[CH], xb[CH], ya[CH], yb[CH];
-        if (nfull > 0) {
-#pragma unroll
-            for (int i = 0; i < CH; i++) { xa[i] = pa[(l - i) * C]; xb[i] = pd[(l - i) * C]; }
-        }
-        for (int k = 0; k < nfull; k += 2) {
-            if (k + 1 < nfull) {
-#pragma unroll
-                for (int i = 0; i < CH; i++) { ya[i] = pa[(l - CH - i) * C]; yb[i] = pd[(l - CH - i) * C]; }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; i++) { rad = rad + (xb[i] - rad) * xa[i]; xb[i] = rad; }
-#pragma unroll
-            for (int i = 0; i < CH; i++) pd[(l - i) * C] = xb[i];
-            l -= CH;
-            if (k + 1 < nfull) {
-                if (k + 2 < nfull) {
-#pragma unroll
-                    for (int i = 0; i < CH; i++) { xa[i] = pa[(l - CH - i) * C]; xb[i] = pd[(l - CH - i) * C]; }
-                }
-#pragma unroll
-                for (int i = 0; i < CH; i++) { rad = rad + (yb[i] - rad) * ya[i]; yb[i] = rad; }
-#pragma unroll
-                for (int i = 0; i < CH; i++) pd[(l - i) * C] = yb[i];
-                l -= CH;
-            }
+        int v = nv - 1;
+        if (nv & 1) { V4 a = pa[v], b = pd[v]; down4(a, b); pd[v] = b; v--; }
+        V4 xa0, xb0, xa1, xb1, ya0, yb0, ya1, yb1;
+        if (v >= 1) { xa0 = pa[v]; xb0 = pd[v]; xa1 = pa[v - 1]; xb1 = pd[v - 1]; }
+        while (v >= 1) {
+            const bool more = v >= 3;
+            if (more) { ya0 = pa[v - 2]; yb0 = pd[v - 2]; ya1 = pa[v - 3]; yb1 = pd[v - 3]; }
+            down4(xa0, xb0); down4(xa1, xb1);
+            pd[v] = xb0; pd[v - 1] = xb1;
+            v -= 2;
+            if (!more) break;
+            if (v >= 3) { xa0 = pa[v - 2]; xb0 = pd[v - 2]; xa1 = pa[v - 3]; xb1 = pd[v - 3]; }
+            down4(ya0, yb0); down4(ya1, yb1);
+            pd[v] = yb0; pd[v - 1] = yb1;
+            v -= 2;
         }
     }
     // ---- surface: emission + reflection turn the downward radiance into the upward one (:319-333) ----
     const R pfs = pf0[gl * C + c];
     const R rad0 = pfs * plankbnd;
     rad = rad0 + reflect * rad;
-    R dl = pfs * dplankbnd;
+    dl = pfs * dplankbnd;
     u0[s * GR * C + gl * C + c] = rad;
     if (s == 0) dl0[gl * C + c] = dl;
-    // ---- upward: layers 0 .. nlay-1 ----
-    l = 0;
+    // ---- upward: vectors 0 .. nv-1 ----
     {
-        R xa[CH], xb[CH], ya[CH], yb[CH];
-        if (nfull > 0) {
-#pragma unroll
-            for (int i = 0; i < CH; i++) { xa[i] = pa[(l + i) * C]; xb[i] = pu[(l + i) * C]; }
+        int v = 0;
+        const int nv2 = nv & ~1;
+        V4 xa0, xb0, xa1, xb1, ya0, yb0, ya1, yb1;
+        if (nv2 >= 2) { xa0 = pa[0]; xb0 = pu[0]; xa1 = pa[1]; xb1 = pu[1]; }
+        while (v < nv2) {
+            const bool more = v + 2 < nv2;
+            if (more) { ya0 = pa[v + 2]; yb0 = pu[v + 2]; ya1 = pa[v + 3]; yb1 = pu[v + 3]; }
+            up4(xa0, xb0); up4(xa1, xb1);
+            pu[v] = xb0; pu[v + 1] = xb1;
+            if (dudTs) { pa[v] = xa0; pa[v + 1] = xa1; }
+            v += 2;
+            if (!more) break;
+            if (v + 2 < nv2) { xa0 = pa[v + 2]; xb0 = pu[v + 2]; xa1 = pa[v + 3]; xb1 = pu[v + 3]; }
+            up4(ya0, yb0); up4(ya1, yb1);
+            pu[v] = yb0; pu[v + 1] = yb1;
+            if (dudTs) { pa[v] = ya0; pa[v + 1] = ya1; }
+            v += 2;
         }
-        for (int k = 0; k < nfull; k += 2) {
-            if (k + 1 < nfull) {
-#pragma unroll
-                for (int i = 0; i < CH; i++) { ya[i] = pa[(l + CH + i) * C]; yb[i] = pu[(l + CH + i) * C]; }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; i++) { rad = rad + (xb[i] - rad) * xa[i]; xb[i] = rad; if (dudTs) { dl = dl - dl * xa[i]; xa[i] = dl; } }
-#pragma unroll
-            for (int i = 0; i < CH; i++) { pu[(l + i) * C] = xb[i]; if (dudTs) pa[(l + i) * C] = xa[i]; }
-            l += CH;
-            if (k + 1 < nfull) {
-                if (k + 2 < nfull) {
-#pragma unroll
-                    for (int i = 0; i < CH; i++) { xa[i] = pa[(l + CH + i) * C]; xb[i] = pu[(l + CH + i) * C]; }
-                }
-#pragma unroll
-                for (int i = 0; i < CH; i++) { rad = rad + (yb[i] - rad) * ya[i]; yb[i] = rad; if (dudTs) { dl = dl - dl * ya[i]; ya[i] = dl; } }
-#pragma unroll
-                for (int i = 0; i < CH; i++) { pu[(l + i) * C] = yb[i]; if (dudTs) pa[(l + i) * C] = ya[i]; }
-                l += CH;
-            }
+        if (nv & 1) {
+            V4 a = pa[v], b = pu[v];
+            up4(a, b);
+            pu[v] = b;
+            if (dudTs) pa[v] = a;
         }
     }
-    for (int i = 0; i < nrem; i++, l++) {
-        const R a = pa[l * C];
-        rad = rad + (pu[l * C] - rad) * a; pu[l * C] = rad;
-        if (dudTs) { dl = dl - dl * a; pa[l * C] = dl; }
+    // the padding layers' absorptivity stays zero for the next stage that uses this buffer
+    if (dudTs && (nlay & 3)) {
+        R *const z = reinterpret_cast<R *>(pa);
+        for (int l = nlay; l < 4 * nv; l++) z[l] = 0;
     }
 }
 
@@ -162,13 +160,13 @@ GR_DEV void lwc_sweep(const LwArgs<R> &A, const LwDev<R> &T, R *__restrict__ buf
 template <typename R> struct LwcSums { R d, u, u0, du, du0, dc, uc, uc0, duc, duc0; };
 template <typename R, bool CLD, int C>
 GR_DEV void lwc_collect(const LwArgs<R> &A, const LwOut<R> &O, const R *__restrict__ buf, int PS, int nlay, const LwcStage<R> &st, int c,
-                        int lay, int pc, bool valid, LwcSums<R> &b, LwcAcc<R> &acc)
+                        int lay, int pc, bool valid, LwcSums<R> &b, LwcAcc<R> &acc, R *__restrict__ accl, int accs)
 {
     using K = LwcK<CLD>;
     constexpr int GR = K::GR, NST = K::NST;
     const bool dudTs = A.dudTs != 0;
     const R sumfac = st.sumfac;
-    const R *const pf0 = buf + (size_t)K::NPL * GR * PS, *const u0 = pf0 + GR * C, *const dl0 = u0 + NST * GR * C;
+    const R *const pf0 = buf + (size_t)K::NPL * GR * C * PS, *const u0 = pf0 + GR * C, *const dl0 = u0 + NST * GR * C;
 #pragma unroll
     for (int gl = 0; gl < GR; gl++) {
         if (gl < st.nvalid) {
@@ -194,11 +192,12 @@ GR_DEV void lwc_collect(const LwArgs<R> &A, const LwOut<R> &O, const R *__restri
             if (dudTs) O.dolrb_dTs[(size_t)(O.col0 + pc) * NB_LW + (st.ib - 1)] = b.du;
         }
         // band sums -> totals, in band order like k_lw_reduce
-        acc.d += b.d; acc.u += b.u; acc.u0 += b.u0;
-        if (dudTs) { acc.du += b.du; acc.du0 += b.du0; }
         if (CLD) {
-            acc.dc += b.dc; acc.uc += b.uc; acc.uc0 += b.uc0;
-            if (dudTs) { acc.duc += b.duc; acc.duc0 += b.duc0; }
+            accl[0 * accs] += b.d; accl[1 * accs] += b.u; accl[2 * accs] += b.u0; accl[5 * accs] += b.dc; accl[6 * accs] += b.uc; accl[7 * accs] += b.uc0;
+            if (dudTs) { accl[3 * accs] += b.du; accl[4 * accs] += b.du0; accl[8 * accs] += b.duc; accl[9 * accs] += b.duc0; }
+        } else {
+            acc.d += b.d; acc.u += b.u; acc.u0 += b.u0;
+            if (dudTs) { acc.du += b.du; acc.du0 += b.du0; }
         }
         b = LwcSums<R>{};
     }
@@ -215,7 +214,8 @@ template <typename R> struct LwcWorker {
 // I0 = index of the band's first stage in the kernel's stage sequence (sets the plane buffer of each stage)
 template <typename R, typename BAND, bool CLD, bool DBG, int C, int I0>
 GR_DEV void lwc_band(const LwArgs<R> &A, const LwOut<R> &O, const LwDev<R> &T, R *__restrict__ lds, int PS, int nlay, bool worker,
-                     const LwcWorker<R> &S, int p2c, int p2gl, int p2s, int p2pc, LwcStage<R> (&ring)[2], LwcSums<R> &bsum, LwcAcc<R> &acc)
+                     const LwcWorker<R> &S, int p2c, int p2gl, int p2s, int p2pc, LwcStage<R> (&ring)[2], LwcSums<R> &bsum, LwcAcc<R> &acc,
+                     R *__restrict__ accl, int accs)
 {
     using K = LwcK<CLD>;
     using R2 = typename Vec2<R>::T;
@@ -252,13 +252,7 @@ GR_DEV void lwc_band(const LwArgs<R> &A, const LwOut<R> &O, const LwDev<R> &T, R
     const R *const taucmc_b = CLD ? A.taucmc + (size_t)G0 * nlay * n : nullptr;
     // gas optical depth and Planck fraction of ALL the band's g-points at once: a worker fetches each of its table rows whole and once
     // (16-byte pieces at immediate offsets of one address), instead of a quarter of the row per group of four g-points
-    constexpr int WB = NG >= 4 ? pad4(NG) : 2;
-    // EW g-points per evaluation of the k-distribution (a worker fetches EW reals of each of its table rows at a time)
-#ifndef LWC_EVALW
-#define LWC_EVALW 4
-#endif
-    constexpr int EW = NG < 4 ? 2 : (LWC_EVALW > WB ? WB : LWC_EVALW);
-    R tau[WB], pf[WB];
+    constexpr int W = NG >= 4 ? 4 : 2;          // g-points per evaluation of the k-distribution: one 16-byte piece of each table row
 
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -267,73 +261,64 @@ GR_DEV void lwc_band(const LwArgs<R> &A, const LwOut<R> &O, const LwDev<R> &T, R
         R *const bprev = lds + (size_t)((I + 1) & 1) * bufsz;   // stage I-1 (phase 2 now)
         if (worker) {
             if (S.act) {
-                if (I >= 2) lwc_collect<R, CLD, C>(A, O, bcur, PS, nlay, ring[I & 1], S.c, S.lay, S.pc, S.valid, bsum, acc);
-                R *const pf0 = bcur + (size_t)K::NPL * GR * PS;
-                // the stage's g-points that have not been evaluated yet
+                if (I >= 2) lwc_collect<R, CLD, C>(A, O, bcur, PS, nlay, ring[I & 1], S.c, S.lay, S.pc, S.valid, bsum, acc, accl, accs);
+                R *const pf0 = bcur + (size_t)K::NPL * GR * C * PS;
+                // one group of W g-points at a time, table rows to LDS cells, before the next group's rows are requested
 #pragma unroll
-                for (int go = 0; go < WB; go += EW) {
-                    const bool mine = EW <= GR ? (go >= r * GR && go < r * GR + GR) : (r * GR >= go && r * GR < go + EW && (r * GR) % EW == 0);
-                    if (!mine || go >= NG) continue;
-                    R t4[EW], p4[EW];
-#ifdef LWC_X_NOEVAL          // timing experiments only (results are wrong)
+                for (int q = 0; q < GR / W; q++) {
+                    const int go = r * GR + q * W;
+                    if (go >= NG) continue;
+                    R tau[W], pf[W];
+                    BAND::template eval<R, W>(T, S.L, P, go, tau, pf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    int itg[W];
+                    R2 eg[W];
 #pragma unroll
-                    for (int j = 0; j < EW; j++) { t4[j] = (R)0.1 * (R)(S.lay + 1); p4[j] = (R)0.1; }
-#else
-                    BAND::template eval<R, EW>(T, S.L, P, go, t4, p4);
-#endif
-#pragma unroll
-                    for (int j = 0; j < EW; j++) { tau[go + j] = t4[j]; pf[go + j] = p4[j]; }
-                }
-                int itg[GR];
-                R2 eg[GR];
-#pragma unroll
-                for (int gl = 0; gl < GR; gl++) {
-                    const int g = r * GR + gl;
-                    itg[gl] = 0; eg[gl].x = 0; eg[gl].y = 0;
-                    if (g >= NG) continue;
-                    if (DBG) {
-                        const size_t o = ((size_t)S.pc * NG_LW + (G0 + g)) * nlay + S.lay;   // Fortran (nlay,140,ncol)
-                        if (S.valid) { A.dbg_taug[o] = tau[g] + ta; A.dbg_pfracs[o] = pf[g]; }
+                    for (int j = 0; j < W; j++) {
+                        const int g = go + j;
+                        itg[j] = 0; eg[j].x = 0; eg[j].y = 0;
+                        if (g >= NG) continue;          // padding of the band's last group
+                        if (DBG) {
+                            const size_t o = ((size_t)S.pc * NG_LW + (G0 + g)) * nlay + S.lay;   // Fortran (nlay,140,ncol)
+                            if (S.valid) { A.dbg_taug[o] = tau[j] + ta; A.dbg_pfracs[o] = pf[j]; }
+                        }
+                        R odepth = secdiff * (tau[j] + ta);
+                        if (odepth < 0) odepth = 0;
+                        const R tblind = odepth / (bpade + odepth);
+                        itg[j] = (int)(tblint * tblind + (R)0.5);
+                        eg[j] = lut_at(itg[j]);
                     }
-                    R odepth = secdiff * (tau[g] + ta);
-                    if (odepth < 0) odepth = 0;
-                    const R tblind = odepth / (bpade + odepth);
-                    itg[gl] = (int)(tblint * tblind + (R)0.5);
-#ifdef LWC_X_NOLUT           // timing experiments only (results are wrong)
-                    eg[gl].x = tblind; eg[gl].y = odepth;
-#else
-                    eg[gl] = lut_at(itg[gl]);
-#endif
-                }
 #pragma unroll
-                for (int gl = 0; gl < GR; gl++) {
-                    const int g = r * GR + gl;
-                    if (g >= NG) continue;
-                    const R agas = (R)1. - eg[gl].x, tfacgas = eg[gl].y;
-                    const R bbdgas = pf[g] * (blay + tfacgas * dplankdn);
-                    const R bbugas = pf[g] * (blay + tfacgas * dplankup);
-                    *LWC_CELL(bcur, 0, gl, S.lay, S.c) = agas; *LWC_CELL(bcur, 1, gl, S.lay, S.c) = bbdgas; *LWC_CELL(bcur, 2, gl, S.lay, S.c) = bbugas;
-                    if (CLD) { *LWC_CELL(bcur, 3, gl, S.lay, S.c) = agas; *LWC_CELL(bcur, 4, gl, S.lay, S.c) = bbdgas; *LWC_CELL(bcur, 5, gl, S.lay, S.c) = bbugas; }
-                    if (S.lay == 0) pf0[gl * C + S.c] = pf[g];
-                }
-                // cloudy cells (few layers of a column have any): the total-sky values replace the gas-only ones just written
-                if (CLD && laycld) {
-#pragma unroll
-                    for (int gl = 0; gl < GR; gl++) {
-                        const int g = r * GR + gl;
+                    for (int j = 0; j < W; j++) {
+                        const int g = go + j, gl = q * W + j;
                         if (g >= NG) continue;
-                        const R tc = taucmc_b[((size_t)S.lay * NG + g) * n + S.pos];
-                        if (tc > 0) {
-                            // cloud added to the DISCRETISED gas optical depth (:264-268)
-                            const R odtot = ldg(T.tau_tbl, (uint32_t)itg[gl] * (uint32_t)sizeof(R)) + secdiff * tc;
-                            const R tb2 = odtot / (bpade + odtot);
-                            const int ittot = (int)(tblint * tb2 + (R)0.5);
-                            const R2 e2 = lut_at(ittot);
-                            *LWC_CELL(bcur, 0, gl, S.lay, S.c) = (R)1. - e2.x;
-                            *LWC_CELL(bcur, 1, gl, S.lay, S.c) = pf[g] * (blay + e2.y * dplankdn);
-                            *LWC_CELL(bcur, 2, gl, S.lay, S.c) = pf[g] * (blay + e2.y * dplankup);
+                        const R agas = (R)1. - eg[j].x, tfacgas = eg[j].y;
+                        const R bbdgas = pf[j] * (blay + tfacgas * dplankdn);
+                        const R bbugas = pf[j] * (blay + tfacgas * dplankup);
+                        *LWC_CELL(bcur, 0, gl, S.lay, S.c) = agas; *LWC_CELL(bcur, 1, gl, S.lay, S.c) = bbdgas; *LWC_CELL(bcur, 2, gl, S.lay, S.c) = bbugas;
+                        if (CLD) { *LWC_CELL(bcur, 3, gl, S.lay, S.c) = agas; *LWC_CELL(bcur, 4, gl, S.lay, S.c) = bbdgas; *LWC_CELL(bcur, 5, gl, S.lay, S.c) = bbugas; }
+                        if (S.lay == 0) pf0[gl * C + S.c] = pf[j];
+                    }
+                    // cloudy cells (few layers of a column have any): the total-sky values replace the gas-only ones just written
+                    if (CLD && laycld) {
+#pragma unroll
+                        for (int j = 0; j < W; j++) {
+                            const int g = go + j, gl = q * W + j;
+                            if (g >= NG) continue;
+                            const R tc = taucmc_b[((size_t)S.lay * NG + g) * n + S.pos];
+                            if (tc > 0) {
+                                // cloud added to the DISCRETISED gas optical depth (:264-268)
+                                const R odtot = ldg(T.tau_tbl, (uint32_t)itg[j] * (uint32_t)sizeof(R)) + secdiff * tc;
+                                const R tb2 = odtot / (bpade + odtot);
+                                const int ittot = (int)(tblint * tb2 + (R)0.5);
+                                const R2 e2 = lut_at(ittot);
+                                *LWC_CELL(bcur, 0, gl, S.lay, S.c) = (R)1. - e2.x;
+                                *LWC_CELL(bcur, 1, gl, S.lay, S.c) = pf[j] * (blay + e2.y * dplankdn);
+                                *LWC_CELL(bcur, 2, gl, S.lay, S.c) = pf[j] * (blay + e2.y * dplankup);
+                            }
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else if (I >= 1) {
@@ -375,7 +360,7 @@ __global__ void __launch_bounds__(LWC_MAXT) k_lw_cols(LwArgs<R> A, LwOut<R> O, L
     const int grp = (int)(blockIdx.x % 8u) * per + (int)(blockIdx.x / 8u);
     if (grp >= ngroups || (int)(blockIdx.x / 8u) >= per) return;              // uniform: before any barrier
     const int nlay = A.nlay;
-    const int PS = lwc_plane_stride(nlay, C);
+    const int PS = lwc_layer_stride(nlay);            // reals between the layer runs of neighbouring (g-point, column) pairs
     const int t = (int)threadIdx.x;
     const int nwt = (int)blockDim.x - 64;
     const bool worker = t < nwt;
@@ -399,10 +384,18 @@ __global__ void __launch_bounds__(LWC_MAXT) k_lw_cols(LwArgs<R> A, LwOut<R> O, L
         if (pos >= end) pos = end - 1;
         p2pc = A.perm[pos];
     }
+    // padding layers (zero absorptivity) and everything else start from zero
+    {
+        const size_t tot = 2 * lwc_buf_reals<CLD>(nlay, C) + (CLD ? (size_t)10 * nwt : 0);
+        for (size_t i = (size_t)t; i < tot; i += blockDim.x) lds[i] = 0;
+        __syncthreads();
+    }
     LwcAcc<R> acc{};
+    R *const accl = lds + 2 * lwc_buf_reals<CLD>(nlay, C) + t;      // cloudy instantiation: this worker's totals, [10][nwt] (zeroed above)
+    const int accs = nwt;
     LwcSums<R> bsum{};
     LwcStage<R> ring[2] = {};
-#define LWC_BAND(B, ib) lwc_band<R, B, CLD, DBG, C, lwc_stages_before<CLD>(ib)>(A, O, T, lds, PS, nlay, worker, S, p2c, p2gl, p2s, p2pc, ring, bsum, acc)
+#define LWC_BAND(B, ib) lwc_band<R, B, CLD, DBG, C, lwc_stages_before<CLD>(ib)>(A, O, T, lds, PS, nlay, worker, S, p2c, p2gl, p2s, p2pc, ring, bsum, acc, accl, nwt)
     LWC_BAND(Band1, 1); LWC_BAND(Band2, 2); LWC_BAND(Band3, 3); LWC_BAND(Band4, 4);
     LWC_BAND(Band5, 5); LWC_BAND(Band6, 6); LWC_BAND(Band7, 7); LWC_BAND(Band8, 8);
     LWC_BAND(Band9, 9); LWC_BAND(Band10, 10); LWC_BAND(Band11, 11); LWC_BAND(Band12, 12);
@@ -411,17 +404,21 @@ __global__ void __launch_bounds__(LWC_MAXT) k_lw_cols(LwArgs<R> A, LwOut<R> O, L
     // drain the pipeline: phase 2 of the last stage, phase 3 of the last two
     constexpr int N = lwc_stages_before<CLD>(17);
     const size_t bufsz = lwc_buf_reals<CLD>(nlay, C);
-    if (worker) { if (S.act) lwc_collect<R, CLD, C>(A, O, lds + (size_t)(N & 1) * bufsz, PS, nlay, ring[N & 1], S.c, S.lay, S.pc, S.valid, bsum, acc); }
+    if (worker) { if (S.act) lwc_collect<R, CLD, C>(A, O, lds + (size_t)(N & 1) * bufsz, PS, nlay, ring[N & 1], S.c, S.lay, S.pc, S.valid, bsum, acc, accl, accs); }
     else lwc_sweep<R, CLD, C>(A, T, lds + (size_t)((N + 1) & 1) * bufsz, PS, nlay, ring[(N + 1) & 1], p2c, p2gl, p2s, p2pc);
     __syncthreads();
     if (!worker || !S.act) return;
-    lwc_collect<R, CLD, C>(A, O, lds + (size_t)((N + 1) & 1) * bufsz, PS, nlay, ring[(N + 1) & 1], S.c, S.lay, S.pc, S.valid, bsum, acc);
+    lwc_collect<R, CLD, C>(A, O, lds + (size_t)((N + 1) & 1) * bufsz, PS, nlay, ring[(N + 1) & 1], S.c, S.lay, S.pc, S.valid, bsum, acc, accl, accs);
 
     // ---- the worker's levels of the API outputs (LW/rrtmg_lw_rad.F90:587-605) --------------------------------------------------
     if (!S.valid) return;
     const int ld = A.ld, lay = S.lay, pc = S.pc;
     const bool dudTs = A.dudTs != 0;
     const size_t lo = (size_t)lay * ld + pc, up = lo + ld;
+    if (CLD) {
+        acc.d = accl[0 * accs]; acc.u = accl[1 * accs]; acc.u0 = accl[2 * accs]; acc.du = accl[3 * accs]; acc.du0 = accl[4 * accs];
+        acc.dc = accl[5 * accs]; acc.uc = accl[6 * accs]; acc.uc0 = accl[7 * accs]; acc.duc = accl[8 * accs]; acc.duc0 = accl[9 * accs];
+    }
     O.dflx[lo] = acc.d; O.uflx[up] = acc.u;
     O.dflxc[lo] = CLD ? acc.dc : acc.d; O.uflxc[up] = CLD ? acc.uc : acc.u;
     if (dudTs) { O.duflx_dTs[up] = acc.du; O.duflxc_dTs[up] = CLD ? acc.duc : acc.du; }

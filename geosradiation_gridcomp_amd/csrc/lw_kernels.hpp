@@ -310,6 +310,14 @@ template <typename R, int W> GR_DEV void ldw(const R *__restrict__ tab, uint32_t
 // byte offset of row r (0-based) of a [rows][S] table, columns go..go+W-1
 #define ROWB(r) (((uint32_t)(r) * (uint32_t)S + (uint32_t)go) * (uint32_t)sizeof(R))
 
+// Wide evaluations (W > 4: k_lw_cols fetches half or whole rows per lane) must not have the rows of ALL their terms in flight at once
+// (22 rows x W registers): a compiler-level fence after each multi-row term keeps at most one term's rows outstanding.
+template <int W> GR_DEV void row_fence()
+{
+#ifdef LWC_ROW_FENCE
+    if constexpr (W > 4) asm volatile("" ::: "memory");
+#endif
+}
 template <typename R, int W, int S, bool INIT> GR_DEV void axw(R (&acc)[W], R c, const R *__restrict__ tab, int row, int go)
 {
     R r[W];
@@ -332,6 +340,7 @@ template <typename R, int W, int S> GR_DEV void add_linw(R (&acc)[W], R s, R f, 
     linw<R, W, S>(t, f, tab, row, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = acc[j] + s * t[j];
+    row_fence<W>();
 }
 // minor gas on a (species parameter, T) grid, rows [indm][jm], NSP species rows per T (e.g. :546-551)
 template <typename R, int W, int S, int NSP>
@@ -342,6 +351,7 @@ GR_DEV void minor2w(R (&o)[W], const R *__restrict__ tab, int jm, int indm, R fm
     linw<R, W, S>(m2, fm, tab, indm * NSP + (jm - 1), go);
 #pragma unroll
     for (int j = 0; j < W; j++) o[j] = m1[j] + minorfrac * (m2[j] - m1[j]);
+    row_fence<W>();
 }
 
 // binary-species parameter (e.g. LW/rrtmg_lw_taumol.F90:435-441) with the interpolation weights of the
@@ -386,6 +396,7 @@ GR_DEV void major_a(R (&acc)[W], const R *__restrict__ absa, int ind, const Spec
     if (sp.edge) axw<R, W, S, false>(t, sp.c2 * facB, absa, base + 11, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = INIT ? sp.speccomb * t[j] : acc[j] + sp.speccomb * t[j];
+    row_fence<W>();
 }
 // upper-atmosphere binary side, 5 species rows, always linear (e.g. :706-716)
 template <typename R, int W, int S, bool INIT>
@@ -399,6 +410,7 @@ GR_DEV void major_b5(R (&acc)[W], const R *__restrict__ absb, int ind, const Spe
     axw<R, W, S, false>(t, c1 * facB, absb, ind + 5, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = INIT ? sp.speccomb * t[j] : acc[j] + sp.speccomb * t[j];
+    row_fence<W>();
 }
 // single key species: col * 4-point (p,T) interpolation (e.g. :240-244); ind0/ind1 1-based
 template <typename R, int W, int S>
@@ -411,6 +423,7 @@ GR_DEV void major1(R (&acc)[W], const R *__restrict__ tab, int ind0, int ind1, c
     axw<R, W, S, false>(t, L.fac11, tab, ind1, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = col * t[j];
+    row_fence<W>();
 }
 // "too much of a minor gas" column adjustment (e.g. :461-468)
 template <typename R> GR_DEV R adjcol(R colx, R coldry, R chiref, R thresh, R a, R pw)
