@@ -599,21 +599,27 @@ def main():
             d["so_" + k] = torch.zeros(ncol, device=dev, dtype=tdt)
         d["so_flx_sfc_band"] = torch.zeros((8, ncol), device=dev, dtype=tdt)
     ptr = {k: v.data_ptr() for k, v in d.items()}
-    # --lit f < 1: RRTMG_SW runs on the packed daytime columns only, as SORADCORE does after PackIt (SOL:3686, :7753-7773; SURVEY
-    # 8(d) cfg 4 has about half of a tile lit): the first f * ncol columns of the batch, as contiguous arrays of their own
-    ncol_sw = ncol if a.lit >= 1.0 else max(64, int(round(ncol * a.lit)))
+    # --lit f < 1: day / night.  A pseudo-random fraction f of the columns is lit; like SORADCORE after `daytime = ZTH > 0.` + PackIt
+    # (SOL:3686, :7753-7773; SURVEY 8(d) cfg 4 has about half of a tile lit) RRTMG_SW runs on the packed daytime columns only, and every
+    # step builds the lit index, packs the SW inputs, and unpacks the SW outputs into the full-size fields (geosrad_lit_*_dev)
+    ncol_sw = ncol
     ptr_sw = ptr
-    if do_sw and ncol_sw < ncol:
-        sw_names = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat"] \
+    lit = None
+    if do_sw and a.lit < 1.0:
+        h = (np.arange(shard_start(rank, ncol), shard_start(rank, ncol) + ncol, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
+        day = (h.astype(np.float64) / float(1 << 24)) < a.lit
+        zth = np.where(day, inp["coszen"], -0.5).astype(np.float32 if a.real == 4 else np.float64)
+        ncol_sw = int(day.sum())
+        sw_in = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat"] \
             + SW_IN + (SW_AER if aerosol else [])
-        dsw = {k: d[k][..., :ncol_sw].contiguous() for k in sw_names}
-        for k in ("swuflx", "swdflx", "swuflxc", "swdflxc"):
-            dsw[k] = torch.zeros((nlay + 1, ncol_sw), device=dev, dtype=tdt)
-        for k in SW_OUT1:
-            dsw[k] = torch.zeros(ncol_sw, device=dev, dtype=tdt)
-        dsw["fswband"] = torch.zeros((14, ncol_sw), device=dev, dtype=tdt)
+        sw_out = ["swuflx", "swdflx", "swuflxc", "swdflxc", "fswband"] + SW_OUT1
+        dsw = {k: torch.zeros(d[k].shape[:-1] + (ncol_sw,), device=dev, dtype=tdt) for k in sw_in + sw_out}
         dsw["clearCounts_sw"] = torch.zeros((4, ncol_sw), device=dev, dtype=torch.int32)
         ptr_sw = {k: v.data_ptr() for k, v in dsw.items()}
+        lit = {"zth": torch.from_numpy(zth).to(dev), "idx": torch.zeros(ncol, device=dev, dtype=torch.int32),
+               "pos": torch.zeros(ncol, device=dev, dtype=torch.int32), "n": torch.zeros(1, device=dev, dtype=torch.int32),
+               "in": [(k, int(np.prod(d[k].shape[:-1])) if d[k].dim() > 1 else 1) for k in sw_in],
+               "out": [(k, int(np.prod(d[k].shape[:-1])) if d[k].dim() > 1 else 1) for k in sw_out]}
     ptr_ch = {k[3:]: v for k, v in ptr.items() if k.startswith("ch_")}
     ptr_so = {k[3:]: v for k, v in ptr.items() if k.startswith("so_")}
 
@@ -631,7 +637,15 @@ def main():
         if do_lw:
             ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
         if do_sw:      # GEOS call: isolvar 0 scaled to scon, normalised fluxes (SOL:6230-6300)
+            if lit is not None:
+                ctx.lit_index_dev(sw_stream, ncol, lit["zth"].data_ptr(), lit["idx"].data_ptr(), lit["pos"].data_ptr(), lit["n"].data_ptr(),
+                                  want_count=False)
+                for k, nlev in lit["in"]:
+                    ctx.lit_pack_dev(sw_stream, ncol_sw, ncol, nlev, lit["idx"].data_ptr(), lit["n"].data_ptr(), ptr[k], ptr_sw[k])
             ctx.rrtmg_sw_dev(sw_stream, ncol_sw, nlay, 1361.0, 1.0, 0, ptr_sw, 3, 1, doy, 10 if aerosol else 0, lm, mh, normFlx=1)
+            if lit is not None:
+                for k, nlev in lit["out"]:
+                    ctx.lit_unpack_dev(sw_stream, ncol_sw, ncol, nlev, lit["pos"].data_ptr(), ptr_sw[k], ptr[k], default=0.0)
         if do_irrad:
             for k in aer0:                    # taua / ssaa / asya are in-out (rescaled in place): restore the inputs
                 d["ch_" + k].copy_(aer0[k])
@@ -705,7 +719,7 @@ def main():
             wl = ("%sper-GPU share: %d columns/GPU, %d layers, %s, McICA clouds on %.0f %% of the columns (ih=1), aerosols %s, "
                   "%s" % ("BASELINE configs[3] (C360 tile / 8 GPUs) " if ncol == 97_200 and a.scheme == "lwsw" else "",
                                          ncol, nlay, schemes, 100 * a.cloudy, "on" if aerosol else "off",
-                                         "every column lit" if ncol_sw == ncol else "RRTMG_SW on the %d lit columns (packed)" % ncol_sw))
+                                         "every column lit" if ncol_sw == ncol else "RRTMG_SW on the %d lit columns (lit index + PackIt / UnPackIt on the device every step)" % ncol_sw))
         out = {
             "metric": "columns/sec (LW+SW, 72 layers)" if a.scheme == "lwsw" else "columns/sec", "value": value, "unit": "columns/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -518,6 +518,25 @@ class Context:
                                       ctypes.c_double(cwp_tiny), so, v("cldy_stoch"), v("ciwp_stoch"), v("clwp_stoch"))
         self._chk(rc)
 
+    # ---- lit-column compaction (GEOS_SolarGridComp.F90:3686, PackIt / UnPackIt :7753-7799); device addresses ------------------
+    def lit_index_dev(self, stream, ncol, zth, lit_index, lit_pos, nlit_dev, want_count=True):
+        """zth: (ncol,) reals; lit_index, lit_pos: (ncol,) int32; nlit_dev: (1,) int32.  Returns NumLit when want_count (synchronises)."""
+        n = ctypes.c_int(0)
+        rc = self.L.geosrad_lit_index_dev(self.h, ctypes.c_void_p(stream), ctypes.c_int(ncol), ctypes.c_void_p(zth), ctypes.c_void_p(lit_index),
+                                          ctypes.c_void_p(lit_pos), ctypes.c_void_p(nlit_dev), ctypes.byref(n) if want_count else None)
+        self._chk(rc)
+        return n.value if want_count else None
+
+    def lit_pack_dev(self, stream, pdim, udim, nlev, lit_index, nlit_dev, unpacked, packed):
+        self._chk(self.L.geosrad_lit_pack_dev(self.h, ctypes.c_void_p(stream), ctypes.c_int(pdim), ctypes.c_int(udim), ctypes.c_int(nlev),
+                                              ctypes.c_void_p(lit_index), ctypes.c_void_p(nlit_dev), ctypes.c_void_p(unpacked),
+                                              ctypes.c_void_p(packed)))
+
+    def lit_unpack_dev(self, stream, pdim, udim, nlev, lit_pos, packed, unpacked, default=None):
+        self._chk(self.L.geosrad_lit_unpack_dev(self.h, ctypes.c_void_p(stream), ctypes.c_int(pdim), ctypes.c_int(udim), ctypes.c_int(nlev),
+                                                ctypes.c_void_p(lit_pos), ctypes.c_void_p(packed), ctypes.c_void_p(unpacked),
+                                                ctypes.c_int(0 if default is None else 1), ctypes.c_double(0.0 if default is None else default)))
+
     def clearCounts_threeBand(self, ncol, nsubcol, nlay, cloudLM, cloudMH, cldy_stoch):
         cldy = np.ascontiguousarray(cldy_stoch, dtype=np.int32)
         cnt = np.zeros((ncol, 4), dtype=np.int32)

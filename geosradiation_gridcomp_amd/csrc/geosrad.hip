@@ -288,6 +288,11 @@ struct geosrad_ctx {
     virtual int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
                         int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
                         int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
+    virtual int lit_index_dev(hipStream_t st, int ncol, const void *zth, int32_t *idx, int32_t *pos, int32_t *nlit_dev, int *nlit_host) = 0;
+    virtual int lit_pack_dev(hipStream_t st, int pdim, int udim, int nlev, const int32_t *idx, const int32_t *nlit_dev, const void *unpacked,
+                             void *packed) = 0;
+    virtual int lit_unpack_dev(hipStream_t st, int pdim, int udim, int nlev, const int32_t *pos, const void *packed, void *unpacked,
+                               int use_default, double dflt) = 0;
 };
 
 // order of the `in` / `out` pointer arrays of sw_dev / sw_host
@@ -1146,6 +1151,43 @@ template <typename R> struct Ctx : geosrad_ctx {
         U.slrsf = O(GEOSRAD_SWS_SLRSF); U.slrsfc = O(GEOSRAD_SWS_SLRSFC); U.slrsfna = O(GEOSRAD_SWS_SLRSFNA); U.slrsfcna = O(GEOSRAD_SWS_SLRSFCNA);
         U.slrsuf = O(GEOSRAD_SWS_SLRSUF); U.slrsufc = O(GEOSRAD_SWS_SLRSUFC); U.slrsufna = O(GEOSRAD_SWS_SLRSUFNA); U.slrsufcna = O(GEOSRAD_SWS_SLRSUFCNA);
         hipLaunchKernelGGL((k_sw_update_surface<R>), dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, U);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+
+    // ---- lit-column compaction (GEOS_SolarGridComp.F90:3686, PackIt / UnPackIt :7753-7799) --------------------------------------
+    int lit_index_dev(hipStream_t st, int ncol, const void *zth, int32_t *idx, int32_t *pos, int32_t *nlit_dev, int *nlit_host) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || !zth || !idx || !pos || !nlit_dev) return fail(GEOSRAD_EINVAL, "lit_index: bad arguments");
+        hipLaunchKernelGGL(k_lit_index<R>, dim3(1), dim3(1024), 0, st, ncol, (const R *)zth, idx, pos, nlit_dev);
+        HIPCHK(hipGetLastError());
+        if (nlit_host) {      // the caller sizes the packed call with it (NumLit = count(daytime) in the GridComp)
+            int32_t v = 0;
+            HIPCHK(hipMemcpyAsync(&v, nlit_dev, sizeof v, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            *nlit_host = v;
+        }
+        return GEOSRAD_OK;
+    }
+    int lit_pack_dev(hipStream_t st, int pdim, int udim, int nlev, const int32_t *idx, const int32_t *nlit_dev, const void *unpacked,
+                     void *packed) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (pdim <= 0 || udim <= 0 || nlev <= 0 || !idx || !nlit_dev || !unpacked || !packed) return fail(GEOSRAD_EINVAL, "lit_pack: bad arguments");
+        const int nmax = pdim < udim ? pdim : udim;
+        hipLaunchKernelGGL(k_lit_pack<R>, dim3((unsigned)((nmax + 255) / 256), nlev), dim3(256), 0, st, pdim, udim, idx, nlit_dev,
+                           (const R *)unpacked, (R *)packed);
+        HIPCHK(hipGetLastError());
+        return GEOSRAD_OK;
+    }
+    int lit_unpack_dev(hipStream_t st, int pdim, int udim, int nlev, const int32_t *pos, const void *packed, void *unpacked, int use_default,
+                       double dflt) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (pdim <= 0 || udim <= 0 || nlev <= 0 || !pos || !unpacked || !packed) return fail(GEOSRAD_EINVAL, "lit_unpack: bad arguments");
+        hipLaunchKernelGGL(k_lit_unpack<R>, dim3((unsigned)((udim + 255) / 256), nlev), dim3(256), 0, st, pdim, udim, pos, (const R *)packed,
+                           (R *)unpacked, use_default, (R)dflt);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
     }
@@ -2372,6 +2414,22 @@ int geosrad_rad_tendencies_dev(geosrad_ctx *c, void *stream, int ncol, int lm, d
 {
     if (!c || !in || !out) return GEOSRAD_EINVAL;
     return c->rad_tendencies_dev((hipStream_t)stream, ncol, lm, grav, cp, in, out);
+}
+
+int geosrad_lit_index_dev(geosrad_ctx *c, void *stream, int ncol, const void *zth, int32_t *lit_index, int32_t *lit_pos, int32_t *nlit_dev,
+                          int *nlit_host)
+{
+    return c ? c->lit_index_dev((hipStream_t)stream, ncol, zth, lit_index, lit_pos, nlit_dev, nlit_host) : GEOSRAD_EINVAL;
+}
+int geosrad_lit_pack_dev(geosrad_ctx *c, void *stream, int pdim, int udim, int nlev, const int32_t *lit_index, const int32_t *nlit_dev,
+                         const void *unpacked, void *packed)
+{
+    return c ? c->lit_pack_dev((hipStream_t)stream, pdim, udim, nlev, lit_index, nlit_dev, unpacked, packed) : GEOSRAD_EINVAL;
+}
+int geosrad_lit_unpack_dev(geosrad_ctx *c, void *stream, int pdim, int udim, int nlev, const int32_t *lit_pos, const void *packed,
+                           void *unpacked, int use_default, double dflt)
+{
+    return c ? c->lit_unpack_dev((hipStream_t)stream, pdim, udim, nlev, lit_pos, packed, unpacked, use_default, dflt) : GEOSRAD_EINVAL;
 }
 
 int geosrad_profile(geosrad_ctx *c, int enable)

@@ -727,4 +727,56 @@ template <typename R, int V> __global__ void __launch_bounds__(256) k_rad_tenden
 #undef VFOR
 #undef VSET
 
+// ---------------------------------------------------------------------------------------------------
+// Lit-column compaction of the solar component (GEOS_SolarGridComp.F90:3686 `daytime = ZTH > 0.`, PackIt / UnPackIt :7753-7799):
+// SORADCORE only sees the NumLit daytime columns, packed to the front of every field in (i, j) order.
+//   k_lit_index: stable list of the lit columns (one 1024-thread block, like k_partition): idx[m] = column of packed position m,
+//                pos[column] = packed position or -1, *nlit = NumLit
+//   k_lit_pack  : Packed(m, l) = UnPacked(idx[m], l)
+//   k_lit_unpack: UnPacked(idx[m], l) = Packed(m, l); dark columns get DEFAULT when one is given (PRESENT(DEFAULT)), else keep their value
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(1024) k_lit_index(int ncol, const R *__restrict__ zth, int32_t *__restrict__ idx, int32_t *__restrict__ pos,
+                                                    int32_t *__restrict__ nlit)
+{
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x;
+    const int chunk = (ncol + 1023) / 1024;
+    const int b = t * chunk, e = (b + chunk < ncol) ? b + chunk : ncol;
+    int c = 0;
+    for (int i = b; i < e; i++) c += zth[i] > (R)0;
+    cnt[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive Hillis-Steele scan
+        const int v = t >= d ? cnt[t - d] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    int m = cnt[t] - c;                              // lit columns before this thread's chunk
+    for (int i = b; i < e; i++) {
+        if (zth[i] > (R)0) { idx[m] = i; pos[i] = m; m++; }
+        else pos[i] = -1;
+    }
+    if (t == 0) *nlit = cnt[1023];
+}
+template <typename R>
+__global__ void __launch_bounds__(256) k_lit_pack(int pdim, int udim, const int32_t *__restrict__ idx, const int32_t *__restrict__ nlit,
+                                                  const R *__restrict__ unpacked, R *__restrict__ packed)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (m >= *nlit) return;
+    packed[(size_t)l * pdim + m] = unpacked[(size_t)l * udim + idx[m]];
+}
+template <typename R>
+__global__ void __launch_bounds__(256) k_lit_unpack(int pdim, int udim, const int32_t *__restrict__ pos, const R *__restrict__ packed,
+                                                    R *__restrict__ unpacked, int use_default, R dflt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (i >= udim) return;
+    const int m = pos[i];
+    if (m >= 0) unpacked[(size_t)l * udim + i] = packed[(size_t)l * pdim + m];
+    else if (use_default) unpacked[(size_t)l * udim + i] = dflt;
+}
+
 }  // namespace geosrad

@@ -9,6 +9,7 @@ module geosrad_gridcomp
    implicit none
    private
    public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_update_surface, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lit_index, lit_pack, lit_unpack
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
    ! ---- GEOSRAD_LWD_* ----
@@ -145,6 +146,24 @@ module geosrad_gridcomp
          integer(c_int), value :: ncol, lm
          real(c_double), value :: grav, cp
          type(c_ptr), intent(in) :: fin(*), fout(*)
+      end function
+      integer(c_int) function geosrad_lit_index_dev(ctx, stream, ncol, zth, lit_index, lit_pos, nlit_dev, nlit_host) bind(C, name='geosrad_lit_index_dev')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx, stream, zth, lit_index, lit_pos, nlit_dev
+         integer(c_int), value :: ncol
+         integer(c_int), intent(out) :: nlit_host
+      end function
+      integer(c_int) function geosrad_lit_pack_dev(ctx, stream, pdim, udim, nlev, lit_index, nlit_dev, unpacked, packed) bind(C, name='geosrad_lit_pack_dev')
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx, stream, lit_index, nlit_dev, unpacked, packed
+         integer(c_int), value :: pdim, udim, nlev
+      end function
+      integer(c_int) function geosrad_lit_unpack_dev(ctx, stream, pdim, udim, nlev, lit_pos, packed, unpacked, use_default, dflt) &
+            bind(C, name='geosrad_lit_unpack_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream, lit_pos, packed, unpacked
+         integer(c_int), value :: pdim, udim, nlev, use_default
+         real(c_double), value :: dflt
       end function
       integer(c_int) function geosrad_check(ctx, stream) bind(C, name='geosrad_check')
          import :: c_int, c_ptr
@@ -327,5 +346,33 @@ contains
       type(c_ptr), intent(in) :: fin(RT_NIN), fout(RT_NOUT)
       if (geosrad_rad_tendencies_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), real(grav,c_double), real(cp,c_double), &
             fin, fout) /= 0) call geosrad_fail('GEOS_RadiationGridComp RUN')
+   end subroutine
+
+   ! lit-column compaction on device fields (GEOS_SolarGridComp.F90:3686 `daytime = ZTH > 0.`; PackIt / UnPackIt :7753-7799).
+   ! zth (ncol) reals; lit_idx, lit_pos (ncol) and nlit_dev (1) default integers, all device addresses.
+   subroutine lit_index(ncol, zth, lit_idx, lit_pos, nlit_dev, NumLit)
+      integer, intent(in) :: ncol
+      type(c_ptr), intent(in) :: zth, lit_idx, lit_pos, nlit_dev
+      integer, intent(out) :: NumLit
+      integer(c_int) :: n
+      if (geosrad_lit_index_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), zth, lit_idx, lit_pos, nlit_dev, n) /= 0) &
+         call geosrad_fail('daytime compaction')
+      NumLit = n
+   end subroutine
+   subroutine lit_pack(Packed, UnPacked, lit_idx, nlit_dev, Pdim, Udim, LM)      ! PackIt's argument order, device addresses
+      type(c_ptr), intent(in) :: Packed, UnPacked, lit_idx, nlit_dev
+      integer, intent(in) :: Pdim, Udim, LM
+      if (geosrad_lit_pack_dev(geosrad_ctx_handle(), c_null_ptr, int(Pdim,c_int), int(Udim,c_int), int(LM,c_int), lit_idx, nlit_dev, &
+            UnPacked, Packed) /= 0) call geosrad_fail('PackIt')
+   end subroutine
+   subroutine lit_unpack(Packed, UnPacked, lit_pos, Pdim, Udim, LM, DEFAULT)    ! UnPackIt's argument order, device addresses
+      type(c_ptr), intent(in) :: Packed, UnPacked, lit_pos
+      integer, intent(in) :: Pdim, Udim, LM
+      real, intent(in), optional :: DEFAULT
+      real(c_double) :: d
+      d = 0
+      if (present(DEFAULT)) d = DEFAULT
+      if (geosrad_lit_unpack_dev(geosrad_ctx_handle(), c_null_ptr, int(Pdim,c_int), int(Udim,c_int), int(LM,c_int), lit_pos, Packed, &
+            UnPacked, merge(1_c_int, 0_c_int, present(DEFAULT)), d) /= 0) call geosrad_fail('UnPackIt')
    end subroutine
 end module geosrad_gridcomp

@@ -419,6 +419,22 @@ enum { GEOSRAD_RT_DTDT, GEOSRAD_RT_RADLW, GEOSRAD_RT_RADSW, GEOSRAD_RT_RADLWC, G
 int geosrad_rad_tendencies_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, double grav, double cp, const void *const *in,
                                void *const *out);
 
+/* ---- lit-column compaction of the solar component ----------------------------------------------------------------------
+ * GEOS_SolarGridComp.F90:3686 (`daytime = ZTH > 0.`, NumLit = count(daytime)) and PackIt / UnPackIt (:7753-7799): SORADCORE works on
+ * the daytime columns only, packed to the front of every field in (i, j) order; on a node each GPU therefore takes its share of the
+ * LIT columns.  All pointers are device pointers of the context's real kind (int32 for the index arrays).
+ *   geosrad_lit_index_dev : lit_index[m] = column of packed position m (stable order), lit_pos[column] = packed position or -1,
+ *                           *nlit_dev = NumLit; when nlit_host is not NULL the stream is synchronised and NumLit returned in it
+ *   geosrad_lit_pack_dev  : Packed(m, l) = UnPacked(lit_index[m], l), l = 1..nlev; Packed is (pdim, nlev), UnPacked (udim, nlev)
+ *   geosrad_lit_unpack_dev: UnPacked(lit_index[m], l) = Packed(m, l); dark columns receive `dflt` when use_default != 0
+ *                           (UnPackIt's optional DEFAULT), otherwise they keep their values */
+int geosrad_lit_index_dev(geosrad_ctx *ctx, void *stream, int ncol, const void *zth, int32_t *lit_index, int32_t *lit_pos,
+                          int32_t *nlit_dev, int *nlit_host);
+int geosrad_lit_pack_dev(geosrad_ctx *ctx, void *stream, int pdim, int udim, int nlev, const int32_t *lit_index, const int32_t *nlit_dev,
+                         const void *unpacked, void *packed);
+int geosrad_lit_unpack_dev(geosrad_ctx *ctx, void *stream, int pdim, int udim, int nlev, const int32_t *lit_pos, const void *packed,
+                           void *unpacked, int use_default, double dflt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -503,3 +503,73 @@ def test_update_export_surface_block(gpu_ctx, rk):
         assert ref[k].dtype == dt, k
         np.testing.assert_array_equal(t[k].cpu().numpy(), ref[k], err_msg=k)
     assert (ref["ALBEDO"] == ud).sum() > n // 3 and (ref["ALBEDO"] == dt(.01)).any() and (ref["ALBEDO"] == dt(0.9)).any()
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+def test_lit_column_compaction_roundtrip_and_sw_on_packed_columns(gpu_ctx, rk):
+    """SW first compacts the lit columns (`daytime = ZTH > 0.`, PackIt, GEOS_SolarGridComp.F90:3686,7753-7773), runs the solver on
+    the packed batch and scatters the results back (UnPackIt :7776-7799).  Pack / unpack against numpy, and RRTMG_SW on the packed
+    columns + unpack equal to the same columns of an unpacked call, bit for bit; dark columns receive UnPackIt's DEFAULT."""
+    import torch
+    from geosradiation_gridcomp_amd import synth
+    ctx = gpu_ctx[rk]
+    tdt = torch.float32 if rk == 4 else torch.float64
+    n, nlay = 1500, 72
+    inp = synth.make_columns(n, nlay, start=12_000, aerosol=True, cloudy_frac=0.5)
+    rng = np.random.default_rng(3)
+    day = rng.uniform(size=n) < 0.47
+    zth = np.where(day, inp["coszen"], -rng.uniform(0.0, 1.0, n)).astype(ctx.dtype)      # night: cos(zenith) <= 0
+    zth[5] = 0.0
+    day[5] = False
+    st = torch.cuda.current_stream().cuda_stream
+    t_zth = torch.from_numpy(zth).cuda()
+    idx = torch.zeros(n, dtype=torch.int32, device="cuda"); pos = torch.zeros(n, dtype=torch.int32, device="cuda")
+    nl = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nlit = ctx.lit_index_dev(st, n, t_zth.data_ptr(), idx.data_ptr(), pos.data_ptr(), nl.data_ptr())
+    want_idx = np.flatnonzero(day)
+    assert nlit == want_idx.size == int(nl.item())
+    np.testing.assert_array_equal(idx.cpu().numpy()[:nlit], want_idx)
+    want_pos = np.full(n, -1, dtype=np.int32); want_pos[want_idx] = np.arange(nlit)
+    np.testing.assert_array_equal(pos.cpu().numpy(), want_pos)
+    pdim = nlit + 9                                       # NumMax may exceed NumLit (the balanced buffer is larger)
+
+    def pack(a):      # numpy (nlev, n) -> device (nlev, pdim)
+        a = np.ascontiguousarray(a, dtype=ctx.dtype)
+        a2 = a.reshape(-1, n)
+        u = torch.from_numpy(a2).cuda()
+        p = torch.full((a2.shape[0], pdim), -5.0, dtype=tdt, device="cuda")
+        ctx.lit_pack_dev(st, pdim, n, a2.shape[0], idx.data_ptr(), nl.data_ptr(), u.data_ptr(), p.data_ptr())
+        np.testing.assert_array_equal(p.cpu().numpy()[:, :nlit], a2[:, want_idx])
+        assert (p.cpu().numpy()[:, nlit:] == -5.0).all()
+        return p
+    names = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat",
+             "tauaer_sw", "ssaaer_sw", "asmaer_sw", "coszen", "asdir", "asdif", "aldir", "aldif"]
+    d = {k: pack(inp[k]) for k in names}
+    for k in ("swuflx", "swdflx", "swuflxc", "swdflxc"):
+        d[k] = torch.zeros((nlay + 1, pdim), dtype=tdt, device="cuda")
+    for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "cotdtp", "cotdhp", "cotdmp", "cotdlp", "cotntp", "cotnhp", "cotnmp", "cotnlp"):
+        d[k] = torch.zeros(pdim, dtype=tdt, device="cuda")
+    d["fswband"] = torch.zeros((14, pdim), dtype=tdt, device="cuda")
+    d["clearCounts_sw"] = torch.zeros((4, pdim), dtype=torch.int32, device="cuda")
+    ctx.set_inhomogeneity(1)
+    try:
+        # the packed arrays have leading dimension pdim: the solver is called on nlit columns of a (pdim, .) batch -> pass pdim-wide arrays
+        # through a contiguous nlit-wide view (what SORADCORE's Num2do-wide dummies are)
+        dn = {k: v[..., :nlit].contiguous() for k, v in d.items()}
+        ctx.rrtmg_sw_dev(st, nlit, nlay, 1361.0, 1.0, 0, {k: v.data_ptr() for k, v in dn.items()}, 3, 1, int(inp["dyofyr"]), 10,
+                         int(inp["cloudLM"]), int(inp["cloudMH"]), normFlx=1)
+        ctx.check(st)
+        full = ctx.rrtmg_sw_columns(inp, iaer=10, normFlx=1)
+    finally:
+        ctx.set_inhomogeneity(0)
+    for k in ("swuflx", "swdflx", "swuflxc", "swdflxc", "fswband", "nirr", "parf"):
+        src = dn[k].reshape(-1, nlit).contiguous()
+        nlev = src.shape[0]
+        out = torch.full((nlev, n), 123.0, dtype=tdt, device="cuda")
+        ctx.lit_unpack_dev(st, nlit, n, nlev, pos.data_ptr(), src.data_ptr(), out.data_ptr(), default=0.0)
+        o = out.cpu().numpy().reshape(full[k].shape)
+        np.testing.assert_array_equal(o[..., day], full[k][..., day], err_msg=k)       # bitwise: a column never depends on its batch
+        assert (o[..., ~day] == 0.0).all()
+        keep = torch.full((nlev, n), 123.0, dtype=tdt, device="cuda")
+        ctx.lit_unpack_dev(st, nlit, n, nlev, pos.data_ptr(), src.data_ptr(), keep.data_ptr())     # no DEFAULT: dark columns untouched
+        assert (keep.cpu().numpy().reshape(full[k].shape)[..., ~day] == 123.0).all()
