@@ -128,11 +128,34 @@ def _cpu_worker(args):
             t = time.perf_counter()
             clib.rrtmg_lw(inp, "f32")
             t_lw = time.perf_counter() - t
+    t_ref_stages = t_port_stages = 0.0
     if "sw" in scheme:
         clib.lib(); clib.set_inhomogeneity(ih, "f32")
         t = time.perf_counter()
         clib.rrtmg_sw(inp, prec="f32", iaer=10 if aerosol else 0, normFlx=1)
         t_sw = time.perf_counter() - t
+        # bracket the port by reference code: the stages of rrtmg_sw that DO build from the reference's sources (setcoef_sw + taumol_sw,
+        # the McICA generator, cldprmc_sw) timed as the reference's own Fortran and as the port, on a quarter of the sample
+        from oracle import reflib
+        if reflib.available("r4"):
+            nq = max(64, ncol // 4)
+            sub = {k: (np.ascontiguousarray(v[..., :nq]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v) for k, v in inp.items()}
+            reflib.lib("r4"); reflib.set_inhomogeneity(ih, "r4")
+            svar = [np.float32(1.0)] * 3; sb = np.ones((3, 29), dtype=np.float32)
+            for which in ("reference", "port"):
+                t = time.perf_counter()
+                if which == "reference":
+                    reflib.sw_setcoef_taumol(sub, isolvar=0, svar=svar, svar_bnd=sb, kind="r4")
+                    cl, ci, cw = reflib.mcica(sub["zm"], sub["alat"], int(inp["dyofyr"]), sub["play"], sub["cldf"], sub["ciwp"], sub["clwp"], 112,
+                                              seed_order=(4, 3, 2, 1), kind="r4")
+                    reflib.sw_cldprmc(cl, ci, cw, sub["rei"], sub["rel"], iceflag=3, kind="r4")
+                    t_ref_stages = (time.perf_counter() - t) * (ncol / nq)
+                else:
+                    clib.sw_setcoef_taumol(sub, isolvar=0, svar=svar, svar_bnd=sb, prec="f32")
+                    cl, ci, cw = clib.mcica(sub["zm"], sub["alat"], int(inp["dyofyr"]), sub["play"], sub["cldf"], sub["ciwp"], sub["clwp"], 112,
+                                            seed_order=(4, 3, 2, 1), prec="f32")
+                    clib.sw_cldprmc(cl, ci, cw, sub["rei"], sub["rel"], iceflag=3, prec="f32")
+                    t_port_stages = (time.perf_counter() - t) * (ncol / nq)
     if scheme in ("chou", "irrad"):
         ch = synth.chou_lw_inputs(inp, aerosol=aerosol)
         clib.lib()
@@ -145,7 +168,7 @@ def _cpu_worker(args):
         t = time.perf_counter()
         clib.sorad(cs, "f32")
         t_sw = time.perf_counter() - t
-    return t_lw, t_sw
+    return t_lw, t_sw, t_ref_stages, t_port_stages
 
 
 def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
@@ -164,14 +187,19 @@ def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
     with ctx.Pool(cores) as pool:
         per = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
-    busy = max(a + b for a, b in per)
-    lw_s = sum(a for a, _ in per) / len(per); sw_s = sum(b for _, b in per) / len(per)
+    busy = max(p[0] + p[1] for p in per)
+    lw_s = sum(p[0] for p in per) / len(per); sw_s = sum(p[1] for p in per) / len(per)
+    ref_st = sum(p[2] for p in per) / len(per); port_st = sum(p[3] for p in per) / len(per)
     legs = []
     if "lw" in scheme:
         legs.append(f"rrtmg_lw = {'reference Fortran (oracle/_ref), psize=4' if lw_kind == 'reference' else 'plain-C oracle'} "
                     f"{per_core / lw_s:.0f} col/s/core")
     if "sw" in scheme:
         legs.append(f"rrtmg_sw = plain-C oracle (reference driver needs ESMF/MAPL: unbuildable here) {per_core / sw_s:.0f} col/s/core")
+        if ref_st > 0:
+            legs.append(f"of it the stages the reference's own Fortran provides (setcoef_sw + taumol_sw + generate_stochastic_clouds + cldprmc_sw): "
+                        f"reference {ref_st:.2f} s vs port {port_st:.2f} s per {per_core} columns = {100 * port_st / sw_s:.0f} % of the port's "
+                        f"rrtmg_sw time; with those stages at the reference's speed the SW leg would take {sw_s - port_st + ref_st:.2f} s instead of {sw_s:.2f} s")
     if scheme in ("chou", "irrad"):
         legs.append(f"irrad = plain-C oracle (irrad.F90 needs MAPL: unbuildable here) {per_core / lw_s:.0f} col/s/core")
     if scheme in ("chou", "sorad"):
@@ -179,7 +207,9 @@ def cpu_baseline(nlay, scheme, cloudy, aerosol, per_core=4096):
     return {"value": cores * per_core / busy, "unit": "columns/s", "cores": cores, "kind": kind,
             "sample": f"{cores} processes x {per_core} columns of the bench workload ({nlay} layers, cloudy fraction {cloudy}, "
                       f"aerosol {aerosol}); " + "; ".join(legs) + f"; slowest process {busy:.2f} s (pool wall {wall:.2f} s incl. input generation)",
-            "single_core_columns_per_s": per_core / (lw_s + sw_s)}
+            "single_core_columns_per_s": per_core / (lw_s + sw_s),
+            "sw_reference_stages": None if ref_st <= 0 else {"reference_s": ref_st, "port_s": port_st, "port_rrtmg_sw_s": sw_s,
+                                                              "fraction_of_port_sw": port_st / sw_s, "columns": per_core}}
 
 
 def _hb_cpu_worker(args):
