@@ -520,6 +520,9 @@ def main():
     ap.add_argument("--rats", type=int, default=0, help="gridcomp: RATS diagnostics for the first N gases of gridcomp.RAT_GAS (0-8)")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--host-api", action="store_true",
+                    help="lwsw / lw / sw: also time the drop-in host-pointer entry points (geosrad_rrtmg_lw / _sw: pinned staging, chunk-pipelined "
+                         "H2D / kernels / D2H) on the same columns and report the PCIe-inclusive rate next to the device-resident one")
     ap.add_argument("--control-path-only", action="store_true",
                     help="no GPU work: launcher, rank -> shard, barrier, MAX over ranks and rank 0's JSON line only (CPU rehearsal / tests)")
     a = ap.parse_args()
@@ -715,6 +718,27 @@ def main():
         torch.cuda.synchronize()
         prof1 = ctx.profile_read()
 
+    host_api = None
+    if a.host_api and rank == 0 and (do_lw or do_sw):
+        # the reference interface: host arrays in, host arrays out (what the Fortran drop-in of INTEGRATION.md 1-3 calls); PCIe included
+        hsteps = max(2, min(a.steps, 5))
+        ht = []
+        hlw = hsw = None
+        for it in range(hsteps + 1):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if do_lw:       # output arrays are the caller's and persist between calls, as a Fortran caller's do
+                hlw = ctx.rrtmg_lw_columns(inp if aerosol else {k: v for k, v in inp.items() if k != "tauaer"}, out=hlw)
+            if do_sw:
+                hsw = ctx.rrtmg_sw_columns(inp, iaer=10 if aerosol else 0, normFlx=1, out=hsw)
+            ht.append(time.perf_counter() - t1)
+        hbest = sorted(ht[1:])[len(ht[1:]) // 2]           # median of the steps after the first (which allocates the staging slots)
+        hbytes = (algorithmic_bytes_lw(nlay, a.real, aerosol) if do_lw else 0) + (algorithmic_bytes_sw(nlay, a.real, aerosol) if do_sw else 0)
+        host_api = {"value": ncol / hbest, "unit": "columns/s", "ms_per_step": hbest * 1e3, "steps": hsteps,
+                    "pcie_bytes_per_column": hbytes, "pcie_GB_per_s": hbytes * ncol / hbest / 1e9,
+                    "note": "geosrad_rrtmg_lw + geosrad_rrtmg_sw on host arrays, one after the other (numpy -> ctypes, pageable caller memory): "
+                            "copy threads -> pinned staging -> H2D | kernels | D2H on three streams, chunks of 16 384 columns"}
+
     if rank == 0:
         total_cols = world * ncol * a.steps
         value = total_cols / elapsed
@@ -769,6 +793,8 @@ def main():
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,
         }
+        if host_api is not None:
+            out["host_api"] = host_api
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -123,7 +123,7 @@ class Context:
     def rrtmg_lw(self, ncol, nlay, psize, dudTs, play, plev, tlay, tlev, tsfc, emis,
                  h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr,
                  cldf, ciwp, clwp, rei, rel, iceflglw, liqflglw, tauaer, zm, alat, dyofyr, cloudLM, cloudMH,
-                 band_output=None):
+                 band_output=None, out=None):
         """Returns dict(uflx,dflx,uflxc,dflxc,duflx_dTs,duflxc_dTs (nlay+1,ncol); clearCounts (4,ncol);
         olrb,dolrb_dTs (ncol,16))."""
         dt = self.dtype
@@ -132,10 +132,11 @@ class Context:
                                 cldf, ciwp, clwp, rei, rel)]
         play, plev, tlay, tlev, tsfc, emis, tauaer, zm, alat = map(c, (play, plev, tlay, tlev, tsfc, emis, tauaer, zm, alat))
         assert play.shape == (nlay, ncol) and plev.shape == (nlay + 1, ncol)
-        out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs")}
-        out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
-        out["olrb"] = np.zeros((ncol, NBNDLW), dtype=dt)
-        out["dolrb_dTs"] = np.zeros((ncol, NBNDLW), dtype=dt)
+        if out is None:       # (a caller that keeps its output arrays, like a Fortran caller does, passes the dict of an earlier call)
+            out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs")}
+            out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
+            out["olrb"] = np.zeros((ncol, NBNDLW), dtype=dt)
+            out["dolrb_dTs"] = np.zeros((ncol, NBNDLW), dtype=dt)
         bo = np.zeros(NBNDLW, dtype=np.int32) if band_output is None else np.ascontiguousarray(band_output, dtype=np.int32)
         ci = ctypes.c_int
         rc = self.L.geosrad_rrtmg_lw(
@@ -147,12 +148,12 @@ class Context:
         self._chk(rc)
         return out
 
-    def rrtmg_lw_columns(self, inp, psize=4, dudTs=True, iceflg=3, liqflg=1, band_output=None):
+    def rrtmg_lw_columns(self, inp, psize=4, dudTs=True, iceflg=3, liqflg=1, band_output=None, out=None):
         """Convenience: `inp` as produced by synth.make_columns."""
         nlay, ncol = inp["play"].shape
         return self.rrtmg_lw(ncol, nlay, psize, dudTs, inp["play"], inp["plev"], inp["tlay"], inp["tlev"], inp["tsfc"],
                              inp["emis"], *[inp[k] for k in _IN2D], iceflg, liqflg, inp.get("tauaer"), inp["zm"],
-                             inp["alat"], inp["dyofyr"], inp["cloudLM"], inp["cloudMH"], band_output=band_output)
+                             inp["alat"], inp["dyofyr"], inp["cloudLM"], inp["cloudMH"], band_output=band_output, out=out)
 
     def rrtmg_lw_taumol(self, inp):
         """(taug, pfracs) numpy (ncol,140,nlay) == Fortran (nlay,140,ncol), as left by the reference's taumol."""
@@ -170,7 +171,7 @@ class Context:
     # ---- RRTMG_SW, host arrays -------------------------------------------------------------------------
     def rrtmg_sw(self, rpart, ncol, nlay, scon, adjes, coszen, isolvar, play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr,
                  iceflgsw, liqflgsw, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer,
-                 asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, do_drfband=False, bndscl=None, indsolvar=None):
+                 asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, do_drfband=False, bndscl=None, indsolvar=None, out=None):
         """rrtmg_sw (SW/rrtmg_sw_rad.F90:68).  Returns dict(swuflx,swdflx,swuflxc,swdflxc (nlay+1,ncol); nirr..uvrf,
         cotdtp..cotnlp (ncol); fswband[,drband,dfband] (14,ncol); clearCounts (4,ncol))."""
         dt = self.dtype
@@ -180,13 +181,14 @@ class Context:
         coszen, play, plev, tlay, zm, alat, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif = map(
             c, (coszen, play, plev, tlay, zm, alat, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif))
         assert play.shape == (nlay, ncol) and plev.shape == (nlay + 1, ncol)
-        out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
-        for k in ["nirr", "nirf", "parr", "parf", "uvrr", "uvrf"] + _SW_COT:
-            out[k] = np.zeros(ncol, dtype=dt)
-        out["fswband"] = np.zeros((NBNDSW, ncol), dtype=dt)
-        if do_drfband:
-            out["drband"] = np.zeros((NBNDSW, ncol), dtype=dt); out["dfband"] = np.zeros((NBNDSW, ncol), dtype=dt)
-        out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
+        if out is None:
+            out = {k: np.zeros((nlay + 1, ncol), dtype=dt) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
+            for k in ["nirr", "nirf", "parr", "parf", "uvrr", "uvrf"] + _SW_COT:
+                out[k] = np.zeros(ncol, dtype=dt)
+            out["fswband"] = np.zeros((NBNDSW, ncol), dtype=dt)
+            if do_drfband:
+                out["drband"] = np.zeros((NBNDSW, ncol), dtype=dt); out["dfband"] = np.zeros((NBNDSW, ncol), dtype=dt)
+            out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
         bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
         ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
         ci, cd = ctypes.c_int, ctypes.c_double
@@ -201,14 +203,14 @@ class Context:
         return out
 
     def rrtmg_sw_columns(self, inp, scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqflg=1, iaer=0, normFlx=0, do_drfband=False,
-                         bndscl=None, indsolvar=None, rpart=4):
+                         bndscl=None, indsolvar=None, rpart=4, out=None):
         """Convenience: `inp` as produced by synth.make_columns."""
         nlay, ncol = inp["play"].shape
         aer = [inp.get(k) if iaer == 10 else None for k in ("tauaer_sw", "ssaaer_sw", "asmaer_sw")]
         return self.rrtmg_sw(rpart, ncol, nlay, scon, adjes, inp["coszen"], isolvar, inp["play"], inp["plev"], inp["tlay"],
                              *[inp[k] for k in _SW_GAS], iceflg, liqflg, inp["cldf"], inp["ciwp"], inp["clwp"], inp["rei"], inp["rel"],
                              inp["dyofyr"], inp["zm"], inp["alat"], iaer, *aer, inp["asdir"], inp["asdif"], inp["aldir"], inp["aldif"],
-                             inp["cloudLM"], inp["cloudMH"], normFlx, do_drfband=do_drfband, bndscl=bndscl, indsolvar=indsolvar)
+                             inp["cloudLM"], inp["cloudMH"], normFlx, do_drfband=do_drfband, bndscl=bndscl, indsolvar=indsolvar, out=out)
 
     def rrtmg_sw_taumol(self, inp, scon=1361.0, isolvar=0, bndscl=None, indsolvar=None):
         """(taug, taur) numpy (ncol,112,nlay) and ssi (ncol,112) as left by the reference's taumol_sw."""

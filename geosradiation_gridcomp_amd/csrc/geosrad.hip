@@ -10,6 +10,9 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <thread>
+#include <functional>
+#include <chrono>
 
 #include <cstddef>
 #include <cstdint>
@@ -233,7 +236,135 @@ struct geosrad_ctx {
         spans.clear();
     }
     int fail(int code, const std::string &msg) { last_error = msg; return code; }
-    virtual ~geosrad_ctx() {}
+
+    // ---- host-pointer entry points: chunk pipeline --------------------------------------------------------------------------
+    // The reference interface hands over host arrays, Fortran (ncol, rows): column index fastest.  A batch goes through the GPU in
+    // chunks of `host_chunk` columns: copy threads gather a chunk's rows into a pinned staging slot, one DMA moves the slot to HBM,
+    // the solver runs on it, one DMA brings the outputs back and the threads scatter them - on three streams and two slots, so that
+    // the gathering of chunk k+1, the transfers and the kernels of chunk k and the scattering of chunk k-1 overlap.
+    struct PipeArr { const void *src; void *dst; size_t rows, ebytes; size_t off; };      // src: copied in; dst: copied back (either may be null)
+    int host_chunk = 16384, host_chunk_default = 16384, host_threads = 8;
+    char *pipe_pin[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [slot][0 = to the device, 1 = from the device]
+    char *pipe_dev[2] = {nullptr, nullptr};
+    size_t pipe_pin_bytes = 0, pipe_dev_bytes = 0;
+    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr;
+    hipEvent_t pipe_ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};      // per slot: h2d, compute, d2h done
+    void pipe_release()
+    {
+        for (int s = 0; s < 2; s++) {
+            for (int d = 0; d < 2; d++) if (pipe_pin[s][d]) { (void)hipHostFree(pipe_pin[s][d]); pipe_pin[s][d] = nullptr; }
+            if (pipe_dev[s]) { (void)hipFree(pipe_dev[s]); pipe_dev[s] = nullptr; }
+            for (int e = 0; e < 3; e++) if (pipe_ev[s][e]) { (void)hipEventDestroy(pipe_ev[s][e]); pipe_ev[s][e] = nullptr; }
+        }
+        if (pipe_h2d) { (void)hipStreamDestroy(pipe_h2d); pipe_h2d = nullptr; }
+        if (pipe_d2h) { (void)hipStreamDestroy(pipe_d2h); pipe_d2h = nullptr; }
+        pipe_pin_bytes = pipe_dev_bytes = 0;
+    }
+    // rows of `arrs` (a chunk's nc columns starting at c0 of ncol) between the caller's arrays and a staging slot, on copy threads
+    void pipe_copy(std::vector<PipeArr> &arrs, char *slot, size_t slot_base, int ncol, int c0, int nc, bool to_slot)
+    {
+        struct Item { const PipeArr *a; size_t row; };
+        std::vector<Item> items;
+        for (auto &a : arrs) {
+            if (to_slot ? !a.src : !a.dst) continue;
+            for (size_t r = 0; r < a.rows; r++) items.push_back({&a, r});
+        }
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                const PipeArr &a = *items[i].a;
+                const size_t r = items[i].row;
+                char *sl = slot + (a.off - slot_base) + r * (size_t)nc * a.ebytes;      // a chunk's arrays are dense: leading dimension nc
+                if (to_slot) memcpy(sl, (const char *)a.src + (r * (size_t)ncol + (size_t)c0) * a.ebytes, (size_t)nc * a.ebytes);
+                else memcpy((char *)a.dst + (r * (size_t)ncol + (size_t)c0) * a.ebytes, sl, (size_t)nc * a.ebytes);
+            }
+        };
+        size_t bytes = 0;
+        for (auto &it : items) bytes += (size_t)nc * it.a->ebytes;
+        const int nt = bytes < ((size_t)4 << 20) ? 1 : host_threads;
+        if (nt <= 1) { work(0, items.size()); return; }
+        std::vector<std::thread> th;
+        const size_t per = (items.size() + nt - 1) / nt;
+        for (int t = 0; t < nt; t++) {
+            const size_t lo = t * per, hi = lo + per < items.size() ? lo + per : items.size();
+            if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+        for (auto &t : th) t.join();
+    }
+    // arrs must be ordered: copied in only, copied both ways, copied back only.  run(stream, nc, c0, device base of the slot) enqueues
+    // the solver for one chunk whose arrays lie at dev + a.off, dense with leading dimension nc (slots are sized for
+    // cn = min(ncol, host_chunk) columns).
+    int host_pipeline(int ncol, std::vector<PipeArr> &arrs, const std::function<int(hipStream_t, int, int, char *, int)> &run)
+    {
+        const int cn = ncol < host_chunk ? ncol : host_chunk;
+        size_t off = 0, in_end = 0, out_begin = (size_t)-1;
+        for (auto &a : arrs) {
+            a.off = off;
+            if (a.dst && out_begin == (size_t)-1) out_begin = off;
+            off += (a.rows * (size_t)cn * a.ebytes + 255) & ~(size_t)255;
+            if (a.src) in_end = off;
+        }
+        if (out_begin == (size_t)-1) out_begin = off;
+        const size_t total = off, in_bytes = in_end, out_bytes = total - out_begin;
+#define PIPECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(GEOSRAD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+        if (!pipe_h2d) {
+            PIPECHK(hipStreamCreateWithFlags(&pipe_h2d, hipStreamNonBlocking));
+            PIPECHK(hipStreamCreateWithFlags(&pipe_d2h, hipStreamNonBlocking));
+            for (int s = 0; s < 2; s++) for (int e = 0; e < 3; e++) PIPECHK(hipEventCreateWithFlags(&pipe_ev[s][e], hipEventDisableTiming));
+        }
+        if (total > pipe_dev_bytes || total > pipe_pin_bytes) {
+            PIPECHK(hipDeviceSynchronize());
+            for (int s = 0; s < 2; s++) {
+                if (pipe_dev[s]) { (void)hipFree(pipe_dev[s]); pipe_dev[s] = nullptr; }
+                for (int d = 0; d < 2; d++) if (pipe_pin[s][d]) { (void)hipHostFree(pipe_pin[s][d]); pipe_pin[s][d] = nullptr; }
+                if (hipMalloc((void **)&pipe_dev[s], total) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the host-API staging slot failed");
+                for (int d = 0; d < 2; d++)
+                    if (hipHostMalloc((void **)&pipe_pin[s][d], total, hipHostMallocDefault) != hipSuccess)
+                        return fail(GEOSRAD_ENOMEM, "hipHostMalloc of the pinned host-API staging slot failed");
+            }
+            pipe_dev_bytes = pipe_pin_bytes = total;
+        }
+        const int nchunks = (ncol + cn - 1) / cn;
+        const bool trace = getenv("GEOSRAD_HOST_TRACE") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_g = 0, t_s = 0, t_w = 0, t_e = 0;
+        const double t_begin = now();
+        for (int k = 0; k <= nchunks; k++) {
+            if (k < nchunks) {
+                const int s = k & 1, c0 = k * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
+                double t0 = now();
+                if (k >= 2) PIPECHK(hipEventSynchronize(pipe_ev[s][0]));            // the slot's previous transfer has left the staging memory
+                double t1 = now(); t_w += t1 - t0;
+                pipe_copy(arrs, pipe_pin[s][0], 0, ncol, c0, nc, true);
+                t0 = now(); t_g += t0 - t1;
+                if (k >= 2) PIPECHK(hipStreamWaitEvent(pipe_h2d, pipe_ev[s][2], 0));   // ... and chunk k-2 has been copied out of the device slot
+                if (in_bytes) PIPECHK(hipMemcpyAsync(pipe_dev[s], pipe_pin[s][0], in_bytes, hipMemcpyHostToDevice, pipe_h2d));
+                PIPECHK(hipEventRecord(pipe_ev[s][0], pipe_h2d));
+                PIPECHK(hipStreamWaitEvent(stream, pipe_ev[s][0], 0));
+                const int rc = run(stream, nc, c0, pipe_dev[s], cn);
+                if (rc) { (void)hipDeviceSynchronize(); return rc; }
+                PIPECHK(hipEventRecord(pipe_ev[s][1], stream));
+                PIPECHK(hipStreamWaitEvent(pipe_d2h, pipe_ev[s][1], 0));
+                if (out_bytes) PIPECHK(hipMemcpyAsync(pipe_pin[s][1] + out_begin, pipe_dev[s] + out_begin, out_bytes, hipMemcpyDeviceToHost, pipe_d2h));
+                PIPECHK(hipEventRecord(pipe_ev[s][2], pipe_d2h));
+                t_e += now() - t0;
+            }
+            if (k >= 1) {
+                const int j = k - 1, s = j & 1, c0 = j * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
+                double t0 = now();
+                PIPECHK(hipEventSynchronize(pipe_ev[s][2]));
+                double t1 = now(); t_w += t1 - t0;
+                pipe_copy(arrs, pipe_pin[s][1], 0, ncol, c0, nc, false);
+                t_s += now() - t1;
+            }
+        }
+        if (trace)
+            fprintf(stderr, "geosrad host pipeline: %d columns, %d chunks of %d, %.1f MB in / %.1f MB out per chunk: total %.1f ms = gather %.1f + "
+                            "scatter %.1f + enqueue %.1f + waiting for the GPU %.1f\n", ncol, nchunks, cn, in_bytes / 1e6, out_bytes / 1e6,
+                    now() - t_begin, t_g, t_s, t_e, t_w);
+#undef PIPECHK
+        return GEOSRAD_OK;
+    }
+    virtual ~geosrad_ctx() { pipe_release(); }
     virtual int init() = 0;
     virtual int set_tables_lw(const void *blob, size_t n) = 0;
     virtual int set_inhomogeneity(int ih, const void *blob, size_t n) = 0;
@@ -1268,6 +1399,42 @@ template <typename R> struct Ctx : geosrad_ctx {
     {
         HIPCHK(hipSetDevice(device));
         if (ncol <= 0 || nlay <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay");
+        if (!taug) {
+            // production path: pinned staging + chunk pipeline (host_pipeline); the taug / pfracs test hook keeps the plain path below
+            for (int k = 0; k < I_NIN; k++) if (!in[k] && k != I_TAUAER) return fail(GEOSRAD_EINVAL, "null input array");
+            for (int k = 0; k < 4; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+            bool any_bo = false;
+            if (band_output) for (int b = 0; b < 16; b++) any_bo |= band_output[b] != 0;
+            const size_t L = (size_t)nlay, E = sizeof(R);
+            std::vector<PipeArr> arrs;
+            int ix_in[I_NIN], ix_out[O_NOUT], ix_cc = -1;
+            for (int k = 0; k < I_NIN; k++) {
+                ix_in[k] = -1;
+                if (!in[k]) continue;
+                const size_t rows = (k == I_PLEV || k == I_TLEV) ? L + 1 : (k == I_TSFC || k == I_ALAT) ? 1 : k == I_EMIS ? 16 : k == I_TAUAER ? 16 * L : L;
+                ix_in[k] = (int)arrs.size(); arrs.push_back({in[k], nullptr, rows, E, 0});
+            }
+            // olrb / dolrb_dTs, Fortran (16, ncol): 16 reals per column; the reference leaves un-requested bands untouched, so the
+            // caller's content makes the round trip
+            for (int k = 0; k < O_NOUT; k++) ix_out[k] = -1;
+            if (any_bo && out[O_OLRB]) { ix_out[O_OLRB] = (int)arrs.size(); arrs.push_back({out[O_OLRB], out[O_OLRB], 1, 16 * E, 0}); }
+            if (any_bo && dudTs && out[O_DOLRB]) { ix_out[O_DOLRB] = (int)arrs.size(); arrs.push_back({out[O_DOLRB], out[O_DOLRB], 1, 16 * E, 0}); }
+            for (int k = 0; k < O_OLRB; k++) {
+                if (!out[k] || ((k == O_DUFLX || k == O_DUFLXC) && !dudTs)) continue;
+                ix_out[k] = (int)arrs.size(); arrs.push_back({nullptr, out[k], L + 1, E, 0});
+            }
+            ix_cc = (int)arrs.size(); arrs.push_back({nullptr, clearCounts, 4, sizeof(int32_t), 0});      // dst may be null: stays on the device
+            auto run = [&](hipStream_t st, int nc, int, char *dev, int) -> int {
+                const void *din[I_NIN]; void *dout[O_NOUT];
+                for (int k = 0; k < I_NIN; k++) din[k] = ix_in[k] >= 0 ? dev + arrs[ix_in[k]].off : nullptr;
+                for (int k = 0; k < O_NOUT; k++) dout[k] = ix_out[k] >= 0 ? dev + arrs[ix_out[k]].off : nullptr;
+                return lw_dev(st, nc, nlay, dudTs, din, iceflg, liqflg, dyofyr, cloudLM, cloudMH, (int32_t *)(dev + arrs[ix_cc].off), dout,
+                              band_output, nullptr, nullptr, nullptr);
+            };
+            int rc = host_pipeline(ncol, arrs, run);
+            if (rc) return rc;
+            return check(stream);
+        }
         const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
         size_t insz[I_NIN];
         for (int k = 0; k < I_NIN; k++) insz[k] = cl;
@@ -1595,6 +1762,41 @@ template <typename R> struct Ctx : geosrad_ctx {
     {
         HIPCHK(hipSetDevice(device));
         if (ncol <= 0 || nlay <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay");
+        if (!dbg) {
+            // production path: pinned staging + chunk pipeline (host_pipeline); the stage-dump test hooks keep the plain path below
+            for (int k = 0; k < S_NIN; k++)
+                if (!in[k] && !((k == S_TAUAER || k == S_SSAAER || k == S_ASMAER) && iaer != 10)) return fail(GEOSRAD_EINVAL, "null input array");
+            for (int k = 0; k < SO_DRBAND; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+            if (do_drfband && (!out[SO_DRBAND] || !out[SO_DFBAND])) return fail(GEOSRAD_EINVAL, "do_drfband set but drband/dfband null");
+            const size_t L = (size_t)nlay, E = sizeof(R);
+            std::vector<PipeArr> arrs;
+            int ix_in[S_NIN], ix_out[SO_NOUT], ix_cc = -1;
+            for (int k = 0; k < S_NIN; k++) {
+                ix_in[k] = -1;
+                const bool aer = (k == S_TAUAER || k == S_SSAAER || k == S_ASMAER);
+                if (!in[k] || (aer && iaer != 10)) continue;
+                const size_t rows = k == S_PLEV ? L + 1 : aer ? (size_t)NB_SW * L
+                                  : (k == S_ALAT || k == S_COSZEN || k == S_ASDIR || k == S_ASDIF || k == S_ALDIR || k == S_ALDIF) ? 1 : L;
+                ix_in[k] = (int)arrs.size(); arrs.push_back({in[k], nullptr, rows, E, 0});
+            }
+            for (int k = 0; k < SO_NOUT; k++) {
+                ix_out[k] = -1;
+                if ((k == SO_DRBAND || k == SO_DFBAND) && !do_drfband) continue;
+                const size_t rows = k <= SO_DFLXC ? L + 1 : (k == SO_FSWBAND || k == SO_DRBAND || k == SO_DFBAND) ? (size_t)NB_SW : 1;
+                ix_out[k] = (int)arrs.size(); arrs.push_back({nullptr, out[k], rows, E, 0});
+            }
+            ix_cc = (int)arrs.size(); arrs.push_back({nullptr, clearCounts, 4, sizeof(int32_t), 0});
+            auto run = [&](hipStream_t st, int nc, int, char *dev, int) -> int {
+                const void *din[S_NIN]; void *dout[SO_NOUT];
+                for (int k = 0; k < S_NIN; k++) din[k] = ix_in[k] >= 0 ? dev + arrs[ix_in[k]].off : nullptr;
+                for (int k = 0; k < SO_NOUT; k++) dout[k] = ix_out[k] >= 0 ? dev + arrs[ix_out[k]].off : nullptr;
+                return sw_dev(st, nc, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
+                              (int32_t *)(dev + arrs[ix_cc].off), dout, do_drfband, bndscl, indsolvar, nullptr);
+            };
+            int rc = host_pipeline(ncol, arrs, run);
+            if (rc) return rc;
+            return check(stream);
+        }
         const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
         size_t insz[S_NIN];
         for (int k = 0; k < S_NIN; k++) insz[k] = cl;
@@ -2042,6 +2244,9 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
     {   // A/B switch for the measurements in profiles/: GEOSRAD_LW_PATH=cols | bands
         const char *e = getenv("GEOSRAD_LW_PATH");
         if (e) c->lw_cols_path = !strcmp(e, "cols");
+        // tuning of the host-pointer pipeline: columns per staged chunk, copy threads
+        if ((e = getenv("GEOSRAD_HOST_CHUNK")) && atoi(e) >= 64) c->host_chunk = c->host_chunk_default = atoi(e);
+        if ((e = getenv("GEOSRAD_HOST_THREADS")) && atoi(e) >= 1) c->host_threads = atoi(e) > 64 ? 64 : atoi(e);
     }
     int rc = c->init();
     if (rc) { delete c; return rc; }
@@ -2052,7 +2257,13 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
 int geosrad_destroy(geosrad_ctx *c) { if (!c) return GEOSRAD_EINVAL; (void)hipSetDevice(c->device); delete c; return GEOSRAD_OK; }
 const char *geosrad_last_error(const geosrad_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
 int geosrad_real_kind(const geosrad_ctx *c) { return c ? c->real_kind : 0; }
-int geosrad_set_chunk(geosrad_ctx *c, int n) { if (!c || n < 64) return GEOSRAD_EINVAL; c->chunk = n; return GEOSRAD_OK; }
+int geosrad_set_chunk(geosrad_ctx *c, int n)
+{
+    if (!c || n < 64) return GEOSRAD_EINVAL;
+    c->chunk = n;
+    c->host_chunk = n < c->host_chunk_default ? n : c->host_chunk_default;      // the host-pointer pipeline never stages more than a batch
+    return GEOSRAD_OK;
+}
 size_t geosrad_workspace_bytes(const geosrad_ctx *c) { return c ? c->workspace_bytes() : 0; }
 
 int geosrad_set_tables_lw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_lw(blob, n) : GEOSRAD_EINVAL; }

@@ -68,3 +68,45 @@ def test_c720_share_137_layers(gpu_ctx):
     same = (sw1["clearCounts"][:, :12] == q["clearCounts"]).all(axis=0)
     for k in ("swuflx", "swdflx"):
         assert (np.abs(sw1[k][:, :12].astype(np.float64) - q[k]) <= 5e-3)[:, same].all(), k
+
+
+def test_chou_pair_100k_columns(gpu_ctx):
+    """BASELINE configs[2]'s size for the Chou-Suarez pair: 100 000 columns through irrad and through sorad in one call each
+    (no shrinking of the batch); properties, a shard computed alone (bitwise), spot parity against the plain-C oracle."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    ctx = gpu_ctx[4]
+    n, nlay = 100_000, 72
+    inp = synth.make_columns(n, nlay, start=2_000_000, cloudy_frac=0.6, aerosol=True)
+    ch = synth.chou_lw_inputs(inp, aerosol=True)
+    cs = synth.chou_sw_inputs(inp, aerosol=True)
+    a = ctx.irrad_columns(ch)
+    s = ctx.sorad_columns(cs, do_drfband=True)
+    for k in ("flxu", "flxd", "flcu", "flcd", "dfdts", "sfcem"):
+        assert np.isfinite(a[k]).all(), k
+    for k in ("flx", "flc", "flxu", "flcu", "flx_sfc_band"):
+        assert np.isfinite(s[k]).all(), k
+    assert (a["flxd"][0] == 0).all() and (-a["flxu"][0] > 80).all() and (-a["flxu"][0] < 400).all()        # OLR
+    tot = s["flx"][0].astype(np.float64) + s["flxu"][0]
+    assert (tot <= 1.0 + 1e-5).all() and (tot > 0.99).all()                                               # insolation = net + reflected
+    clear = ~(inp["cldf"] > 0).any(axis=0)
+    np.testing.assert_array_equal(s["flx"][:, clear], s["flc"][:, clear])
+    np.testing.assert_array_equal(a["flxu"][:, clear], a["flcu"][:, clear])
+    sl = slice(61_234, 61_234 + 200)
+
+    def shard(d):
+        return {k: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == n else v) for k, v in d.items()}
+    a1 = ctx.irrad_columns(shard(ch)); s1 = ctx.sorad_columns(shard(cs), do_drfband=True)
+    for k in ("flxu", "flxd", "flcu", "flcd", "dfdts"):
+        np.testing.assert_array_equal(a1[k], a[k][..., sl], err_msg=k)
+    for k in ("flx", "flc", "flxu", "flcu", "flx_sfc_band", "drband"):
+        np.testing.assert_array_equal(s1[k], s[k][..., sl], err_msg=k)
+    o = clib.irrad(sub_columns_any(shard(ch), 24, 200), "r4"); q = clib.sorad(sub_columns_any(shard(cs), 24, 200), "r4")
+    for k in ("flxu", "flxd", "flcu", "flcd"):
+        assert np.abs(a1[k][:, :24].astype(np.float64) - o[k]).max() <= 2e-2, k
+    for k in ("flx", "flc", "flxu", "flcu"):
+        assert np.abs(s1[k][:, :24].astype(np.float64) - q[k]).max() <= 2e-5, k
+
+
+def sub_columns_any(d, m, ncol):
+    return {k: (np.ascontiguousarray(v[..., :m]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v) for k, v in d.items()}
