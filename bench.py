@@ -535,7 +535,7 @@ def main():
     do_lw, do_sw = "lw" in a.scheme, "sw" in a.scheme
     do_irrad, do_sorad = a.scheme in ("chou", "irrad"), a.scheme in ("chou", "sorad")
     if (do_irrad or do_sorad) and a.ncol == 97_200:
-        a.ncol = 20_000              # the Chou kernels carry O(np^2) / 35-pass scratch: a smaller default batch
+        a.ncol = 100_000             # BASELINE configs[2]: 100 000 columns
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -763,7 +763,7 @@ def main():
         if a.scheme == "lwsw" and (ncol, ncol_sw, nlay, a.cloudy, aerosol, a.real) == (97_200, 97_200, 72, 0.6, True, 4):
             traffic = {"k_sw_bands": 66.6e9, "k_lw_bands": 30.1e9}.get(kname)      # profiles/r01_v9_lwsw_pmc_traffic.md (both instantiations)
         elif a.scheme == "chou" and (ncol, nlay, a.cloudy, aerosol, a.real) == (20_000, 72, 0.6, True, 4):
-            traffic = {"k_sorad_pass": 32.9e9, "k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
+            traffic = {"k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
                    "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
                    "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]

@@ -201,6 +201,7 @@ static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vm
 // ---------------------------------------------------------------------------------------------------
 struct geosrad_ctx {
     int device = 0, real_kind = 4, chunk = 131072;
+    bool sorad_col_path = false;    // Chou-Suarez sorad passes: HBM scratch planes, lane = column (default) | GEOSRAD_SORAD_PATH=col: on chip
     bool lw_cols_path = false;      // RRTMG_LW band sweeps: parked cells in HBM (default) | GEOSRAD_LW_PATH=cols: on-chip intermediates
     std::string last_error;
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
@@ -462,6 +463,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     // tables
     char *d_tab = nullptr; size_t tab_bytes = 0;
     char *d_xcw = nullptr; size_t xcw_bytes = 0;
+    size_t so_lds_set = 0;       // dynamic-LDS limit granted to k_sorad_col so far
     LwDev<R> h_T{};            // host copy (device pointers inside)
     LwDev<R> *d_T = nullptr;
     bool have_lw = false;
@@ -2036,9 +2038,20 @@ template <typename R> struct Ctx : geosrad_ctx {
         const int K2 = np + 2;
         const int nc_max = m < chunk ? m : chunk;
         const size_t per = (size_t)nc_max * sizeof(R);
+        // passes: k_sorad_pass (lane = column, the per-level arrays of every pass in HBM scratch planes, 34 x K2 reals per (column, pass))
+        // or k_sorad_col (one block per column, everything on chip, no scratch; GEOSRAD_SORAD_PATH=col)
+        // (a layer count whose on-chip arrays exceed the LDS takes the scratch-plane path)
+        const bool col_path = sorad_col_path && K2 <= 256 && sorad_col_lds_reals<R>(np) * sizeof(R) <= (size_t)160 * 1024;
         const size_t o_lay = 0, o_swh = o_lay + al(4 * K2 * per), o_colv = o_swh + al(K2 * per), o_cld = o_colv + al(8 * per),
-                     o_scr = o_cld + al((size_t)SO_NGRP * 4 * K2 * per), o_psum = o_scr + al((size_t)SO_NPASS * 34 * K2 * per),
-                     need = o_psum + al((size_t)SO_NPASS * 2 * per);
+                     o_psum = o_cld + al((size_t)SO_NGRP * 4 * K2 * per), o_scr = o_psum + al((size_t)SO_NPASS * 3 * per),
+                     need = o_scr + (col_path ? 0 : al((size_t)SO_NPASS * 34 * K2 * per));
+        const size_t so_lds = sorad_col_lds_reals<R>(np) * sizeof(R);
+        if (col_path) {
+            if (so_lds > so_lds_set) {
+                HIPCHK(hipFuncSetAttribute((const void *)k_sorad_col<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)so_lds));
+                so_lds_set = so_lds;
+            }
+        }
         if (need > ws_so_bytes) {
             if (d_ws_so) { HIPCHK(hipFree(d_ws_so)); d_ws_so = nullptr; ws_so_bytes = 0; }
             if (hipMalloc((void **)&d_ws_so, need) != hipSuccess)
@@ -2056,22 +2069,28 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.reff = P(SI_REFF); A.taua = P(SI_TAUA); A.ssaa = P(SI_SSAA); A.asya = P(SI_ASYA); A.rsuvbm = P(SI_RSUVBM);
             A.rsuvdf = P(SI_RSUVDF); A.rsirbm = P(SI_RSIRBM); A.rsirdf = P(SI_RSIRDF);
             A.lay = (R *)(d_ws_so + o_lay); A.swh = (R *)(d_ws_so + o_swh); A.colv = (R *)(d_ws_so + o_colv); A.cld = (R *)(d_ws_so + o_cld);
-            A.scr = (R *)(d_ws_so + o_scr); A.psum = (R *)(d_ws_so + o_psum);
+            A.psum = (R *)(d_ws_so + o_psum); A.scr = col_path ? nullptr : (R *)(d_ws_so + o_scr);
             const dim3 blk(256);
             const unsigned gx = (unsigned)((nc + 255) / 256);
             span_begin(12, st);
             hipLaunchKernelGGL(k_sorad_prep<R>, dim3(gx), blk, 0, st, A);
             hipLaunchKernelGGL(k_sorad_cloud<R>, dim3(gx, SO_NGRP), blk, 0, st, A, (const SoradDev<R> *)d_O);
             span_end(st);
-            span_begin(13, st);
-            hipLaunchKernelGGL(k_sorad_pass<R>, dim3(gx, SO_NPASS), blk, 0, st, A, (const SoradDev<R> *)d_O);
-            span_end(st);
             SoradOut<R> O{};
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
             O.flx = Q(SOO_FLX); O.flc = Q(SOO_FLC); O.fdiruv = Q(SOO_FDIRUV); O.fdifuv = Q(SOO_FDIFUV); O.fdirpar = Q(SOO_FDIRPAR);
             O.fdifpar = Q(SOO_FDIFPAR); O.fdirir = Q(SOO_FDIRIR); O.fdifir = Q(SOO_FDIFIR); O.flxu = Q(SOO_FLXU); O.flcu = Q(SOO_FLCU);
             O.flx_sfc_band = Q(SOO_SFCBAND); O.drband = Q(SOO_DRBAND); O.dfband = Q(SOO_DFBAND);
-            hipLaunchKernelGGL(k_sorad_sum<R>, dim3(gx, np + 1), blk, 0, st, A, O);
+            span_begin(13, st);
+            if (col_path) {   // one block per column, lanes = (pass slot, level) (whole wavefronts), all 35 passes on chip
+                const unsigned nthr = (unsigned)sorad_col_threads(np);
+                const unsigned grid = 8u * (unsigned)((nc + 7) / 8);
+                hipLaunchKernelGGL(k_sorad_col<R>, dim3(grid), dim3(nthr), so_lds, st, A, (const SoradDev<R> *)d_O, O);
+            } else {
+                hipLaunchKernelGGL(k_sorad_pass<R>, dim3(gx, SO_NPASS), blk, 0, st, A, (const SoradDev<R> *)d_O);
+                hipLaunchKernelGGL(k_sorad_sum<R>, dim3(gx, np + 1), blk, 0, st, A, O);
+            }
+            span_end(st);
             hipLaunchKernelGGL(k_sorad_reduce<R>, dim3(gx), blk, 0, st, A, (const SoradDev<R> *)d_O, O);
         }
         HIPCHK(hipGetLastError());
@@ -2244,6 +2263,7 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
     {   // A/B switch for the measurements in profiles/: GEOSRAD_LW_PATH=cols | bands
         const char *e = getenv("GEOSRAD_LW_PATH");
         if (e) c->lw_cols_path = !strcmp(e, "cols");
+        if ((e = getenv("GEOSRAD_SORAD_PATH"))) c->sorad_col_path = !strcmp(e, "col");
         // tuning of the host-pointer pipeline: columns per staged chunk, copy threads
         if ((e = getenv("GEOSRAD_HOST_CHUNK")) && atoi(e) >= 64) c->host_chunk = c->host_chunk_default = atoi(e);
         if ((e = getenv("GEOSRAD_HOST_THREADS")) && atoi(e) >= 1) c->host_threads = atoi(e) > 64 ? 64 : atoi(e);

@@ -3,12 +3,13 @@
 // Reference behaviour: GEOSsolar_GridComp/sorad.F90:43-1588 (SOLUV / SOLIR / CLDFLX inlined, O2 + CO2 flux reductions),
 // deledd :1592-1706; cloud optics GEOS_RadiationShared/getvistau.code, getnirtau.code.  Non-OVERCAST build.
 //
-// sorad is 35 independent spectral passes (5 UV/PAR bands + 3 NIR bands x 10 k-values), each a set of first-order vertical
-// recurrences (delta-Eddington layers + adding over 8 sky situations) -- the RRTMG_SW mapping applies: lane = column,
-// blockIdx.y = spectral pass, every per-level array of a pass in an HBM scratch plane [array][level][column] (coalesced):
+// sorad is 35 independent spectral passes (5 UV/PAR bands + 3 NIR bands x 10 k-values), each a set of delta-Eddington layers (no
+// vertical dependence, fp64, the expensive part) + first-order vertical recurrences (adding over up to 8 sky situations):
 //   k_sorad_prep   : per column   - scaled absorber amounts, cloud-group covers, cloud top
 //   k_sorad_cloud  : per (column, optics group: UV/PAR + 3 NIR bands) - getvistau / getnirtau
-//   k_sorad_pass   : per (column, pass) - deledd of the clear / cloudy portion of every layer, CLDFLX
+//   k_sorad_pass   : per (column, pass), lane = column - deledd of the clear / cloudy portion of every layer, CLDFLX; the per-level arrays of
+//                    the pass in HBM scratch planes [array][level][column] (coalesced); k_sorad_sum adds the passes up (default path)
+//   k_sorad_col    : per column, lanes = (pass, level), the 35 passes on chip: no scratch (GEOSRAD_SORAD_PATH=col)
 //   k_sorad_reduce : per column   - weighted sum over the passes (hk_uv, hk_ir), flux reductions, surface rescaling
 // Sky situations of zero weight (ct = 0: a cloud group without cloud) are skipped: their contribution is `+ x * 0`.
 #pragma once
@@ -36,8 +37,8 @@ template <typename R> struct SoradArgs {
     R *swh;          // [K2][m]    cumulative scaled water vapour (index k = 1..np+1)
     R *colv;         // [8][m]: cc1, cc2, cc3, wvtoa, o3toa, scal0, ntop (as real), spare
     R *cld;          // [SO_NGRP][4][K2][m]: tauclb, tauclf, asycl, ssacl
-    R *scr;          // [SO_NPASS][34][K2][m]: per-pass planes (see k_sorad_pass)
-    R *psum;         // [SO_NPASS][2][m]: fsdir, fsdif of the pass
+    R *scr;          // [SO_NPASS][34][K2][m]: per-pass planes of k_sorad_pass (null on the k_sorad_col path)
+    R *psum;         // [SO_NPASS][3][m]: fsdir, fsdif and the all-sky net flux at the surface of the pass
 };
 template <typename R> struct SoradOut { R *flx, *flc, *fdiruv, *fdifuv, *fdirpar, *fdifpar, *fdirir, *fdifir, *flxu, *flcu, *flx_sfc_band, *drband, *dfband; };
 
@@ -433,8 +434,9 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
             }
         }
     }
-    A.psum[((size_t)pass * 2 + 0) * m + i] = fsdir;
-    A.psum[((size_t)pass * 2 + 1) * m + i] = fsdif;
+    A.psum[((size_t)pass * 3 + 0) * m + i] = fsdir;
+    A.psum[((size_t)pass * 3 + 1) * m + i] = fsdif;
+    A.psum[((size_t)pass * 3 + 2) * m + i] = P(30, np + 1);      // all-sky net flux at the surface (read back from this thread's own plane)
 #undef P
 #undef LY
 #undef TDA
@@ -466,6 +468,212 @@ __global__ void __launch_bounds__(256) k_sorad_sum(SoradArgs<R> A, SoradOut<R> O
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_sorad_col: one block per column, lanes = (pass slot, LEVEL); the 35 spectral passes (5 UV/PAR + 3 x 10 NIR) three at a time with every
+// per-level array of a pass in LDS - nothing of a pass touches HBM (the first version kept 34 planes of scratch per (column, pass)
+// there: 1.6 MB of traffic per column).  Per pass:
+//   phase A (lane = layer k): delta-Eddington R / T of the clear and the cloudy portion of the layer (4 x deledd in fp64, no vertical
+//           dependence; sorad.F90:436-520, 996-1068); lanes 0 and np+1: the layer above the model top and the surface (:365-387, 914-936)
+//   phase B (lane = one of 16 chains): CLDFLX's adding recurrences (:689-872) are first-order in the level index; each of the up to 8
+//           sky situations (high, middle, low group clear | cloudy) has one chain from the top (direct / total transmittance and diffuse
+//           reflectance of the layers above a level) and one from the surface (reflectances of the layers below): 16 lanes walk them
+//           side by side.  (The reference shares a chain's first groups between situations; the values are the same.)
+//   phase C (lane = level k): fluxes of every situation at the level, Eqs. (6.15)-(6.16), weighted by the situation's probability,
+//           then the pass's share hk of the four level fluxes - accumulated over the passes in registers, in pass order (Eq. 6.1).
+// LDS (reals): the column's inputs staged once [3 K2 + 3*8*np + 16 K2]; per pass slot: layer properties [2][5][K2], composites [8][5][K2].
+// ---------------------------------------------------------------------------------------------------
+// Q passes are worked on at a time (lane = (pass slot, level)): Q * (np + 2) lanes of a 256-thread block, 3 for 72 layers
+__host__ __device__ constexpr int sorad_col_q(int np) { return 256 / (np + 2) < 3 ? (256 / (np + 2) < 1 ? 1 : 256 / (np + 2)) : 3; }
+__host__ __device__ constexpr int sorad_col_threads(int np) { return (sorad_col_q(np) * (np + 2) + 63) / 64 * 64; }
+template <typename R> __host__ __device__ constexpr size_t sorad_col_lds_reals(int np)
+{
+    return (size_t)19 * (np + 2) + (size_t)24 * np + (size_t)sorad_col_q(np) * 50 * (np + 2);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp, SoradOut<R> O)
+{
+    extern __shared__ __align__(16) unsigned char so_lds_raw[];
+    R *const lds = reinterpret_cast<R *>(so_lds_raw);
+    // consecutive blocks go to the 8 XCDs in turn: give each XCD a contiguous range of columns (neighbouring columns share the
+    // sectors of the column-fastest input arrays, and so meet in one L2)
+    const int per = (A.m + 7) / 8;
+    const int i = (int)(blockIdx.x % 8u) * per + (int)(blockIdx.x / 8u);
+    if (i >= A.m || (int)(blockIdx.x / 8u) >= per) return;
+    const SoradDev<R> &T = *Tp;
+    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int Q = sorad_col_q(np);
+    const int q = t / K2, k = t - q * K2;          // pass slot and level of this lane (q >= Q: idle lanes of the last wavefront)
+    R *const s_lay = lds;                          // [3][K2]     dp, wh, oh
+    R *const s_aer = s_lay + 3 * K2;               // [3][8][np]  taua, ssaa, asya
+    R *const s_cld = s_aer + 24 * np;              // [4 groups][4][K2]
+    R *const s_lyq = s_cld + 16 * K2;              // [Q][2 portions][5][K2]  rr, tt, td, rs, ts; after phase B: [Q][4][K2] level fluxes of the pass
+    R *const s_cpq = s_lyq + (size_t)Q * 10 * K2;  // [Q][8 situations][5][K2] tda, tta, rsa (level = lower boundary of k), rra, rxa
+    for (int e = t; e < 3 * K2; e += nt) s_lay[e] = A.lay[(size_t)e * m + i];
+    for (int e = t; e < 8 * np; e += nt) {
+        const size_t ja = (size_t)e * ld + i;
+        s_aer[e] = A.taua[ja]; s_aer[8 * np + e] = A.ssaa[ja]; s_aer[16 * np + e] = A.asya[ja];
+    }
+    for (int e = t; e < 16 * K2; e += nt) s_cld[e] = A.cld[(size_t)e * m + i];
+    const R cz = A.cosz[i], dsm = (R)0.602;
+    const R cc1 = A.colv[0 * (size_t)m + i], cc2 = A.colv[1 * (size_t)m + i], cc3 = A.colv[2 * (size_t)m + i];
+    const R wvtoa = A.colv[3 * (size_t)m + i], o3toa = A.colv[4 * (size_t)m + i];
+    const int nh = cc1 > 0 ? 2 : 1, nm = cc2 > 0 ? 2 : 1, ns = cc3 > 0 ? 2 : 1;       // portions of non-zero weight
+    __syncthreads();
+    R *const s_ly = s_lyq + (size_t)(q < Q ? q : 0) * 10 * K2;
+    R *const s_cp = s_cpq + (size_t)(q < Q ? q : 0) * 40 * K2;
+#define LY(f, j, kk) s_ly[(((j) - 1) * 5 + (f)) * K2 + (kk)]              // f: 0 rr 1 tt 2 td 3 rs 4 ts;  j: 1 clear, 2 cloudy portion
+#define CP(s_, f, kk) s_cp[((s_) * 5 + (f)) * K2 + (kk)]                  // f: 0 tda 1 tta 2 rsa 3 rra 4 rxa
+    R flx = 0, flc = 0, flxu = 0, flcu = 0;      // lanes of slot 0: this level's Eq. (6.1) sums over the passes, in pass order
+    const int nround = (SO_NPASS + Q - 1) / Q;
+    for (int rnd = 0; rnd < nround; rnd++) {
+        const int pass = rnd * Q + q;
+        const bool live = q < Q && pass < SO_NPASS;
+        const bool uv = pass < 5;
+        const int ib = uv ? pass + 1 : (pass - 5) / 10 + 1, ik = uv ? 0 : (pass - 5) % 10 + 1;   // band in its region, k-value
+        const int iv = uv ? ib : ib + 5;                                                         // aerosol band 1..8
+        const int grp = uv ? 0 : ib;
+        // ---- phase A: lane = (pass slot, layer) ---------------------------------------------------------------------------------
+        if (live) {
+            if (k == 0) {
+                const R td0 = uv ? gr_exp<R>(-(wvtoa * T.wk_uv[ib - 1] + o3toa * T.zk_uv[ib - 1]) / cz) : gr_exp<R>(-wvtoa * T.xk_ir[ik - 1] / cz);
+                for (int j = 1; j <= 2; j++) { LY(0, j, 0) = 0; LY(3, j, 0) = 0; LY(1, j, 0) = 1; LY(4, j, 0) = 1; LY(2, j, 0) = td0; }
+            } else if (k == np + 1) {
+                const R rb = uv ? A.rsuvbm[i] : A.rsirbm[i], rd = uv ? A.rsuvdf[i] : A.rsirdf[i];
+                for (int j = 1; j <= 2; j++) { LY(0, j, np + 1) = rb; LY(3, j, np + 1) = rd; LY(2, j, np + 1) = 0; LY(1, j, np + 1) = 0; LY(4, j, np + 1) = 0; }
+            } else {
+                const R dp = s_lay[0 * K2 + k], wh = s_lay[1 * K2 + k], oh = s_lay[2 * K2 + k];
+                const int ja = (iv - 1) * np + (k - 1);
+                const R ta_ = s_aer[ja], sa_ = s_aer[8 * np + ja], as_ = s_aer[16 * np + ja];
+                R taurs, tausto, ssatau;
+                if (uv) {
+                    taurs = T.ry_uv[ib - 1] * dp;
+                    tausto = taurs + T.zk_uv[ib - 1] * oh + T.wk_uv[ib - 1] * wh + ta_ + (R)1.0e-7;
+                    ssatau = sa_ + taurs;
+                } else {
+                    taurs = T.ry_ir[ib - 1] * dp;
+                    tausto = taurs + T.xk_ir[ik - 1] * wh + ta_ + (R)1.0e-7;
+                    ssatau = sa_ + taurs + (R)1.0e-8;
+                }
+                const R asysto = as_;
+                R tautob = tausto, asytob = asysto / ssatau, ssatob = ssatau / tautob + (R)1.0e-8;
+                ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
+                R rrt, ttt, tdt, rst, tst, dum;
+                so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
+                so_deledd<R>(tautob, ssatob, asytob, dsm, rst, tst, dum);
+                LY(0, 1, k) = rrt; LY(1, 1, k) = ttt; LY(2, 1, k) = tdt; LY(3, 1, k) = rst; LY(4, 1, k) = tst;
+                // the cloudy portion only matters in sky situations of non-zero weight, i.e. when the layer's group has cloud
+                const R ccg = k < ict ? cc1 : (k < icb ? cc2 : cc3);
+                if (ccg > 0) {
+                    const R tcb = s_cld[(grp * 4 + 0) * K2 + k], tcf = s_cld[(grp * 4 + 1) * K2 + k], asyc = s_cld[(grp * 4 + 2) * K2 + k];
+                    const R ssac = uv ? (R)1 : s_cld[(grp * 4 + 3) * K2 + k];
+                    tautob = tausto + tcb;
+                    ssatob = (uv ? (ssatau + tcb) : (ssatau + ssac * tcb)) / tautob + (R)1.0e-8;
+                    ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
+                    asytob = (uv ? (asysto + asyc * tcb) : (asysto + asyc * ssac * tcb)) / (ssatob * tautob);
+                    const R tautof = tausto + tcf;
+                    R ssatof = (uv ? (ssatau + tcf) : (ssatau + ssac * tcf)) / tautof + (R)1.0e-8;
+                    ssatof = ssatof < (R)0.999999 ? ssatof : (R)0.999999;
+                    const R asytof = (uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf)) / (ssatof * tautof);
+                    so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
+                    so_deledd<R>(tautof, ssatof, asytof, dsm, rst, tst, dum);
+                    LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase B: lane = (pass slot, chain): situation s = ((ih-1)*2 + (im-1))*2 + (is-1), from the top (chains 0-7) / from the surface (8-15)
+        if (t < 16 * Q && rnd * Q + t / 16 < SO_NPASS) {
+            const int qb = t / 16, c = t & 15;
+            R *const b_ly = s_lyq + (size_t)qb * 10 * K2;
+            R *const b_cp = s_cpq + (size_t)qb * 40 * K2;
+#define BLY(f, j, kk) b_ly[(((j) - 1) * 5 + (f)) * K2 + (kk)]
+#define BCP(s_, f, kk) b_cp[((s_) * 5 + (f)) * K2 + (kk)]
+            const int s_ = c & 7, ih = 1 + ((s_ >> 2) & 1), im = 1 + ((s_ >> 1) & 1), is = 1 + (s_ & 1);
+            if (ih <= nh && im <= nm && is <= ns) {
+                if (c < 8) {
+                    R tda = BLY(2, ih, 0), tta = BLY(1, ih, 0), rsa = BLY(3, ih, 0);
+                    BCP(s_, 0, 0) = tda; BCP(s_, 1, 0) = tta; BCP(s_, 2, 0) = rsa;
+                    for (int kk = 1; kk <= np; kk++) {
+                        const int j = kk < ict ? ih : (kk < icb ? im : is);
+                        const R rr = BLY(0, j, kk), tt = BLY(1, j, kk), td = BLY(2, j, kk), rs = BLY(3, j, kk), ts = BLY(4, j, kk);
+                        const R denm = ts / ((R)1. - rsa * rs);
+                        // (the reference writes tda*rsa*rr in the high and middle groups and tda*rr*rsa in the low one)
+                        const R x3 = kk < icb ? tda * rsa * rr : tda * rr * rsa;
+                        const R ntta = tda * tt + (x3 + tta - tda) * denm;
+                        const R nrsa = rs + ts * rsa * denm;
+                        tda = tda * td; tta = ntta; rsa = nrsa;
+                        BCP(s_, 0, kk) = tda; BCP(s_, 1, kk) = tta; BCP(s_, 2, kk) = rsa;
+                    }
+                } else {
+                    R rra = BLY(0, is, np + 1), rxa = BLY(3, is, np + 1);
+                    BCP(s_, 3, np + 1) = rra; BCP(s_, 4, np + 1) = rxa;
+                    for (int kk = np; kk >= 0; kk--) {
+                        const int j = kk >= icb ? is : (kk >= ict ? im : ih);
+                        const R rr = BLY(0, j, kk), tt = BLY(1, j, kk), td = BLY(2, j, kk), rs = BLY(3, j, kk), ts = BLY(4, j, kk);
+                        const R denm = ts / ((R)1. - rs * rxa);
+                        const R nrra = rr + (td * rra + (tt - td) * rxa) * denm;
+                        rxa = rs + ts * rxa * denm; rra = nrra;
+                        BCP(s_, 3, kk) = rra; BCP(s_, 4, kk) = rxa;
+                    }
+                }
+            }
+#undef BLY
+#undef BCP
+        }
+        __syncthreads();
+        // ---- phase C: lane = (pass slot, level k = 1 .. np+1): integration over the sky situations of non-zero weight -----------
+        if (live && k >= 1) {
+            R fall = 0, fclr = 0, fupa = 0, fupc = 0, fsdir = 0, fsdif = 0;
+            for (int ih = 1; ih <= nh; ih++) {
+                const R ch = ih == 1 ? (R)1.0 - cc1 : cc1;
+                for (int im = 1; im <= nm; im++) {
+                    const R cm = im == 1 ? ch * ((R)1.0 - cc2) : ch * cc2;
+                    for (int is = 1; is <= ns; is++) {
+                        const R ct = is == 1 ? cm * ((R)1.0 - cc3) : cm * cc3;
+                        const int s_ = ((ih - 1) * 2 + (im - 1)) * 2 + (is - 1);
+                        const R tda = CP(s_, 0, k - 1), tta = CP(s_, 1, k - 1), rsa = CP(s_, 2, k - 1), rra = CP(s_, 3, k), rxa = CP(s_, 4, k);
+                        const R denm = (R)1. / ((R)1. - rsa * rxa);      // Eqs. (6.15), (6.16)
+                        const R fdndir = tda;
+                        const R xx4 = tda * rra, yy = tta - tda;
+                        const R fdndif = (xx4 * rsa + yy) * denm;
+                        const R fupdif = (xx4 + yy * rxa) * denm;
+                        const R flxdn = fdndir + fdndif - fupdif;
+                        // the first sky situation (all-clear portions) starts the weighted sums: 0 + x * ct, as the reference's zeroed arrays give
+                        if (s_ == 0) { fupc = fupdif; fclr = flxdn; fupa = (R)0 + fupdif * ct; fall = (R)0 + flxdn * ct; }
+                        else { fupa = fupa + fupdif * ct; fall = fall + flxdn * ct; }
+                        fsdir = fsdir + fdndir * ct;
+                        fsdif = fsdif + fdndif * ct;
+                    }
+                }
+            }
+            // the pass's level fluxes, for the lanes of slot 0 to add up in pass order (the layer properties are not needed any more)
+            s_ly[0 * K2 + k] = fall; s_ly[1 * K2 + k] = fclr; s_ly[2 * K2 + k] = fupa; s_ly[3 * K2 + k] = fupc;
+            if (k == np + 1) {      // surface: what k_sorad_reduce needs of the pass
+                A.psum[((size_t)pass * 3 + 0) * m + i] = fsdir;
+                A.psum[((size_t)pass * 3 + 1) * m + i] = fsdif;
+                A.psum[((size_t)pass * 3 + 2) * m + i] = fall;
+            }
+        }
+        __syncthreads();
+        if (q == 0 && k >= 1) {
+            for (int qq = 0; qq < Q && rnd * Q + qq < SO_NPASS; qq++) {
+                const R hk = A.hk[rnd * Q + qq];
+                const R *const f = s_lyq + (size_t)qq * 10 * K2;
+                flx = flx + f[0 * K2 + k] * hk; flc = flc + f[1 * K2 + k] * hk; flxu = flxu + f[2 * K2 + k] * hk; flcu = flcu + f[3 * K2 + k] * hk;
+            }
+        }
+        __syncthreads();       // the next round rewrites the layer properties and the composites
+    }
+#undef LY
+#undef CP
+    if (q == 0 && k >= 1) {
+        const size_t o = (size_t)(k - 1) * ld + i;
+        O.flx[o] = flx; O.flc[o] = flc; O.flxu[o] = flxu; O.flcu[o] = flcu;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_sorad_reduce: per column -- flux integration over the passes (Eq. 6.1), O2 / CO2 reductions (:1425-1552), surface rescaling
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
@@ -476,15 +684,14 @@ __global__ void __launch_bounds__(256) k_sorad_reduce(SoradArgs<R> A, const Sora
     const SoradDev<R> &T = *Tp;
     const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
 #define OUT2(a, k) a[(size_t)((k) - 1) * ld + i]
-#define SCR(pass, q, k) A.scr[(((size_t)(pass) * 34 + (q)) * K2 + (k)) * m + i]
-    // (the level fluxes were summed over the passes by k_sorad_sum)
+    // (the level fluxes were summed over the passes by k_sorad_col)
     // surface band fluxes and direct / diffuse partition
     R fdiruv = 0, fdifuv = 0, fdirpar = 0, fdifpar = 0, fdirir = 0, fdifir = 0, band[8], drb[8], dfb[8];
     for (int b = 0; b < 8; b++) { band[b] = 0; drb[b] = 0; dfb[b] = 0; }
     for (int p = 0; p < SO_NPASS; p++) {
-        const R hk = A.hk[p], fs = A.psum[((size_t)p * 2 + 0) * m + i], fd = A.psum[((size_t)p * 2 + 1) * m + i];
+        const R hk = A.hk[p], fs = A.psum[((size_t)p * 3 + 0) * m + i], fd = A.psum[((size_t)p * 3 + 1) * m + i];
         const int b = p < 5 ? p : 5 + (p - 5) / 10;
-        band[b] = band[b] + SCR(p, 30, np + 1) * hk; drb[b] = drb[b] + fs * hk; dfb[b] = dfb[b] + fd * hk;
+        band[b] = band[b] + A.psum[((size_t)p * 3 + 2) * m + i] * hk; drb[b] = drb[b] + fs * hk; dfb[b] = dfb[b] + fd * hk;
         if (p < 4) { fdiruv = fdiruv + fs * hk; fdifuv = fdifuv + fd * hk; }
         else if (p == 4) { fdirpar = fs * hk; fdifpar = fd * hk; }
         else { fdirir = fdirir + fs * hk; fdifir = fdifir + fd * hk; }
@@ -550,7 +757,6 @@ __global__ void __launch_bounds__(256) k_sorad_reduce(SoradArgs<R> A, const Sora
         if (A.do_drfband) { O.drband[(size_t)b * ld + i] = xx4 * drb[b]; O.dfband[(size_t)b * ld + i] = xx4 * dfb[b]; }
     }
 #undef OUT2
-#undef SCR
 }
 
 }  // namespace geosrad

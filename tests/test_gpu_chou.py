@@ -119,3 +119,39 @@ def test_sorad_properties(gpu_ctx):
     r = ctx.rrtmg_sw_columns(flat, normFlx=1, iaer=10)
     d = np.abs(af["flcu"][0] - r["swuflxc"][-1])
     assert d.max() < 0.03 and np.median(d) < 0.012, (d.max(), np.median(d))
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_sorad_on_chip_path_matches_oracle_and_default_path(gpu_ctx, rk):
+    """GEOSRAD_SORAD_PATH=col: one block per column, lanes = (pass, level), the 35 passes in LDS - no per-pass scratch in HBM
+    (sorad_kernels.hpp k_sorad_col).  Same gates as the default path, and the two agree."""
+    import os
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import Context
+    from oracle import clib
+    old = os.environ.get("GEOSRAD_SORAD_PATH")
+    os.environ["GEOSRAD_SORAD_PATH"] = "col"
+    try:
+        ctx = Context(rk)
+    finally:
+        if old is None:
+            del os.environ["GEOSRAD_SORAD_PATH"]
+        else:
+            os.environ["GEOSRAD_SORAD_PATH"] = old
+    try:
+        for nlay, cf in ((72, 0.7), (137, 1.0), (72, 0.0)):
+            inp = synth.make_columns(70, nlay, start=5150 + nlay, cloudy_frac=cf, aerosol=True)
+            cs = synth.chou_sw_inputs(inp, aerosol=True)
+            g = ctx.sorad_columns(cs, do_drfband=True)
+            d = gpu_ctx[rk].sorad_columns(cs, do_drfband=True)
+            o = clib.sorad(cs, _kind(rk), do_drfband=True)
+            tol = 1e-9 if rk == 8 else 2e-5
+            for k in SO_KEYS:
+                assert np.abs(g[k].astype(np.float64) - o[k].astype(np.float64)).max() <= tol, (nlay, k)
+                assert np.abs(g[k].astype(np.float64) - d[k].astype(np.float64)).max() <= 0.1 * tol, (nlay, k)
+            sub = {k: (np.ascontiguousarray(v[..., 20:41]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == 70 else v) for k, v in cs.items()}
+            p = ctx.sorad_columns(sub, do_drfband=True)
+            for k in SO_KEYS:
+                np.testing.assert_array_equal(p[k], g[k][..., 20:41], err_msg=k)      # a column's result does not depend on its batch
+    finally:
+        ctx.close()

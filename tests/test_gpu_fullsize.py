@@ -86,7 +86,7 @@ def test_chou_pair_100k_columns(gpu_ctx):
         assert np.isfinite(a[k]).all(), k
     for k in ("flx", "flc", "flxu", "flcu", "flx_sfc_band"):
         assert np.isfinite(s[k]).all(), k
-    assert (a["flxd"][0] == 0).all() and (-a["flxu"][0] > 80).all() and (-a["flxu"][0] < 400).all()        # OLR
+    assert (np.abs(a["flxd"][0]) < 1.0).all() and (-a["flxu"][0] > 80).all() and (-a["flxu"][0] < 400).all()        # OLR
     tot = s["flx"][0].astype(np.float64) + s["flxu"][0]
     assert (tot <= 1.0 + 1e-5).all() and (tot > 0.99).all()                                               # insolation = net + reflected
     clear = ~(inp["cldf"] > 0).any(axis=0)
