@@ -717,8 +717,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(cl * sizeof(R)); if (w) w->rcorr = (R *)p;
         p = take(NG_LW * cl * sizeof(R)); if (w) w->taucmc = (R *)p;
         const size_t clp = (size_t)nlay * (((size_t)nc + 255) & ~(size_t)255);      // tiled by 256-column block
-        p = take(NG_LW * clp * sizeof(R2)); if (w) w->s1 = (R2 *)p;
-        p = take(NG_LW * clp * sizeof(R2)); if (w) w->s2 = (R2 *)p;
+        // parked cells of the band sweeps: a 2-byte Pade index per (layer, g-point) and stream (lw_kernels.hpp band_body)
+        p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s1 = (R2 *)p;
+        p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s2 = (R2 *)p;
         p = take((size_t)6 * NB_LW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
         return off;
     }

@@ -1085,8 +1085,18 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     const R *const taucmc_b = A.taucmc + bandoff;
     // the parked (a, B-up) pairs are tiled by 256-column block, [block][layer][g][256]: a block's scratch is one contiguous run
     const uint32_t npad = ((uint32_t)n + 255u) & ~255u;
-    R2 *const s1_b = A.s1 + (size_t)G0 * nlay * npad;
-    R2 *const s2_b = A.s2 + (size_t)G0 * nlay * npad;
+    // what is parked per cell between the sweeps: the Pade index of the cell's discretised optical depth, 2 bytes - the up sweep
+    // re-forms (absorptivity, source) from it: table look-up + the layer's Planck terms + the Planck fraction, which is re-evaluated
+    // there (a quarter of the bytes of the (a, B-up) pair the first version parked; -DGEOSRAD_LW_PARK_PAIRS builds that version)
+#ifdef GEOSRAD_LW_PARK_PAIRS
+    using PK = R2;
+#define LW_PK(a_, bbu_, it_) R2{(a_), (bbu_)}
+#else
+    using PK = uint16_t;
+#define LW_PK(a_, bbu_, it_) ((uint16_t)(it_))
+#endif
+    PK *const s1_b = reinterpret_cast<PK *>(A.s1) + (size_t)G0 * nlay * npad;
+    PK *const s2_b = reinterpret_cast<PK *>(A.s2) + (size_t)G0 * nlay * npad;
     const uint32_t tbase = (ucol >> 8) * (uint32_t)nlay * (uint32_t)NG * 256u + (ucol & 255u);
 #ifdef GEOSRAD_LW_NOTILE
 #define SCELL(lay, g) (((uint32_t)(lay) * (uint32_t)NG + (uint32_t)(g)) * (uint32_t)npad + ucol)
@@ -1114,7 +1124,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
 
     // (a, B-up) pairs of the g-group processed last, waiting to be written (see phase 2 below)
     constexpr bool DEFER = !CLD;       // the cloudy instantiation has no registers to spare for it
-    R2 pend1[W], pend2[W];
+    PK pend1[W], pend2[W];
     uint32_t poff[W];
     int npend = 0;
     uint32_t pmask2 = 0;
@@ -1168,8 +1178,8 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
 #pragma unroll
                 for (int j = 0; j < W; j++)
                     if (j < npend) {
-                        stg_nt(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
-                        if (CLD && (pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
+                        stg_nt(s1_b, poff[j] * (uint32_t)sizeof(PK), pend1[j]);
+                        if (CLD && (pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(PK), pend2[j]);
                     }
             }
             npend = 0; pmask2 = 0;
@@ -1187,6 +1197,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 const uint32_t cell = cell0 + (uint32_t)g * (uint32_t)n;
                 const uint32_t scell = SCELL(lay, g);
                 R atot = agas, bbutot = bbugas;
+                int itp = itgas;                 // index parked for the total-sky stream
                 const R radprev = rad[g];
                 bool cldcell = false;
                 if (CLD && laycld) {
@@ -1197,6 +1208,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                         const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
                         const R tb2 = odtot / (bpade + odtot);
                         const int ittot = (int)(tblint * tb2 + (R)0.5);
+                        itp = ittot;
                         const R2 e2 = lut_at(ittot);
                         atot = (R)1. - e2.x;
                         const R bbdtot = pf[j] * (blay + e2.y * dplankdn);
@@ -1205,14 +1217,14 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     }
                 }
                 if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
-                if (DEFER) { pend1[j].x = atot; pend1[j].y = bbutot; poff[j] = scell; npend = j + 1; }
-                else { R2 sv; sv.x = atot; sv.y = bbutot; stg_nt(s1_b, scell * (uint32_t)sizeof(R2), sv); }
+                if (DEFER) { pend1[j] = LW_PK(atot, bbutot, itp); poff[j] = scell; npend = j + 1; }
+                else stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(atot, bbutot, itp));
                 dsum = dsum + sumfac * rad[g];
                 if (CLD && ccol) {
                     if (diverge) {
                         radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
-                        if (DEFER) { pend2[j].x = agas; pend2[j].y = bbugas; pmask2 |= 1u << j; }
-                        else { R2 sg; sg.x = agas; sg.y = bbugas; stg_nt(s2_b, scell * (uint32_t)sizeof(R2), sg); }
+                        if (DEFER) { pend2[j] = LW_PK(agas, bbugas, itgas); pmask2 |= 1u << j; }
+                        else stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(agas, bbugas, itgas));
                     } else {
                         radc[g] = rad[g];
                     }
@@ -1290,25 +1302,26 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 const R bbugas = pf[j] * (blay + tfacgas * dplankup);
                 const uint32_t scell = SCELL(lay, g);
                 R atot = agas, bbutot = bbugas, bbd = bbdgas;
+                int itp = itg[j];
                 if (wcl) {
                     // cloud added to the DISCRETISED gas tau (:264-268); evaluated for the whole wave, kept for the cloudy cells
                     const bool cld = tcv[j] > 0;
                     const R odtot = ttb[j] + secdiff * tcv[j];
                     const R tb2 = odtot / (bpade + odtot);
                     const int ittot = (int)(tblint * tb2 + (R)0.5);
-                    const R2 e2 = lut_at(cld ? ittot : itg[j]);
+                    itp = cld ? ittot : itg[j];
+                    const R2 e2 = lut_at(itp);
                     const R ac = (R)1. - e2.x;
                     const R bbdtot = pf[j] * (blay + e2.y * dplankdn), bbut = pf[j] * (blay + e2.y * dplankup);
                     atot = cld ? ac : agas; bbutot = cld ? bbut : bbugas; bbd = cld ? bbdtot : bbdgas;
                 }
                 rad[g] = rad[g] + (bbd - rad[g]) * atot;
-                R2 sv; sv.x = atot; sv.y = bbutot;
-                stg_nt(s1_b, scell * (uint32_t)sizeof(R2), sv);
+                stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(atot, bbutot, itp));
                 dsum = dsum + sumfac * rad[g];
                 if (CLD) {
                     const R rc = radc[g] + (bbdgas - radc[g]) * agas;
                     radc[g] = diverge ? rc : rad[g];
-                    if (wdv) { R2 sg; sg.x = agas; sg.y = bbugas; stg_nt(s2_b, scell * (uint32_t)sizeof(R2), sg); }
+                    if (wdv) stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(agas, bbugas, itg[j]));
                     dcsum = dcsum + sumfac * radc[g];
                 }
                 if (lay == 0) {
@@ -1335,8 +1348,8 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
 #pragma unroll
     for (int j = 0; j < W; j++)
         if (j < npend) {
-            stg_nt(s1_b, poff[j] * (uint32_t)sizeof(R2), pend1[j]);
-            if (CLD && (pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(R2), pend2[j]);
+            stg_nt(s1_b, poff[j] * (uint32_t)sizeof(PK), pend1[j]);
+            if (CLD && (pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(PK), pend2[j]);
         }
     // TOA downward flux is zero (level nlay); written so the reduce kernel can sum unconditionally
     PART(0, nlay, 0);
@@ -1355,18 +1368,19 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     }
     for (int lay = 0; lay < nlay; lay++) {
         usum = 0; ucsum = 0; dusum = 0; ducsum = 0;
-        R2 sv[NG], sg[NG];
+        PK sv[NG], sg[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) sv[g] = ldg_nt(s1_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
+        for (int g = 0; g < NG; g++) sv[g] = ldg_nt(s1_b, SCELL(lay, g) * (uint32_t)sizeof(PK));
         if (CLD && lay <= wtop) {
             // (lanes that have no pair of their own here read what happens to be there and do not use it)
 #pragma unroll
-            for (int g = 0; g < NG; g++) sg[g] = ldg_nt(s2_b, SCELL(lay, g) * (uint32_t)sizeof(R2));
+            for (int g = 0; g < NG; g++) sg[g] = ldg_nt(s2_b, SCELL(lay, g) * (uint32_t)sizeof(PK));
         } else {
 #pragma unroll
             for (int g = 0; g < NG; g++) sg[g] = sv[g];
         }
         const bool own = CLD && ccol && diverge && lay <= ltop;      // above ltop the layer is clear for every g-point: gas == total
+#ifdef GEOSRAD_LW_PARK_PAIRS
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             rad[g] = rad[g] + (sv[g].y - rad[g]) * sv[g].x;
@@ -1382,10 +1396,46 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 ducsum = ducsum + sumfac * dclu[g];
             }
         }
+#else
+        // (absorptivity, upward source) of the cell from its parked index: the transmittance table, the layer's Planck terms and
+        // the Planck fraction, which the band body evaluates again (its optical-depth terms are dead code here)
+        Layer<R> L;
+        load_layer<R>(A, lay, col, pc, L);
+        Prep<R> P;
+        BAND::template prep<R>(T, A, L, P);
+        const R blay = planck_at<R>(T.totplnk, IB, ldg(A.tlay, L.ab));
+        const R dplankup = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)ld, L.ab)) - blay;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            R tau[W], pf[W];
+            BAND::template eval<R, W>(T, L, P, q * W, tau, pf);
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                if (g >= NG) continue;
+                const R2 e1 = lut_at((int)sv[g]);
+                const R a1 = (R)1. - e1.x, b1 = pf[j] * (blay + e1.y * dplankup);
+                rad[g] = rad[g] + (b1 - rad[g]) * a1;
+                dlu[g] = dlu[g] - dlu[g] * a1;
+                usum = usum + sumfac * rad[g];
+                dusum = dusum + sumfac * dlu[g];
+                if (CLD) {
+                    const R2 e2 = lut_at(own ? (int)sg[g] : (int)sv[g]);
+                    const R gx = (R)1. - e2.x, gy = pf[j] * (blay + e2.y * dplankup);
+                    const R rc = radc[g] + (gy - radc[g]) * gx, dc = dclu[g] - dclu[g] * gx;
+                    radc[g] = diverge ? rc : rad[g];
+                    dclu[g] = diverge ? dc : dlu[g];
+                    ucsum = ucsum + sumfac * radc[g];
+                    ducsum = ducsum + sumfac * dclu[g];
+                }
+            }
+        }
+#endif
         PART(2, lay + 1, usum);
         if (CLD && ccol) PART(3, lay + 1, ucsum);
         if (dudTs) { PART(4, lay + 1, dusum); if (CLD && ccol) PART(5, lay + 1, ducsum); }
     }
+#undef LW_PK
 #undef PART
 }
 
