@@ -760,8 +760,15 @@ def main():
         # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
         # separate rocprofv3 --pmc runs): only quoted for the exact configuration those passes were collected on
         traffic = None
-        if a.scheme == "lwsw" and (ncol, ncol_sw, nlay, a.cloudy, aerosol, a.real) == (97_200, 97_200, 72, 0.6, True, 4):
-            traffic = {"k_sw_bands": 66.6e9, "k_lw_bands": 30.1e9}.get(kname)      # profiles/r01_v9_lwsw_pmc_traffic.md (both instantiations)
+        default_paths = not (os.environ.get("GEOSRAD_LW_PATH") or os.environ.get("GEOSRAD_SORAD_PATH") or os.environ.get("GEOSRAD_LIB"))
+        if a.scheme == "lwsw" and default_paths and (ncol, ncol_sw, nlay, a.cloudy, aerosol, a.real) == (97_200, 97_200, 72, 0.6, True, 4):
+            # profiles/r02_traffic.json: the shipped build's counters, the kernel's launches of one step summed -> per launch here
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")) as fh:
+                    t = json.load(fh)["lwsw_97200_72_0.6_aer_f32"].get(kname)
+                traffic = t["traffic_bytes"] / launches_per_step if t else None
+            except (OSError, KeyError, ValueError):
+                traffic = None
         elif a.scheme == "chou" and (ncol, nlay, a.cloudy, aerosol, a.real) == (20_000, 72, 0.6, True, 4):
             traffic = {"k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
@@ -787,8 +794,8 @@ def main():
                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
                          "columns_per_launch": ncol_k / launches_per_step,
                          "note": "fused k-distribution + two-stream sweep is FP32/latency bound (~170 FLOP per algorithmic byte, "
-                                 "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small; `traffic` (PMC) is in "
-                                 "profiles/" + ("; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own "
+                                 "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small; `traffic` = PMC bytes of this "
+                                 "kernel per step / its launches per step (profiles/r02_traffic.json)" + ("; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own "
                                                 "duration from two further steps on one stream" if side is not None else "")},
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,

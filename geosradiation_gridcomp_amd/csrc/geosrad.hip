@@ -880,7 +880,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             } else if (A.dbg_taug) {
                 hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             } else {
-                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(band_grid(nc, NB_LW)), blk, lds, st, A, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             }
             span_end(st);
@@ -912,7 +912,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 B.part = rat_part;
                 span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, B, d_T); span_end(st);
                 span_begin(4, st);
-                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(band_grid(nc, NB_LW)), blk, lds, st, B, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
                 span_end(st);
                 LwOut<R> OR{};
@@ -1722,10 +1722,10 @@ template <typename R> struct Ctx : geosrad_ctx {
                                    (R *)dbg[4] + (size_t)c0 * NG_SW * nlay, (R *)dbg[5] + (size_t)c0 * NG_SW * nlay);
             span_begin(8, st);
             if (dbg) {
-                hipLaunchKernelGGL((k_sw_bands<R, true, true>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, true, true>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
             } else {
-                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
-                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
             }
             span_end(st);
             SwOut<R> O{};
@@ -1742,8 +1742,8 @@ template <typename R> struct Ctx : geosrad_ctx {
                 // sweeps and the reduction are repeated, without the aerosol terms; validation, setcoef and McICA are shared
                 A.iaer = 0; A.do_drfband = 0;
                 span_begin(8, st);
-                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
-                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(gx, NB_SW), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
+                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
                 span_end(st);
                 SwOut<R> N{};
                 auto QN = [&](int k) { return (R *)sw_na_out[k] + c0; };

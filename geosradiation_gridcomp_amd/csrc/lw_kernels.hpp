@@ -1452,7 +1452,26 @@ __host__ __device__ constexpr int lw_band_ng(int ib)
     return ng[ib];
 }
 
-// blockIdx.y selects the band.  Two instantiations are launched back to back: CLD = false handles the
+// Grid of the band kernels (RRTMG_LW and RRTMG_SW): one block per (256-column block, band), 8 * ceil(gx / 8) * nb blocks in ONE
+// dimension.  The hardware deals consecutive blocks to the 8 XCDs in turn; block id therefore takes XCD id % 8, and within that XCD
+// the nb bands of a column block are consecutive: they run at about the same time on one L2, so the column block's setcoef record,
+// gas arrays and indices - which every band reads - come from HBM once instead of once per band (the first version's
+// (column block, band) = (blockIdx.x, blockIdx.y) grid ran all column blocks of a band before the next band's).
+// A launch with gridDim.y == nb keeps the (column block, band) = (blockIdx.x, blockIdx.y) order: all column blocks of a band before the
+// next band, heaviest bands first - every resident block then runs the same band body on the same tables, which the cloudy RRTMG_LW
+// instantiation (the largest code) needs more than it needs the inputs from L2 (measured: 6.7 against 7.7 ms).
+GR_DEV bool band_block(int ncol, int nb, int &bstart, int &bslot)
+{
+    if (gridDim.y > 1) { bstart = (int)(blockIdx.x * blockDim.x); bslot = (int)blockIdx.y; return true; }
+    const unsigned id = blockIdx.x, xcd = id & 7u, slot = id >> 3;
+    const unsigned cblk = (slot / (unsigned)nb) * 8u + xcd;
+    bslot = (int)(slot % (unsigned)nb);
+    bstart = (int)(cblk * blockDim.x);
+    return bstart < ncol;
+}
+__host__ inline unsigned band_grid(int ncol, int nb) { const unsigned gx = (unsigned)((ncol + 255) / 256); return 8u * ((gx + 7u) / 8u) * (unsigned)nb; }
+
+// Two instantiations are launched back to back: CLD = false handles the
 // 256-column blocks of compacted positions that hold clear columns only, CLD = true the others (k_partition);
 // a block of the wrong kind exits immediately, so each kernel keeps the register budget of its own path.
 // T is passed BY VALUE: table pointers that arrive as kernel arguments are known to be global-address-space
@@ -1461,11 +1480,12 @@ __host__ __device__ constexpr int lw_band_ng(int ib)
 template <typename R, bool CLD, bool DBG>
 __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
 {
-    if (!((A.band_mask >> LW_BAND_ORDER[blockIdx.y]) & 1u)) return;      // a RATS pass re-runs the bands its gas appears in
+    int bstart, bslot;
+    if (!band_block(A.ncol, NB_LW, bstart, bslot)) return;
+    if (!((A.band_mask >> LW_BAND_ORDER[bslot]) & 1u)) return;      // a RATS pass re-runs the bands its gas appears in
     const int nclear = *A.nclear;
     // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
     // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
-    const int bstart = (int)(blockIdx.x * blockDim.x);
     const int bend = bstart + (int)blockDim.x < A.ncol ? bstart + (int)blockDim.x : A.ncol;
     if (!DBG && (CLD ? bend <= nclear : bstart >= nclear)) return;
     // fp32: the (1 - exp(-tau), tfac) table (80 KB) is copied into LDS once per block - every cell looks it up at an index that
@@ -1477,7 +1497,7 @@ __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
         R2 *const l = reinterpret_cast<R2 *>(lw_lds);
         for (int i = threadIdx.x; i <= NTBL; i += (int)blockDim.x) l[i] = ldg(T.lut, (uint32_t)i * (uint32_t)sizeof(R2));
         {   // the band's small tables, [rows][S] each, in the order selfref (10), forref (4), fracrefa, fracrefb
-            const int ib = LW_BAND_ORDER[blockIdx.y], S = pad4(lw_band_ng(ib));
+            const int ib = LW_BAND_ORDER[bslot], S = pad4(lw_band_ng(ib));
             R *const sm = reinterpret_cast<R *>(lw_lds + LW_LDS_LUT);
             const BandTab<R> &B = T.b[ib];
             const int na = lw_nfraca(ib), nb = lw_nfracb(ib);
@@ -1493,7 +1513,7 @@ __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
     const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
     if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
-    switch (LW_BAND_ORDER[blockIdx.y]) {
+    switch (LW_BAND_ORDER[bslot]) {
         case 1: band_body<R, Band1, CLD, DBG>(A, T, col, nclear, luts); break;
         case 2: band_body<R, Band2, CLD, DBG>(A, T, col, nclear, luts); break;
         case 3: band_body<R, Band3, CLD, DBG>(A, T, col, nclear, luts); break;

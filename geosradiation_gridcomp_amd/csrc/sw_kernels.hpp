@@ -896,16 +896,17 @@ __global__ void __launch_bounds__(256) k_sw_dump_cldprmc(SwArgs<R> A, R *__restr
 template <typename R, bool CLD, bool DBG>
 __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? 2 : 1)) k_sw_bands(SwArgs<R> A, SwDev<R> T, SwSolar<R> SV)
 {
+    int bstart, bslot;       // one-dimensional grid: the bands of a column block run together on one XCD (lw_kernels.hpp band_block)
+    if (!band_block(A.ncol, NB_SW, bstart, bslot)) return;
     const int nclear = *A.nclear;
     // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
     // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
-    const int bstart = (int)(blockIdx.x * blockDim.x);
     const int bend = bstart + (int)blockDim.x < A.ncol ? bstart + (int)blockDim.x : A.ncol;
     if (!DBG && (CLD ? bend <= nclear : bstart >= nclear)) return;
     const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
     if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
-    switch (SW_BAND_ORDER[blockIdx.y]) {
+    switch (SW_BAND_ORDER[bslot]) {
         case 16: sw_band_body<R, SwB16, CLD, DBG>(A, T, SV, col, nclear); break;
         case 17: sw_band_body<R, SwB17, CLD, DBG>(A, T, SV, col, nclear); break;
         case 18: sw_band_body<R, SwB18, CLD, DBG>(A, T, SV, col, nclear); break;
