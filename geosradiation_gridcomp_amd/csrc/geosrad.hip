@@ -1580,7 +1580,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(NG_SW * cl * sizeof(R)); if (w) w->ssacmc = (R *)p;
         p = take(NG_SW * cl * sizeof(R)); if (w) w->asmcmc = (R *)p;
         p = take((size_t)3 * NG_SW * nc * sizeof(R)); if (w) w->cotsum = (R *)p;
-        p = take((size_t)16 * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
+        p = take((size_t)14 * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
         p = take((size_t)4 * NB_SW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
         p = take((size_t)3 * NB_SW * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
         p = take((size_t)8 * 3 * nc * sizeof(R)); if (w) w->cot = (R *)p;

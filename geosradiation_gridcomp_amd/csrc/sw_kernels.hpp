@@ -65,7 +65,7 @@ template <typename R> struct SwArgs {
     R *taucmc, *ssacmc, *asmcmc;         // McICA cloud optics, band-major planes [band][lay][g][col]
     uint8_t *laycloudy;                  // [lay][col] some sub-column of the layer has cloud (only those layers' planes are valid)
     R *cotsum;                           // [3][NG_SW][ncol]  per-sub-column low|mid|high sums of the un-scaled cloud tau
-    R *cell;                             // [16][band-major plane]: 8 parked values per cell, clear sky then total sky
+    R *cell;                             // [15][band-major plane]: parked values per cell, see sw_band_body
     R *part;                             // [4][14][nlay+1][ncol]: cu, cd, fu, fd per band
     R *bsfc;                             // [3][14][ncol]: surface direct, total down, up (of the sky that counts as total)
     R *cot;                              // [8][14][ncol]: PAR cloud optical thickness partial sums per band
@@ -267,6 +267,24 @@ template <typename R, typename B> GR_DEV void sw_prep(const SwDev<R> &T, const S
     if constexpr (B::JB == 22) P.extra = (R)4.35e-4 * L.col[G_O2] / ((R)350.0 * (R)2.0);   // o2cont (:1228,1273)
 }
 
+// Rayleigh optical depth of W g-points starting at `go`: one value per g-point, except band 24 below the tropopause, where rayla is
+// interpolated in the binary-species parameter (js, fs) (:1467)
+template <typename R, typename B, int W>
+GR_DEV void sw_rayl(const SwDev<R> &T, bool lower, R colmol, int js, R fs, int go, R (&ray)[W])
+{
+    constexpr int S = pad4(B::NG);
+    const SwBandTab<R> &Bt = T.b[B::JB - 15];
+    R t[W];
+    if constexpr (B::JB == 24) {
+        if (lower) linw<R, W, S>(t, fs, Bt.rayl, js - 1, go);      // rayla(ig, js..js+1)
+        else ldw<R, W>(Bt.raylb, (uint32_t)go * (uint32_t)sizeof(R), t);
+    } else {
+        ldw<R, W>(Bt.rayl, (uint32_t)go * (uint32_t)sizeof(R), t);
+    }
+#pragma unroll
+    for (int j = 0; j < W; j++) ray[j] = colmol * t[j];
+}
+
 // gas optical depth tau[] and Rayleigh optical depth ray[] of W g-points starting at `go`
 template <typename R, typename B, int W>
 GR_DEV void sw_eval(const SwDev<R> &T, const SwLayer<R> &L, const SwPrep<R> &P, int go, R (&tau)[W], R (&ray)[W])
@@ -335,23 +353,7 @@ GR_DEV void sw_eval(const SwDev<R> &T, const SwLayer<R> &L, const SwPrep<R> &P, 
 #pragma unroll
         for (int j = 0; j < W; j++) tau[j] = tau[j] + c * x[j];
     }
-    // Rayleigh
-    if constexpr (B::JB == 24) {
-        if (L.lower) {
-            R t[W];
-            linw<R, W, S>(t, P.sp.fs, Bt.rayl, P.sp.js - 1, go);      // rayla(ig, js..js+1) (:1467)
-#pragma unroll
-            for (int j = 0; j < W; j++) ray[j] = L.colmol * t[j];
-        } else {
-            R t[W]; ldw<R, W>(Bt.raylb, (uint32_t)go * (uint32_t)sizeof(R), t);
-#pragma unroll
-            for (int j = 0; j < W; j++) ray[j] = L.colmol * t[j];
-        }
-    } else {
-        R t[W]; ldw<R, W>(Bt.rayl, (uint32_t)go * (uint32_t)sizeof(R), t);
-#pragma unroll
-        for (int j = 0; j < W; j++) ray[j] = L.colmol * t[j];
-    }
+    sw_rayl<R, B, W>(T, L.lower, L.colmol, P.sp.js, P.sp.fs, go, ray);
 }
 // Fast-path arithmetic of the fp32 instantiation: 1-ulp hardware reciprocal / sqrt / exp2 instead of the correctly rounded
 // (10-instruction) IEEE sequences.  The per-cell two-stream needs ~16 divisions, which made half of the instruction count;
@@ -441,10 +443,49 @@ template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R rmuz,
     }
 }
 
+// One cell's optics.  Both sweeps of the band body form them (the second from the parked gas optical depth).
+template <typename R> struct SwCell { R tau, om, g, ref, refd, tra, trad, dbt; };
+// clear sky incl. aerosol, delta-scaled with f = g^2 (SW/rrtmg_sw_spcvmc.F90:413-437); layer properties; direct-beam transmittance
+template <typename R> GR_DEV void sw_cell_clear(R tg, R tr, R ta, R om, R as, R prmu0, R rmu0, SwCell<R> &c)
+{
+    R ztauo = tr + tg + ta;
+    R zomco = tr + ta * om;
+    R zgco = f_div<R>(as * om * ta, zomco);
+    zomco = f_div<R>(zomco, ztauo);
+    const R zf = zgco * zgco, zwf = zomco * zf;
+    ztauo = ((R)1. - zwf) * ztauo;
+    zomco = f_div<R>(zomco - zwf, (R)1. - zwf);
+    zgco = f_div<R>(zgco - zf, (R)1. - zf);
+    c.tau = ztauo; c.om = zomco; c.g = zgco;
+    sw_reftra<R>(ztauo, zomco, zgco, prmu0, rmu0, c.ref, c.refd, c.tra, c.trad);
+    c.dbt = f_exp<R>(-ztauo * rmu0);
+}
+// total sky of a cloudy cell: the (already delta-scaled) cloud optics added to the clear-sky ones (:512-536, 541, 547-559)
+template <typename R> GR_DEV void sw_cell_cloud(const SwCell<R> &c, R tc, R oc, R gc, R prmu0, R rmu0, SwCell<R> &t)
+{
+    R g2 = c.tau * c.om * c.g + tc * oc * gc;
+    R o2 = c.tau * c.om + tc * oc;
+    const R t2 = c.tau + tc;
+    g2 = f_div<R>(g2, o2); o2 = f_div<R>(o2, t2);
+    t.tau = t2; t.om = o2; t.g = g2;
+    sw_reftra<R>(t2, o2, g2, prmu0, rmu0, t.ref, t.refd, t.tra, t.trad);
+    t.dbt = f_exp<R>(-t2 * rmu0);
+}
+
 // ---------------------------------------------------------------------------------------------------
-// fused band body.  Vertical index jk = 0 (TOA layer) .. nlay-1 (surface layer) of spcvmc == API layer
-// lay = nlay-1-jk.  Parked per cell (plane q): 0 ref, 1 refd, 2 tra, 3 trad, 4 dbt of the layer; 5 tdbt, 6 ztdn,
-// 7 prdnd at the layer's lower boundary.  Planes 8..15: the same for the total sky of cloudy columns.
+// fused band body.  Vertical index jk = 0 (TOA layer) .. nlay-1 (surface layer) of spcvmc == API layer lay = nlay-1-jk.
+// Two sweeps over the layers of a column, one lane per column, all g-points of the band in registers:
+//   A (surface -> TOA): k-distribution, cell optics, two-stream layer properties (reftra) and the UPWARD adding recurrences
+//     (vrtqdr's prup / prupd, :1453-1505).  Parked per cell (plane q): 0 ref, 1 refd, 2 tra, 3 trad, 4 dbt of the layer (sign bit:
+//     the cell is cloudy); 5 prup, 6 prupd at the layer's upper boundary.  Cloudy columns: 7..11 the layer properties of the total
+//     sky in cloudy cells; 12, 13 prup / prupd of the total sky from the sub-column's lowest cloudy cell upwards (below it they
+//     equal the clear sky's).
+//   B (TOA -> surface): the DOWNWARD recurrences (ptdbt / ztdn / prdnd, :1530-1572) run in registers, and the fluxes of every
+//     level come from the two sides (:1576-1586), band-integrated (:467-502).
+// The recurrences are the reference's, evaluated in the other order: vrtqdr runs down first and parks three values per level, up
+// first parks two - 28 instead of 32 bytes per clear-sky fp32 cell of a kernel that is bound by exactly this traffic
+// (profiles/r02_sw_parked_cells.md, which also has the variants that re-form the layer properties in sweep B instead of parking
+// them: 12 bytes per cell, but the second reftra per cell costs more than the HBM time it saves).
 // ---------------------------------------------------------------------------------------------------
 template <typename R, typename B, bool CLD, bool DBG>
 GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV, int col, int nclear)
@@ -533,23 +574,28 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
     // uniform bases of the parked-cell planes of this band
     const size_t bandoff = (size_t)G0 * nlay * n;
     // parked cell planes are tiled by 256-column block: [block][layer][g][256], so that a block's scratch is one contiguous
-    // 0.9 MB run per plane instead of 1 KB pieces 400 KB apart (TLB reach, DRAM page locality)
+    // run per plane instead of 1 KB pieces 400 KB apart (TLB reach, DRAM page locality)
     const uint32_t npad = ((uint32_t)n + 255u) & ~255u;
     const size_t plane = (size_t)NG_SW * nlay * npad;
     R *const cellb = A.cell + (size_t)G0 * nlay * npad;
     const uint32_t tbase = (ucol >> 8) * (uint32_t)nlay * (uint32_t)NG * 256u + (ucol & 255u);
     const R *const tcb = A.taucmc + bandoff, *const ocb = A.ssacmc + bandoff, *const gcb = A.asmcmc + bandoff;
 #define CELL(q) (cellb + (size_t)(q) * plane)
+#ifdef SW_EXP_NOPARK      // experiment: the arithmetic of both sweeps without the parked-cell traffic (results are wrong)
+#define PST(q, off, v) ((void)0)
+#define PLD(q, off) (prmu0 * (R)0.5)
+#else
+#define PST(q, off, v) stg_nt(CELL(q), off, v)
+#define PLD(q, off) ldg_nt(CELL(q), off)
+#endif
+#define CT4(lay_, g_) ((tbase + ((uint32_t)(lay_) * (uint32_t)NG + (uint32_t)(g_)) * 256u) * (uint32_t)sizeof(R))
 
-    // ---- sweep A: TOA -> surface -----------------------------------------------------------------------
-    R tdbt[NG], ztdn[NG], prdnd[NG], tdbtT[NG], ztdnT[NG], prdndT[NG];
+    // ---- sweep A: surface -> TOA -----------------------------------------------------------------------
+    R prup[NG], prupd[NG], prupT[NG], prupdT[NG];
+    int lowc[NG];            // lowest cloudy layer of sub-column g: the parked total-sky planes hold values from there upwards
 #pragma unroll
-    for (int g = 0; g < NG; g++) { tdbt[g] = 1; ztdn[g] = 1; prdnd[g] = 0; tdbtT[g] = 1; ztdnT[g] = 1; prdndT[g] = 0; }
-    uint32_t cmask = 0;      // bit g: the layer processed last (finally: the surface layer) is cloudy in sub-column g
-    uint32_t dmask = 0;      // bit g: a cloudy cell has been met in sub-column g (total sky diverged from clear sky)
-    for (int jk = 0; jk < nlay; jk++) {
-        const int lay = nlay - 1 - jk;
-        cmask = 0;
+    for (int g = 0; g < NG; g++) { prup[g] = albp; prupd[g] = albd; prupT[g] = albp; prupdT[g] = albd; lowc[g] = 0x7fffffff; }
+    for (int lay = 0; lay < nlay; lay++) {
         SwLayer<R> L;
         sw_load_layer<R>(A, lay, col, L);
         SwPrep<R> P;
@@ -594,244 +640,216 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
             for (int j = 0; j < W; j++) {
                 const int g = q * W + j;
                 if (g >= NG) continue;
-                const uint32_t cb4 = (cell0 + (uint32_t)g * (uint32_t)n) * (uint32_t)sizeof(R);
-                const uint32_t ct4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
+                const uint32_t ct4 = CT4(lay, g);
                 if (DBG) {
                     const size_t o = ((size_t)pc * NG_SW + (G0 + g)) * nlay + lay;       // Fortran (nlay,112,ncol)
                     A.dbg_taug[o] = tg[j]; A.dbg_taur[o] = tr[j];
                 }
-                // clear-sky optical properties incl. aerosol, delta-scaled with f = g^2 (:413-437)
-                R ztauo = tr[j] + tg[j] + ta;
-                R zomco = tr[j] + ta * om;
-                R zgco = f_div<R>(as * om * ta, zomco);
-                zomco = f_div<R>(zomco, ztauo);
-                const R zf = zgco * zgco, zwf = zomco * zf;
-                ztauo = ((R)1. - zwf) * ztauo;
-                zomco = f_div<R>(zomco - zwf, (R)1. - zwf);
-                zgco = f_div<R>(zgco - zf, (R)1. - zf);
-                R ref, refd, tra, trad;
-                sw_reftra<R>(ztauo, zomco, zgco, prmu0, rmu0, ref, refd, tra, trad);
-                R dbt = f_exp<R>(-ztauo * rmu0);
-                // downward adding recurrences (:1530-1572): values at the lower boundary of this layer
+                SwCell<R> c;
+                sw_cell_clear<R>(tg[j], tr[j], ta, om, as, prmu0, rmu0, c);
+                const bool cellcld = CLD && tcv[j] > 0;
+                // the sign bit of the parked direct-beam transmittance (>= 0) carries "this cell is cloudy" to sweep B
+                PST(0, ct4, c.ref); PST(1, ct4, c.refd); PST(2, ct4, c.tra); PST(3, ct4, c.trad); PST(4, ct4, cellcld && ccol ? -c.dbt : c.dbt);
+                // upward adding (:1453-1505): reflectances of everything below the cell's upper boundary
                 {
-                    R zt, pr;
-                    if (jk == 0) { zt = tra; pr = refd; }
-                    else {
-                        const R zreflect = f_rcp<R>((R)1. - refd * prdnd[g]);
-                        zt = tdbt[g] * tra + (trad * ((ztdn[g] - tdbt[g]) + tdbt[g] * ref * prdnd[g])) * zreflect;
-                        pr = refd + trad * trad * prdnd[g] * zreflect;
-                    }
-                    tdbt[g] = dbt * tdbt[g]; ztdn[g] = zt; prdnd[g] = pr;
+                    const R zrj = f_rcp<R>((R)1. - prupd[g] * c.refd);
+                    const R pu = c.ref + (c.trad * ((c.tra - c.dbt) * prupd[g] + c.dbt * prup[g])) * zrj;
+                    const R pd = c.refd + c.trad * c.trad * prupd[g] * zrj;
+                    prup[g] = pu; prupd[g] = pd;
                 }
-                stg_nt(CELL(0), ct4, ref); stg_nt(CELL(1), ct4, refd); stg_nt(CELL(2), ct4, tra); stg_nt(CELL(3), ct4, trad);
-                stg_nt(CELL(4), ct4, dbt); stg_nt(CELL(6), ct4, ztdn[g]); stg_nt(CELL(7), ct4, prdnd[g]);
-                const R tdbt_clear = tdbt[g];
-                bool cellcld = false;
-                R tc = 0;
-                if (CLD) { tc = tcv[j]; cellcld = tc > 0; }
-                // Above the highest cloudy cell of a sub-column the total-sky downward state IS the clear-sky one (same recurrences,
-                // same inputs): nothing is computed or parked for it there; the sign bit of the parked clear-sky T_dir^cum tells
-                // sweep B from which level on the total sky has values of its own.
-                const bool divg = CLD && ccol && (((dmask >> g) & 1u) || cellcld);
-                stg_nt(CELL(5), ct4, divg ? -tdbt_clear : tdbt_clear);
-                if (CLD && ccol && !divg) { tdbtT[g] = tdbt[g]; ztdnT[g] = ztdn[g]; prdndT[g] = prdnd[g]; }
-                if (divg) {
-                    dmask |= 1u << g;
-                    // total sky: cloudy cells get the (already delta-scaled) cloud optics added (:512-536, 541, 547-559)
-                    if (cellcld) {
-                        const R oc = ocv[j], gc = gcv[j];
-                        R g2 = ztauo * zomco * zgco + tc * oc * gc;
-                        R o2 = ztauo * zomco + tc * oc;
-                        const R t2 = ztauo + tc;
-                        g2 = f_div<R>(g2, o2); o2 = f_div<R>(o2, t2);
-                        sw_reftra<R>(t2, o2, g2, prmu0, rmu0, ref, refd, tra, trad);
-                        dbt = f_exp<R>(-t2 * rmu0);
-                        cmask |= 1u << g;
-                        // total-sky layer properties are parked for cloudy cells only (elsewhere they equal the clear-sky ones)
-                        stg_nt(CELL(8), ct4, ref); stg_nt(CELL(9), ct4, refd); stg_nt(CELL(10), ct4, tra); stg_nt(CELL(11), ct4, trad);
-                        stg_nt(CELL(12), ct4, dbt);
+                PST(5, ct4, prup[g]); PST(6, ct4, prupd[g]);
+                if constexpr (CLD) {
+                    const R tc = tcv[j];
+                    // Below the lowest cloudy cell of a sub-column the total-sky upward state IS the clear-sky one (same
+                    // recurrences, same inputs): nothing is computed or parked for it there
+                    if (cellcld && lowc[g] > lay) lowc[g] = lay;
+                    const bool divg = ccol && lowc[g] <= lay;
+                    if (ccol && !divg) { prupT[g] = prup[g]; prupdT[g] = prupd[g]; }
+                    if (divg) {
+                        SwCell<R> t = c;
+                        if (cellcld) {
+                            sw_cell_cloud<R>(c, tc, ocv[j], gcv[j], prmu0, rmu0, t);
+                            PST(7, ct4, t.ref); PST(8, ct4, t.refd); PST(9, ct4, t.tra); PST(10, ct4, t.trad); PST(11, ct4, t.dbt);
+                        }
+                        const R zrj = f_rcp<R>((R)1. - prupdT[g] * t.refd);
+                        const R pu = t.ref + (t.trad * ((t.tra - t.dbt) * prupdT[g] + t.dbt * prupT[g])) * zrj;
+                        const R pd = t.refd + t.trad * t.trad * prupdT[g] * zrj;
+                        prupT[g] = pu; prupdT[g] = pd;
+                        PST(12, ct4, pu); PST(13, ct4, pd);
                     }
-                    R zt, pr;
-                    if (jk == 0) { zt = tra; pr = refd; }
-                    else {
-                        const R zreflect = f_rcp<R>((R)1. - refd * prdndT[g]);
-                        zt = tdbtT[g] * tra + (trad * ((ztdnT[g] - tdbtT[g]) + tdbtT[g] * ref * prdndT[g])) * zreflect;
-                        pr = refd + trad * trad * prdndT[g] * zreflect;
-                    }
-                    tdbtT[g] = dbt * tdbtT[g]; ztdnT[g] = zt; prdndT[g] = pr;
-                    // the sign bit of the parked T_dir^cum (>= 0) carries "this layer is cloudy" to sweep B
-                    stg_nt(CELL(13), ct4, cellcld ? -tdbtT[g] : tdbtT[g]); stg_nt(CELL(14), ct4, ztdnT[g]); stg_nt(CELL(15), ct4, prdndT[g]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // ---- sweep B: surface -> TOA (:1453-1505 upward recurrences, :1576-1586 fluxes, band integration :467-502) ----
+    // ---- sweep B: TOA -> surface (:1530-1572 downward recurrences, :1576-1586 fluxes, band integration :467-502) ----
     const size_t qs = (size_t)NB_SW * (nlay + 1) * n;
     R *const part = A.part + (size_t)(IBM - 1) * (nlay + 1) * n;
 #define PART(kind, lev, val) stg(part + (size_t)(kind) * qs + (size_t)(lev) * n, cb, (R)(val))
-    R prup[NG], prupd[NG], prupT[NG], prupdT[NG];
-    R sdir = 0, sfd = 0, sfu = 0;
-    // level nlay+1 of spcvmc = surface = API level 0
+    R tdbt[NG], ztdn[NG], prdnd[NG], tdbtT[NG], ztdnT[NG], prdndT[NG];
+    uint32_t dmask = 0;      // bit g: a cloudy cell has been met in sub-column g (total-sky downward state diverged from clear sky)
+    // level nlay+1 of the API = TOA (spcvmc level 1): ptdbt = ztdn = 1, prdnd = 0
     {
         R cu = 0, cd = 0, fu = 0, fd = 0;
+        R pu0[NG], pd0[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) { pu0[g] = PLD(5, CT4(nlay - 1, g)); pd0[g] = PLD(6, CT4(nlay - 1, g)); }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            prup[g] = albp; prupd[g] = albd; prupT[g] = albp; prupdT[g] = albd;
+            tdbt[g] = 1; ztdn[g] = 1; prdnd[g] = 0; tdbtT[g] = 1; ztdnT[g] = 1; prdndT[g] = 0;
+            const uint32_t u4 = CT4(nlay - 1, g);
             const R zi = zinc[g] * prmu0;
+            const R pu = pu0[g], pd = pd0[g];
             {
-                const R zr = f_rcp<R>((R)1. - prdnd[g] * prupd[g]);
-                const R u = (tdbt[g] * prup[g] + (ztdn[g] - tdbt[g]) * prupd[g]) * zr;
-                const R d = tdbt[g] + (ztdn[g] - tdbt[g] + tdbt[g] * prup[g] * prdnd[g]) * zr;
-                cu = cu + zi * u; cd = cd + zi * d;
-                if (!(CLD && ccol)) { sdir = sdir + zi * tdbt[g]; sfd = sfd + zi * d; sfu = sfu + zi * u; }
+                const R zr = f_rcp<R>((R)1. - prdnd[g] * pd);
+                cu = cu + zi * ((tdbt[g] * pu + (ztdn[g] - tdbt[g]) * pd) * zr);
+                cd = cd + zi * (tdbt[g] + (ztdn[g] - tdbt[g] + tdbt[g] * pu * prdnd[g]) * zr);
             }
             if (CLD && ccol) {
-                const R zr = f_rcp<R>((R)1. - prdndT[g] * prupdT[g]);
-                const R u = (tdbtT[g] * prupT[g] + (ztdnT[g] - tdbtT[g]) * prupdT[g]) * zr;
-                const R d = tdbtT[g] + (ztdnT[g] - tdbtT[g] + tdbtT[g] * prupT[g] * prdndT[g]) * zr;
-                fu = fu + zi * u; fd = fd + zi * d;
-                sdir = sdir + zi * tdbtT[g]; sfd = sfd + zi * d; sfu = sfu + zi * u;
+                R puT = pu, pdT = pd;
+                if (lowc[g] <= nlay - 1) { puT = PLD(12, u4); pdT = PLD(13, u4); }
+                const R zr = f_rcp<R>((R)1. - prdndT[g] * pdT);
+                fu = fu + zi * ((tdbtT[g] * puT + (ztdnT[g] - tdbtT[g]) * pdT) * zr);
+                fd = fd + zi * (tdbtT[g] + (ztdnT[g] - tdbtT[g] + tdbtT[g] * puT * prdndT[g]) * zr);
             }
         }
-        PART(0, 0, cu); PART(1, 0, cd);
-        if (CLD && ccol) { PART(2, 0, fu); PART(3, 0, fd); }
+        PART(0, nlay, cu); PART(1, nlay, cd);
+        if (CLD && ccol) { PART(2, nlay, fu); PART(3, nlay, fd); }
+    }
+    // The clear-sky values of a group of W cells (five layer properties, the two upward reflectances at the lower boundary) are
+    // requested one group AHEAD of their use, so that a wave always has a group's loads in flight while it does another's arithmetic
+    struct Park { R ref[W], refd[W], tra[W], trad[W], dbt[W], pu[W], pd[W]; };
+    // (straight-line code: at the surface layer the reflectances of the layer below are requested from the layer itself and
+    // replaced by the albedo on use; a branch around the loads made the compiler wait for all outstanding loads at the join)
+    auto request = [&](int lay, int q, Park &b) {
+        const int lu = lay > 0 ? lay - 1 : 0;
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const int g = q * W + j;
+            b.ref[j] = 0; b.refd[j] = 0; b.tra[j] = 0; b.trad[j] = 0; b.dbt[j] = 0; b.pu[j] = 0; b.pd[j] = 0;
+            if (g >= NG) continue;
+            const uint32_t c4 = CT4(lay, g), u4 = CT4(lu, g);
+            b.ref[j] = PLD(0, c4); b.refd[j] = PLD(1, c4); b.tra[j] = PLD(2, c4); b.trad[j] = PLD(3, c4); b.dbt[j] = PLD(4, c4);
+            b.pu[j] = PLD(5, u4); b.pd[j] = PLD(6, u4);
+        }
+    };
+    Park nx;
+    request(nlay - 1, 0, nx);
+    R sdir = 0, sfd = 0, sfu = 0;
+    for (int lay = nlay - 1; lay >= 0; lay--) {      // cross layer `lay`; its lower boundary is API level `lay`
+        const int jk = nlay - 1 - lay;
+        R cu = 0, cd = 0, fu = 0, fd = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            Park cur = nx;
+            if (q + 1 < NQ) request(lay, q + 1, nx);
+            else request(lay > 0 ? lay - 1 : 0, 0, nx);      // (after the surface layer: a harmless repeat)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < W; j++) { cur.pu[j] = lay > 0 ? cur.pu[j] : albp; cur.pd[j] = lay > 0 ? cur.pd[j] : albd; }
+            // total sky: two wave-uniform tests (ballots) decide whether the group's cloudy-cell properties / diverged upward
+            // reflectances are requested at all; lanes a test does not concern load along and select the clear-sky value afterwards
+            R refT[W], refdT[W], traT[W], tradT[W], dbtT[W], puT[W], pdT[W], dbt[W];
+            bool cm[W], dv[W];
+            bool anycm = false, anydv = false;
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                cm[j] = false; dv[j] = false;
+                dbt[j] = cur.dbt[j];
+                if constexpr (CLD) {
+                    if (g < NG) {
+                        // the sign bit of the parked direct-beam transmittance (>= 0) carries "this cell is cloudy" from sweep A
+                        cm[j] = ccol && __builtin_signbit(cur.dbt[j]);
+                        dbt[j] = __builtin_signbit(cur.dbt[j]) ? -cur.dbt[j] : cur.dbt[j];
+                        dv[j] = ccol && lay > 0 && lowc[g] <= lay - 1;
+                        anycm = anycm || cm[j]; anydv = anydv || dv[j];
+                    }
+                }
+                refT[j] = cur.ref[j]; refdT[j] = cur.refd[j]; traT[j] = cur.tra[j]; tradT[j] = cur.trad[j]; dbtT[j] = dbt[j];
+                puT[j] = cur.pu[j]; pdT[j] = cur.pd[j];
+            }
+            if constexpr (CLD) {
+                const bool wcm = __ballot(anycm) != 0, wdv = __ballot(anydv) != 0;
+                if (wcm || wdv) {
+#pragma unroll
+                    for (int j = 0; j < W; j++) {
+                        const int g = q * W + j;
+                        if (g >= NG) continue;
+                        const uint32_t c4 = CT4(lay, g);
+                        if (wcm) {
+                            const R a0 = PLD(7, c4), a1 = PLD(8, c4), a2 = PLD(9, c4), a3 = PLD(10, c4), a4 = PLD(11, c4);
+                            if (cm[j]) { refT[j] = a0; refdT[j] = a1; traT[j] = a2; tradT[j] = a3; dbtT[j] = a4; }
+                        }
+                        if (wdv) {
+                            const uint32_t u4 = CT4(lay > 0 ? lay - 1 : 0, g);
+                            const R b0 = PLD(12, u4), b1 = PLD(13, u4);
+                            if (dv[j]) { puT[j] = b0; pdT[j] = b1; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const int g = q * W + j;
+                if (g >= NG) continue;
+                const R zi = zinc[g] * prmu0;
+                // downward adding recurrences (:1530-1572): values at the lower boundary of this layer
+                {
+                    R zt, pr;
+                    if (jk == 0) { zt = cur.tra[j]; pr = cur.refd[j]; }
+                    else {
+                        const R zreflect = f_rcp<R>((R)1. - cur.refd[j] * prdnd[g]);
+                        zt = tdbt[g] * cur.tra[j] + (cur.trad[j] * ((ztdn[g] - tdbt[g]) + tdbt[g] * cur.ref[j] * prdnd[g])) * zreflect;
+                        pr = cur.refd[j] + cur.trad[j] * cur.trad[j] * prdnd[g] * zreflect;
+                    }
+                    tdbt[g] = dbt[j] * tdbt[g]; ztdn[g] = zt; prdnd[g] = pr;
+                }
+                R u, d;
+                {
+                    const R zr = f_rcp<R>((R)1. - prdnd[g] * cur.pd[j]);
+                    u = (tdbt[g] * cur.pu[j] + (ztdn[g] - tdbt[g]) * cur.pd[j]) * zr;
+                    d = tdbt[g] + (ztdn[g] - tdbt[g] + tdbt[g] * cur.pu[j] * prdnd[g]) * zr;
+                    cu = cu + zi * u; cd = cd + zi * d;
+                }
+                if constexpr (CLD) {
+                    // Above the highest cloudy cell of a sub-column the total-sky downward state IS the clear-sky one
+                    const bool divg = ccol && (((dmask >> g) & 1u) || cm[j]);
+                    if (ccol && !divg) { tdbtT[g] = tdbt[g]; ztdnT[g] = ztdn[g]; prdndT[g] = prdnd[g]; }
+                    if (divg) {
+                        dmask |= 1u << g;
+                        R zt, pr;
+                        if (jk == 0) { zt = traT[j]; pr = refdT[j]; }
+                        else {
+                            const R zreflect = f_rcp<R>((R)1. - refdT[j] * prdndT[g]);
+                            zt = tdbtT[g] * traT[j] + (tradT[j] * ((ztdnT[g] - tdbtT[g]) + tdbtT[g] * refT[j] * prdndT[g])) * zreflect;
+                            pr = refdT[j] + tradT[j] * tradT[j] * prdndT[g] * zreflect;
+                        }
+                        tdbtT[g] = dbtT[j] * tdbtT[g]; ztdnT[g] = zt; prdndT[g] = pr;
+                    }
+                    if (ccol) {
+                        const R zr = f_rcp<R>((R)1. - prdndT[g] * pdT[j]);
+                        u = (tdbtT[g] * puT[j] + (ztdnT[g] - tdbtT[g]) * pdT[j]) * zr;
+                        d = tdbtT[g] + (ztdnT[g] - tdbtT[g] + tdbtT[g] * puT[j] * prdndT[g]) * zr;
+                        fu = fu + zi * u; fd = fd + zi * d;
+                    }
+                }
+                // surface: direct, total downward and upward flux of the sky that counts as total (:624-671)
+                if (lay == 0) { sdir = sdir + zi * ((CLD && ccol) ? tdbtT[g] : tdbt[g]); sfd = sfd + zi * d; sfu = sfu + zi * u; }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one group's arithmetic at a time
+        }
+        PART(0, lay, cu); PART(1, lay, cd);
+        if (CLD && ccol) { PART(2, lay, fu); PART(3, lay, fd); }
     }
     stg(A.bsfc + (size_t)(0 * NB_SW + IBM - 1) * n, cb, sdir);
     stg(A.bsfc + (size_t)(1 * NB_SW + IBM - 1) * n, cb, sfd);
     stg(A.bsfc + (size_t)(2 * NB_SW + IBM - 1) * n, cb, sfu);
-    for (int jk = nlay - 1; jk >= 0; jk--) {       // add layer jk on top; its upper boundary is spcvmc level jk (0-based)
-        const int lay = nlay - 1 - jk;
-        const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;
-        const uint32_t cellu = ((uint32_t)(lay + 1) * (uint32_t)NG) * (uint32_t)n + ucol;    // layer above: holds this level's tdbt/ztdn/prdnd
-        R cu = 0, cd = 0, fu = 0, fd = 0;
-        uint32_t cnext = 0;
-        if constexpr (CLD) {
-        // cloudy columns: four g-points at a time - all clear-sky values of the chunk are requested together, two wave-uniform tests
-        // (ballots) decide whether the chunk's total-sky values are requested at all, and only then does the arithmetic start.
-        // A per-lane branch around each conditional load made every load of a layer wait for the one before it.  Lanes a test
-        // does not concern load along and select the clear-sky value afterwards.
-        constexpr int GC = 4;
-#pragma unroll
-        for (int g0 = 0; g0 < NG; g0 += GC) {
-            R ref[GC], refd[GC], tra[GC], trad[GC], dbt[GC], tbc[GC], ztc[GC], prc[GC];
-            R refT[GC], refdT[GC], traT[GC], tradT[GC], dbtT[GC], tbT[GC], ztT[GC], prT[GC];
-            bool ldv[GC];
-            bool anycm = false, anydv = false;
-#pragma unroll
-            for (int j = 0; j < GC; j++) {
-                const int g = g0 + j;
-                if (g >= NG) continue;
-                const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-                const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-                ref[j] = ldg_nt(CELL(0), c4); refd[j] = ldg_nt(CELL(1), c4); tra[j] = ldg_nt(CELL(2), c4); trad[j] = ldg_nt(CELL(3), c4); dbt[j] = ldg_nt(CELL(4), c4);
-                if (jk > 0) { tbc[j] = ldg_nt(CELL(5), u4); ztc[j] = ldg_nt(CELL(6), u4); prc[j] = ldg_nt(CELL(7), u4); }
-                else { tbc[j] = 1; ztc[j] = 1; prc[j] = 0; }
-            }
-#pragma unroll
-            for (int j = 0; j < GC; j++) {
-                const int g = g0 + j;
-                ldv[j] = false;
-                if (g >= NG) continue;
-                ldv[j] = ccol && jk > 0 && __builtin_signbit(tbc[j]);
-                tbc[j] = __builtin_signbit(tbc[j]) ? -tbc[j] : tbc[j];
-                anydv = anydv || ldv[j];
-                anycm = anycm || (ccol && ((cmask >> g) & 1u));
-            }
-            const bool wcm = __ballot(anycm) != 0, wdv = __ballot(anydv) != 0;
-#pragma unroll
-            for (int j = 0; j < GC; j++) {
-                const int g = g0 + j;
-                refT[j] = ref[j]; refdT[j] = refd[j]; traT[j] = tra[j]; tradT[j] = trad[j]; dbtT[j] = dbt[j];
-                tbT[j] = tbc[j]; ztT[j] = ztc[j]; prT[j] = prc[j];
-                if (g >= NG) continue;
-                const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-                const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-                if (wcm) { refT[j] = ldg_nt(CELL(8), c4); refdT[j] = ldg_nt(CELL(9), c4); traT[j] = ldg_nt(CELL(10), c4); tradT[j] = ldg_nt(CELL(11), c4); dbtT[j] = ldg_nt(CELL(12), c4); }
-                if (wdv) { tbT[j] = ldg_nt(CELL(13), u4); ztT[j] = ldg_nt(CELL(14), u4); prT[j] = ldg_nt(CELL(15), u4); }
-            }
-#pragma unroll
-            for (int j = 0; j < GC; j++) {
-                const int g = g0 + j;
-                if (g >= NG) continue;
-                const R zi = zinc[g] * prmu0;
-                {
-                    const R zrj = f_rcp<R>((R)1. - prupd[g] * refd[j]);
-                    const R pu = ref[j] + (trad[j] * ((tra[j] - dbt[j]) * prupd[g] + dbt[j] * prup[g])) * zrj;
-                    const R pd = refd[j] + trad[j] * trad[j] * prupd[g] * zrj;
-                    prup[g] = pu; prupd[g] = pd;
-                    const R zr = f_rcp<R>((R)1. - prc[j] * pd);
-                    cu = cu + zi * ((tbc[j] * pu + (ztc[j] - tbc[j]) * pd) * zr);
-                    cd = cd + zi * (tbc[j] + (ztc[j] - tbc[j] + tbc[j] * pu * prc[j]) * zr);
-                }
-                {
-                    const bool cm = ccol && ((cmask >> g) & 1u);
-                    const R r0 = cm ? refT[j] : ref[j], r1 = cm ? refdT[j] : refd[j], r2 = cm ? traT[j] : tra[j], r3 = cm ? tradT[j] : trad[j],
-                            r4 = cm ? dbtT[j] : dbt[j];
-                    const R zrj = f_rcp<R>((R)1. - prupdT[g] * r1);
-                    const R pu = r0 + (r3 * ((r2 - r4) * prupdT[g] + r4 * prupT[g])) * zrj;
-                    const R pd = r1 + r3 * r3 * prupdT[g] * zrj;
-                    prupT[g] = pu; prupdT[g] = pd;
-                    // above the sub-column's highest cloud: the clear-sky values
-                    const bool dv = ldv[j];
-                    const bool cl = dv && __builtin_signbit(tbT[j]);          // the layer above is cloudy in this sub-column
-                    if (cl) cnext |= 1u << g;
-                    const R tbr = dv ? tbT[j] : tbc[j];
-                    const R tb = cl ? -tbr : tbr, zt = dv ? ztT[j] : ztc[j], pr = dv ? prT[j] : prc[j];
-                    const R zr = f_rcp<R>((R)1. - pr * pd);
-                    fu = fu + zi * ((tb * pu + (zt - tb) * pd) * zr);
-                    fd = fd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);      // one chunk's values in flight at a time
-        }
-        } else {
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            const uint32_t c4 = (tbase + ((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-            const uint32_t u4 = (tbase + ((uint32_t)(lay + 1) * (uint32_t)NG + (uint32_t)g) * 256u) * (uint32_t)sizeof(R);
-            const R zi = zinc[g] * prmu0;
-            R ref = ldg_nt(CELL(0), c4), refd = ldg_nt(CELL(1), c4), tra = ldg_nt(CELL(2), c4), trad = ldg_nt(CELL(3), c4), dbt = ldg_nt(CELL(4), c4);
-            R tbc, ztc, prc;
-            bool ldiv = false;
-            {
-                const R zrj = f_rcp<R>((R)1. - prupd[g] * refd);
-                const R pu = ref + (trad * ((tra - dbt) * prupd[g] + dbt * prup[g])) * zrj;
-                const R pd = refd + trad * trad * prupd[g] * zrj;
-                prup[g] = pu; prupd[g] = pd;
-                if (jk > 0) {
-                    tbc = ldg_nt(CELL(5), u4); ztc = ldg_nt(CELL(6), u4); prc = ldg_nt(CELL(7), u4);
-                    if (CLD) { ldiv = __builtin_signbit(tbc); tbc = ldiv ? -tbc : tbc; }
-                } else { tbc = 1; ztc = 1; prc = 0; ldiv = false; }
-                const R zr = f_rcp<R>((R)1. - prc * pd);
-                cu = cu + zi * ((tbc * pu + (ztc - tbc) * pd) * zr);
-                cd = cd + zi * (tbc + (ztc - tbc + tbc * pu * prc) * zr);
-            }
-            if (CLD && ccol) {
-                if (cmask & (1u << g)) {
-                    ref = ldg_nt(CELL(8), c4); refd = ldg_nt(CELL(9), c4); tra = ldg_nt(CELL(10), c4); trad = ldg_nt(CELL(11), c4); dbt = ldg_nt(CELL(12), c4);
-                }
-                const R zrj = f_rcp<R>((R)1. - prupdT[g] * refd);
-                const R pu = ref + (trad * ((tra - dbt) * prupdT[g] + dbt * prupT[g])) * zrj;
-                const R pd = refd + trad * trad * prupdT[g] * zrj;
-                prupT[g] = pu; prupdT[g] = pd;
-                R tb = tbc, zt = ztc, pr = prc;              // above the sub-column's highest cloud: the clear-sky values
-                if (ldiv) {
-                    tb = ldg_nt(CELL(13), u4); zt = ldg_nt(CELL(14), u4); pr = ldg_nt(CELL(15), u4);
-                    if (__builtin_signbit(tb)) { cnext |= 1u << g; tb = -tb; }
-                }
-                const R zr = f_rcp<R>((R)1. - pr * pd);
-                fu = fu + zi * ((tb * pu + (zt - tb) * pd) * zr);
-                fd = fd + zi * (tb + (zt - tb + tb * pu * pr) * zr);
-            }
-        }
-        }
-        PART(0, lay + 1, cu); PART(1, lay + 1, cd);
-        if (CLD && ccol) { PART(2, lay + 1, fu); PART(3, lay + 1, fd); }
-        cmask = cnext;
-    }
 #undef PART
+#undef PST
+#undef PLD
+#undef CT4
 #undef CELL
 
     // ---- PAR in-cloud optical thickness diagnostics (SW/rrtmg_sw_spcvmc.F90:749-1109), bands 24-26 ---------------
