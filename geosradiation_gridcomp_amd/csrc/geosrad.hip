@@ -768,7 +768,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             HIPCHK(hipMemcpy(pe.d_seg, segs.data(), segs.size() * sizeof(McSegDev), hipMemcpyHostToDevice));
             it = plans.emplace(key, pe).first;
         }
-        out.seg = it->second.d_seg; out.jsub = it->second.jsub; out.jhalf = it->second.jhalf;
+        out.seg = it->second.d_seg; out.nseg = it->second.nseg; out.jsub = it->second.jsub; out.jhalf = it->second.jhalf;
         nseg_out = it->second.nseg;
         return GEOSRAD_OK;
     }
@@ -861,7 +861,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 rc = mc_plan(0, NG_LW, nlay, MP, nseg);
                 if (rc) return rc;
                 span_begin(3, st);
-                hipLaunchKernelGGL((k_mcica<R, 0>), dim3((unsigned)((nc + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+                hipLaunchKernelGGL((k_mcica<R, 0>), dim3(xcd_grid(nc, 64, nseg)), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
                 span_end(st);
             }
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
@@ -1713,7 +1713,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 rc = mc_plan(2, NG_SW, nlay, MP, nseg);
                 if (rc) return rc;
                 span_begin(3, st);
-                hipLaunchKernelGGL((k_mcica<R, 2>), dim3((unsigned)((nc + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T,
+                hipLaunchKernelGGL((k_mcica<R, 2>), dim3(xcd_grid(nc, 64, nseg)), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T,
                                    (const SwDev<R> *)d_S);
                 span_end(st);
             }
@@ -2201,7 +2201,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                                (const LwDev<R> *)d_T);
         } else {
             // lane = column (tiles beyond 64 KB of LDS: fp64 with more than 127 layers)
-            hipLaunchKernelGGL((k_mcica<R, 1>), dim3((unsigned)((ncol + 63) / 64), nseg), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
+            hipLaunchKernelGGL((k_mcica<R, 1>), dim3(xcd_grid(ncol, 64, nseg)), dim3(64), 0, st, M, MP, (const LwDev<R> *)d_T, (const SwDev<R> *)nullptr);
         }
         span_end(st);
         HIPCHK(hipGetLastError());

@@ -1470,6 +1470,8 @@ GR_DEV bool band_block(int ncol, int nb, int &bstart, int &bslot)
     return bstart < ncol;
 }
 __host__ inline unsigned band_grid(int ncol, int nb) { const unsigned gx = (unsigned)((ncol + 255) / 256); return 8u * ((gx + 7u) / 8u) * (unsigned)nb; }
+// the same grid for blocks of `bsz` columns and `ny` slots per column block (k_mcica: 64 columns, ny = segments of sub-columns)
+__host__ inline unsigned xcd_grid(int ncol, int bsz, int ny) { const unsigned gx = (unsigned)((ncol + bsz - 1) / bsz); return 8u * ((gx + 7u) / 8u) * (unsigned)ny; }
 
 // Two instantiations are launched back to back: CLD = false handles the
 // 256-column blocks of compacted positions that hold clear columns only, CLD = true the others (k_partition);

@@ -313,7 +313,7 @@ GR_DEV void sw_cloud_optics(const SwCldCoef<R> &c, int iceflag, R ciwp, R clwp, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_mcica: one thread per (column, segment of <= 4 consecutive sub-columns of one band); blockIdx.y = segment.
+// k_mcica: one thread per (column, segment of <= 4 consecutive sub-columns of one band).
 // The reference draws one KISS stream per column, sequentially over (sub-column, layer): per sub-column 2*nlay numbers
 // for the cloud-presence pass and, with inhomogeneous condensate, 2*nlay more for the condensate pass
 // (cloud_subcol_gen.F90:402-466).  Here every sub-column of the segment gets its own two stream positions by
@@ -330,7 +330,7 @@ GR_DEV void sw_cloud_optics(const SwCldCoef<R> &c, int iceflag, R ciwp, R clwp, 
 // ---------------------------------------------------------------------------------------------------
 constexpr int MC_S = 4;      // sub-columns per thread
 struct McSegDev { int start, count, band, pad; KissJump j; };      // j: jump to sub-column `start` (unused when start == 0)
-struct McPlan { const McSegDev *seg; KissJump jsub, jhalf; };      // jsub: one sub-column ahead; jhalf: 2*nlay ahead
+struct McPlan { const McSegDev *seg; int nseg; KissJump jsub, jhalf; };      // jsub: one sub-column ahead; jhalf: 2*nlay ahead
 
 template <typename R> struct McArgs {
     int ncol, ld, nlay, nsubcol, doy, cloudLM, cloudMH, iceflg, liqflg;
@@ -350,12 +350,18 @@ template <typename R> struct McArgs {
 template <typename R, int MODE>
 __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev<R> *__restrict__ Tp, const SwDev<R> *__restrict__ Sp)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    // one-dimensional grid (lw_kernels.hpp band_block): the segments of a 64-column block are consecutive blocks of one XCD, so the
+    // layer fields every segment walks (overlap correlations, cloud fraction, water paths, radii: ~2 KB per column) come from HBM
+    // once and from that XCD's L2 for the other segments; with (column block, segment) = (blockIdx.x, blockIdx.y) every segment
+    // fetched them again (PMC: 158 KB per column read for 3 KB of inputs)
+    int bstart, bseg;
+    if (!band_block(M.ncol, P.nseg, bstart, bseg)) return;
+    const int col = bstart + threadIdx.x;
     if (col >= M.ncol) return;
     if (M.nclear && col < *M.nclear) return;      // clear columns: nothing to generate
     const int pc = M.perm ? M.perm[col] : col;    // API arrays are indexed by the original column
     const LwDev<R> &T = *Tp;
-    const McSegDev &SG = P.seg[blockIdx.y];
+    const McSegDev &SG = P.seg[bseg];
     const int s0 = SG.start, ns = SG.count, ib = SG.band;     // uniform over the block
     const int n = M.ncol, ld = M.ld, nlay = M.nlay;
     const bool inhomo = T.xcw != nullptr;
