@@ -437,3 +437,44 @@ def test_fp32_discrete_flip_rate(gpu_ctx):
             assert mask_flips <= 2e-5 * cells and wp_flips <= 2e-4 * cells and cols <= 0.01 * n
     finally:
         ctx.set_inhomogeneity(0); clib.set_inhomogeneity(0, "r4")
+
+
+def test_lw_fp32_is_as_accurate_as_the_reference_precision(gpu_ctx):
+    """The fp32 instantiation against the r8 oracle (pinned bit for bit to the reference's -fdefault-real-8 build) as the truth, next to
+    the r4 oracle (pinned to the reference's default-real build, GEOS's production precision) on the same columns.  r4 and r8 builds
+    seed McICA from different pressure bits, so the comparison uses the clear-sky fluxes of every column and the total-sky fluxes of
+    the cloud-free ones."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    n, nlay = 1024, 72
+    inp = synth.make_columns(n, nlay, start=710_000, aerosol=True, cloudy_frac=0.6)
+    ctx = gpu_ctx[4]
+    ctx.set_inhomogeneity(1)
+    try:
+        g4 = ctx.rrtmg_lw_columns(inp)
+    finally:
+        ctx.set_inhomogeneity(0)
+    o = {}
+    for kind in ("r4", "r8"):
+        clib.set_inhomogeneity(1, kind)
+        try:
+            o[kind] = clib.rrtmg_lw(inp, prec=kind)
+        finally:
+            clib.set_inhomogeneity(0, kind)
+    free = ~(inp["cldf"] > 0).any(axis=0)
+    assert free.sum() >= 300
+
+    def err(x):
+        e = np.zeros(n)
+        for k in ("uflxc", "dflxc"):
+            e = np.maximum(e, np.abs(x[k].astype(np.float64) - o["r8"][k].astype(np.float64)).max(axis=0))
+        for k in ("uflx", "dflx"):
+            e = np.maximum(e, np.where(free, np.abs(x[k].astype(np.float64) - o["r8"][k].astype(np.float64)).max(axis=0), 0.0))
+        return e
+
+    eg, eo = err(g4), err(o["r4"])
+    q = lambda e: (np.median(e), np.percentile(e, 99), e.max())
+    print("fp32 error vs r8 oracle, W m-2 (median, 99 %%, max): GPU %.2e %.2e %.2e | r4 oracle %.2e %.2e %.2e" % (q(eg) + q(eo)))
+    assert np.median(eg) <= 1.25 * np.median(eo) + 1e-6
+    assert np.percentile(eg, 99) <= 1.25 * np.percentile(eo, 99) + 1e-5
+    assert eg.max() <= max(1.5 * eo.max(), 2e-3)      # measured: GPU 7.7e-5 / 1.1e-3 / 2.2e-3 W m-2, r4 oracle 1.7e-4 / 1.1e-3 / 2.2e-3

@@ -260,3 +260,46 @@ def test_sw_cldprmc_stage_matches_reference_golden(gpu_ctx, name, rk):
                     assert (rel > 2e-5).mean() <= 1e-3, (ice, nm, rel.max())     # condensate-overlap flips change a few values
     finally:
         ctx.set_inhomogeneity(0)
+
+
+def test_sw_fp32_is_as_accurate_as_the_reference_precision(gpu_ctx):
+    """What the fp32 instantiation (hardware 1-ulp rcp / sqrt / exp in the two-stream) costs in accuracy, measured against the r8
+    oracle as the truth and set next to the error of the r4 oracle (= the reference's arithmetic in the reference's production
+    precision) on the same columns: the GPU's fp32 fluxes are as close to the truth as default-real CPU fluxes are."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    n, nlay = 1024, 72
+    inp = synth.make_columns(n, nlay, start=700_000, aerosol=True, cloudy_frac=0.6)
+    ctx = gpu_ctx[4]
+    ctx.set_inhomogeneity(1)
+    try:
+        g4 = ctx.rrtmg_sw_columns(inp, iaer=10)
+    finally:
+        ctx.set_inhomogeneity(0)
+    o = {}
+    for kind in ("r4", "r8"):
+        clib.set_inhomogeneity(1, kind)
+        try:
+            o[kind] = clib.rrtmg_sw(inp, prec=kind, iaer=10)
+        finally:
+            clib.set_inhomogeneity(0, kind)
+    # the r4 and r8 builds seed McICA from different pressure bits, so their sub-columns differ by construction: the comparison is made on
+    # the clear-sky fluxes of every column and on the total-sky fluxes of the cloud-free columns
+    free = ~(inp["cldf"] > 0).any(axis=0)
+    assert free.sum() >= 300
+    toa = o["r8"]["swdflx"][nlay].astype(np.float64)
+
+    def err(x):
+        e = np.zeros(n)
+        for k in ("swuflxc", "swdflxc"):
+            e = np.maximum(e, np.abs(x[k].astype(np.float64) - o["r8"][k].astype(np.float64)).max(axis=0))
+        for k in ("swuflx", "swdflx"):
+            e = np.maximum(e, np.where(free, np.abs(x[k].astype(np.float64) - o["r8"][k].astype(np.float64)).max(axis=0), 0.0))
+        return e / toa
+
+    eg, eo = err(g4), err(o["r4"])
+    q = lambda e: (np.median(e), np.percentile(e, 99), e.max())
+    print("fp32 error vs r8 oracle, fraction of the TOA flux (median, 99 %%, max): GPU %.2e %.2e %.2e | r4 oracle %.2e %.2e %.2e" % (q(eg) + q(eo)))
+    assert np.median(eg) <= 1.25 * np.median(eo) + 1e-7
+    assert np.percentile(eg, 99) <= 1.25 * np.percentile(eo, 99) + 1e-6
+    assert eg.max() <= max(1.5 * eo.max(), 1e-4)      # measured: GPU 2.1e-5 / 6.1e-5 / 4.3e-4, r4 oracle 2.2e-5 / 6.1e-5 / 3.4e-4
