@@ -1133,11 +1133,13 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     for (int lay = nlay - 1; lay >= 0; lay--) {
         Layer<R> L;
         load_layer<R>(A, lay, col, pc, L);
-        Prep<R> P;
-        BAND::template prep<R>(T, A, L, P);
+        // the layer's aerosol and temperatures are requested, and the Planck look-ups they lead to made, BEFORE the band's prep: behind
+        // it they were a memory round trip of their own in every layer (5.12 -> 4.85 ms per 100 000 clear-sky columns)
         const R ta = A.tauaer ? ldg(A.tauaer + (size_t)(IB - 1) * nlay * ld, L.ab) : (R)0;
         const R blay = planck_at<R>(T.totplnk, IB, ldg(A.tlay, L.ab));
         const R plk_dn = planck_at<R>(T.totplnk, IB, ldg(A.tlev, L.ab));
+        Prep<R> P;
+        BAND::template prep<R>(T, A, L, P);
         const R dplankup = plk_up - blay, dplankdn = plk_dn - blay;
         plk_up = plk_dn;
         bool laycld = false;
@@ -1401,10 +1403,10 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
         // the Planck fraction, which the band body evaluates again (its optical-depth terms are dead code here)
         Layer<R> L;
         load_layer<R>(A, lay, col, pc, L);
-        Prep<R> P;
-        BAND::template prep<R>(T, A, L, P);
         const R blay = planck_at<R>(T.totplnk, IB, ldg(A.tlay, L.ab));
         const R dplankup = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)ld, L.ab)) - blay;
+        Prep<R> P;
+        BAND::template prep<R>(T, A, L, P);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             R tau[W], pf[W];
