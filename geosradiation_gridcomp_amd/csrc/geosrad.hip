@@ -245,14 +245,18 @@ struct geosrad_ctx {
     // the gathering of chunk k+1, the transfers and the kernels of chunk k and the scattering of chunk k-1 overlap.
     struct PipeArr { const void *src; void *dst; size_t rows, ebytes; size_t off; };      // src: copied in; dst: copied back (either may be null)
     int host_chunk = 16384, host_chunk_default = 16384, host_threads = 8;
-    char *pipe_pin[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [slot][0 = to the device, 1 = from the device]
-    char *pipe_dev[2] = {nullptr, nullptr};
+    // three staging slots, results copied back to the caller two chunks behind the one being gathered: the host thread then never waits
+    // for the GPU in steady state and the H2D engine always has the next chunk queued (two slots in lock-step left it idle while the
+    // host gathered: 4.25 instead of 3.4 ms per 16 384-column chunk)
+    static constexpr int PIPE_SLOTS = 3, PIPE_LAG = 2;
+    char *pipe_pin[PIPE_SLOTS][2] = {};      // [slot][0 = to the device, 1 = from the device]
+    char *pipe_dev[PIPE_SLOTS] = {};
     size_t pipe_pin_bytes = 0, pipe_dev_bytes = 0;
     hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr;
-    hipEvent_t pipe_ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};      // per slot: h2d, compute, d2h done
+    hipEvent_t pipe_ev[PIPE_SLOTS][3] = {};      // per slot: h2d, compute, d2h done
     void pipe_release()
     {
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < PIPE_SLOTS; s++) {
             for (int d = 0; d < 2; d++) if (pipe_pin[s][d]) { (void)hipHostFree(pipe_pin[s][d]); pipe_pin[s][d] = nullptr; }
             if (pipe_dev[s]) { (void)hipFree(pipe_dev[s]); pipe_dev[s] = nullptr; }
             for (int e = 0; e < 3; e++) if (pipe_ev[s][e]) { (void)hipEventDestroy(pipe_ev[s][e]); pipe_ev[s][e] = nullptr; }
@@ -310,11 +314,11 @@ struct geosrad_ctx {
         if (!pipe_h2d) {
             PIPECHK(hipStreamCreateWithFlags(&pipe_h2d, hipStreamNonBlocking));
             PIPECHK(hipStreamCreateWithFlags(&pipe_d2h, hipStreamNonBlocking));
-            for (int s = 0; s < 2; s++) for (int e = 0; e < 3; e++) PIPECHK(hipEventCreateWithFlags(&pipe_ev[s][e], hipEventDisableTiming));
+            for (int s = 0; s < PIPE_SLOTS; s++) for (int e = 0; e < 3; e++) PIPECHK(hipEventCreateWithFlags(&pipe_ev[s][e], hipEventDisableTiming));
         }
         if (total > pipe_dev_bytes || total > pipe_pin_bytes) {
             PIPECHK(hipDeviceSynchronize());
-            for (int s = 0; s < 2; s++) {
+            for (int s = 0; s < PIPE_SLOTS; s++) {
                 if (pipe_dev[s]) { (void)hipFree(pipe_dev[s]); pipe_dev[s] = nullptr; }
                 for (int d = 0; d < 2; d++) if (pipe_pin[s][d]) { (void)hipHostFree(pipe_pin[s][d]); pipe_pin[s][d] = nullptr; }
                 if (hipMalloc((void **)&pipe_dev[s], total) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the host-API staging slot failed");
@@ -329,15 +333,15 @@ struct geosrad_ctx {
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double t_g = 0, t_s = 0, t_w = 0, t_e = 0;
         const double t_begin = now();
-        for (int k = 0; k <= nchunks; k++) {
+        for (int k = 0; k < nchunks + PIPE_LAG; k++) {
             if (k < nchunks) {
-                const int s = k & 1, c0 = k * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
+                const int s = k % PIPE_SLOTS, c0 = k * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
                 double t0 = now();
-                if (k >= 2) PIPECHK(hipEventSynchronize(pipe_ev[s][0]));            // the slot's previous transfer has left the staging memory
+                if (k >= PIPE_SLOTS) PIPECHK(hipEventSynchronize(pipe_ev[s][0]));   // the slot's previous transfer has left the staging memory
                 double t1 = now(); t_w += t1 - t0;
                 pipe_copy(arrs, pipe_pin[s][0], 0, ncol, c0, nc, true);
                 t0 = now(); t_g += t0 - t1;
-                if (k >= 2) PIPECHK(hipStreamWaitEvent(pipe_h2d, pipe_ev[s][2], 0));   // ... and chunk k-2 has been copied out of the device slot
+                if (k >= PIPE_SLOTS) PIPECHK(hipStreamWaitEvent(pipe_h2d, pipe_ev[s][2], 0));   // ... and its previous chunk has been copied out of the device slot
                 if (in_bytes) PIPECHK(hipMemcpyAsync(pipe_dev[s], pipe_pin[s][0], in_bytes, hipMemcpyHostToDevice, pipe_h2d));
                 PIPECHK(hipEventRecord(pipe_ev[s][0], pipe_h2d));
                 PIPECHK(hipStreamWaitEvent(stream, pipe_ev[s][0], 0));
@@ -349,8 +353,8 @@ struct geosrad_ctx {
                 PIPECHK(hipEventRecord(pipe_ev[s][2], pipe_d2h));
                 t_e += now() - t0;
             }
-            if (k >= 1) {
-                const int j = k - 1, s = j & 1, c0 = j * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
+            if (k >= PIPE_LAG && k - PIPE_LAG < nchunks) {
+                const int j = k - PIPE_LAG, s = j % PIPE_SLOTS, c0 = j * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
                 double t0 = now();
                 PIPECHK(hipEventSynchronize(pipe_ev[s][2]));
                 double t1 = now(); t_w += t1 - t0;
