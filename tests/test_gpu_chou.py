@@ -155,3 +155,15 @@ def test_sorad_on_chip_path_matches_oracle_and_default_path(gpu_ctx, rk):
                 np.testing.assert_array_equal(p[k], g[k][..., 20:41], err_msg=k)      # a column's result does not depend on its batch
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_sorad_gpu_layer_split_invariance(gpu_ctx, rk):
+    """The GPU's deledd + CLDFLX pair checked against itself (tests/conftest.py split_layers), clear sky with aerosols."""
+    from geosradiation_gridcomp_amd import synth
+    from tests.conftest import split_layers
+    inp = synth.make_columns(64, 72, start=910, cloudy_frac=0.0, aerosol=True)
+    a = gpu_ctx[rk].sorad_columns(synth.chou_sw_inputs(inp, aerosol=True)); b = gpu_ctx[rk].sorad_columns(synth.chou_sw_inputs(split_layers(inp), aerosol=True))
+    for k in ("flx", "flxu"):
+        d = np.abs(np.asarray(b[k])[0::2].astype(np.float64) - np.asarray(a[k]).astype(np.float64)).max()
+        assert d <= (2e-4 if rk == 8 else 5e-4), (k, d)

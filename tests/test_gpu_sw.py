@@ -303,3 +303,17 @@ def test_sw_fp32_is_as_accurate_as_the_reference_precision(gpu_ctx):
     assert np.median(eg) <= 1.25 * np.median(eo) + 1e-7
     assert np.percentile(eg, 99) <= 1.25 * np.percentile(eo, 99) + 1e-6
     assert eg.max() <= max(1.5 * eo.max(), 1e-4)      # measured: GPU 2.1e-5 / 6.1e-5 / 4.3e-4, r4 oracle 2.2e-5 / 6.1e-5 / 3.4e-4
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_sw_gpu_layer_split_invariance(gpu_ctx, rk):
+    """The GPU's own two-stream + adding pair checked against itself, no oracle involved (tests/conftest.py split_layers): 72 layers
+    against the same atmosphere in 144 half layers, clear sky with aerosols."""
+    from geosradiation_gridcomp_amd import synth
+    from tests.conftest import split_layers
+    inp = synth.make_columns(64, 72, start=910, cloudy_frac=0.0, aerosol=True)
+    a = gpu_ctx[rk].rrtmg_sw_columns(inp, iaer=10); b = gpu_ctx[rk].rrtmg_sw_columns(split_layers(inp), iaer=10)
+    toa = a["swdflx"][72].astype(np.float64)
+    for k in ("swuflx", "swdflx"):
+        d = (np.abs(b[k][0::2].astype(np.float64) - a[k].astype(np.float64)) / toa).max()
+        assert d <= (5e-5 if rk == 8 else 3e-4), (k, d)

@@ -144,3 +144,18 @@ def test_sorad_vs_rrtmg_sw_aerosol_spectral_consistency():
     assert d_rand.max() > 1.5 * d_flat.max()                          # the inconsistent aerosol columns are what made the outliers
     assert inp["coszen"][d_rand.argmax()] < 0.15                      # ... at low sun
     assert abs(np.median(d_rand) - np.median(d_none)) < 2e-3          # the typical column is unaffected
+
+
+def test_sorad_delta_eddington_is_consistent_with_the_adding_recurrences():
+    """Layer-split invariance (tests/conftest.py split_layers) for sorad: deledd's layer solution against CLDFLX's adding, clear sky.
+    (The half layers' mean pressures differ from the whole layer's, which sorad's water-vapour scaling sees: hence 2e-4 and not
+    round-off; measured 6.7e-5 of the insolation.)  An anchor for an oracle that cannot be pinned to the reference (sorad.F90 needs
+    MAPL_ConstantsMod)."""
+    from tests.conftest import split_layers
+    inp = synth.make_columns(16, 72, start=900, cloudy_frac=0.0, aerosol=True)
+    inp = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in inp.items()}
+    for aer in (False, True):
+        a = clib.sorad(synth.chou_sw_inputs(inp, aerosol=aer), "f64"); b = clib.sorad(synth.chou_sw_inputs(split_layers(inp), aerosol=aer), "f64")
+        assert a["rc"] == 0 and b["rc"] == 0
+        for k in ("flx", "flxu", "flc", "flcu"):
+            assert np.abs(np.asarray(b[k])[0::2] - np.asarray(a[k])).max() <= 2e-4, (aer, k)
