@@ -167,3 +167,16 @@ def test_sorad_gpu_layer_split_invariance(gpu_ctx, rk):
     for k in ("flx", "flxu"):
         d = np.abs(np.asarray(b[k])[0::2].astype(np.float64) - np.asarray(a[k]).astype(np.float64)).max()
         assert d <= (2e-4 if rk == 8 else 5e-4), (k, d)
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_irrad_gpu_isothermal_equilibrium(gpu_ctx, rk):
+    """The GPU's level-pair integration checked against physics instead of the oracle: isothermal atmosphere over a black surface of the
+    same temperature -> the upward flux is the same at every level (tests/test_oracle_chou.py::test_irrad_isothermal_equilibrium)."""
+    from geosradiation_gridcomp_amd import synth
+    from tests.test_oracle_chou import _isothermal
+    T0 = 268.0
+    o = gpu_ctx[rk].irrad_columns(synth.chou_lw_inputs(_isothermal(64, T0)))
+    fu = np.asarray(o["flxu"], dtype=np.float64)
+    assert (fu.max(axis=0) - fu.min(axis=0)).max() <= (1e-9 if rk == 8 else 2e-3), (fu.max(axis=0) - fu.min(axis=0)).max()
+    np.testing.assert_allclose(-fu[0], 5.670374e-8 * T0 ** 4, rtol=1e-3)

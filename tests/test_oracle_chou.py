@@ -159,3 +159,27 @@ def test_sorad_delta_eddington_is_consistent_with_the_adding_recurrences():
         assert a["rc"] == 0 and b["rc"] == 0
         for k in ("flx", "flxu", "flc", "flcu"):
             assert np.abs(np.asarray(b[k])[0::2] - np.asarray(a[k])).max() <= 2e-4, (aer, k)
+
+
+def _isothermal(n=12, T0=268.0):
+    inp = synth.make_columns(n, 72, start=40, cloudy_frac=0.0)
+    for k in ("tlay", "tlev"):
+        inp[k] = np.full_like(inp[k], T0)
+    inp["tsfc"] = np.full_like(inp["tsfc"], T0); inp["emis"] = np.ones_like(inp["emis"])
+    return inp
+
+
+def test_irrad_isothermal_equilibrium():
+    """An isothermal atmosphere over a black surface of the same temperature: whatever the absorbers, the upward flux is the band-integrated
+    Planck flux at EVERY level (surface emission x transmittance + emission of the layers below = B).  irrad's level-pair integration
+    (loop 2000) must reproduce that to round-off, and its band Planck fits sum to sigma T^4 within their accuracy - an anchor that
+    needs no reference data (irrad.F90 cannot be built here: MAPL_ConstantsMod)."""
+    T0 = 268.0
+    o = clib.irrad(synth.chou_lw_inputs(_isothermal(T0=T0)), "f64")
+    assert o["rc"] == 0
+    fu = np.asarray(o["flxu"], dtype=np.float64)
+    assert (fu.max(axis=0) - fu.min(axis=0)).max() <= 1e-10                      # measured 2e-13 W m-2
+    np.testing.assert_allclose(-fu[0], 5.670374e-8 * T0 ** 4, rtol=1e-3)          # 292.66 against 292.52 W m-2
+    np.testing.assert_allclose(np.asarray(o["sfcem"]), fu[-1], rtol=1e-12)
+    fd = np.asarray(o["flxd"], dtype=np.float64)
+    assert (np.diff(fd, axis=0) >= -1e-10).all() and (fd[-1] < -fu[-1]).all()     # downward flux grows towards the surface, below B
