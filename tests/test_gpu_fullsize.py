@@ -110,3 +110,37 @@ def test_chou_pair_100k_columns(gpu_ctx):
 
 def sub_columns_any(d, m, ncol):
     return {k: (np.ascontiguousarray(v[..., :m]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("nlay", [4, 203])
+@pytest.mark.parametrize("rk", [8, 4])
+def test_layer_count_limits(gpu_ctx, rk, nlay):
+    """The smallest and the largest layer count the solvers accept (4; mxlay = 203, parrrtm.F90 / parrrsw.F90), a ragged handful of
+    cloudy columns with aerosols: RRTMG_LW and RRTMG_SW against the oracle; one layer more or fewer is refused."""
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import GeosradError
+    from oracle import clib
+    ctx = gpu_ctx[rk]
+    kind = "r8" if rk == 8 else "r4"
+    inp = synth.make_columns(7, nlay, start=5000, cloudy_frac=0.7, aerosol=True)
+    ctx.set_inhomogeneity(1); clib.set_inhomogeneity(1, kind)
+    try:
+        gl = ctx.rrtmg_lw_columns(inp); ol = clib.rrtmg_lw(inp, prec=kind)
+        gs = ctx.rrtmg_sw_columns(inp, iaer=10); os_ = clib.rrtmg_sw(inp, prec=kind, iaer=10)
+    finally:
+        ctx.set_inhomogeneity(0); clib.set_inhomogeneity(0, kind)
+    assert ol["rc"] == 0 and os_["rc"] == 0
+    same = (gl["clearCounts"] == ol["clearCounts"]).all(axis=0) & (gs["clearCounts"] == os_["clearCounts"]).all(axis=0)
+    assert same.all() if rk == 8 else same.sum() >= 5
+    for k in ("uflx", "dflx", "uflxc", "dflxc"):
+        err = np.abs(gl[k].astype(np.float64) - ol[k].astype(np.float64))[:, same].max()
+        assert err <= (1e-6 if rk == 8 else 2e-3), (k, err)
+    toa = os_["swdflx"][nlay].astype(np.float64)
+    for k in ("swuflx", "swdflx", "swuflxc", "swdflxc"):
+        err = (np.abs(gs[k].astype(np.float64) - os_[k].astype(np.float64)) / toa)[:, same].max()
+        assert err <= (1e-9 if rk == 8 else 5e-4), (k, err)
+    bad = synth.make_columns(2, nlay + 1 if nlay == 203 else nlay - 1, start=5000)
+    with pytest.raises(GeosradError):
+        ctx.rrtmg_lw_columns(bad)
+    with pytest.raises(GeosradError):
+        ctx.rrtmg_sw_columns(bad)
