@@ -144,3 +144,25 @@ def test_layer_count_limits(gpu_ctx, rk, nlay):
         ctx.rrtmg_lw_columns(bad)
     with pytest.raises(GeosradError):
         ctx.rrtmg_sw_columns(bad)
+
+
+@pytest.mark.parametrize("nlay", [12, 203, 400])
+@pytest.mark.parametrize("rk", [8, 4])
+def test_chou_layer_count_limits(gpu_ctx, rk, nlay):
+    """irrad and sorad far from the 72 layers everything else uses (their per-band LDS tiles and scratch planes scale with np), a ragged
+    handful of cloudy columns with aerosols, against the oracle."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    ctx = gpu_ctx[rk]
+    prec = "f64" if rk == 8 else "f32"
+    inp = synth.make_columns(5, nlay, start=5100, cloudy_frac=0.8, aerosol=True)
+    ch = synth.chou_lw_inputs(inp, aerosol=True); cs = synth.chou_sw_inputs(inp, aerosol=True)
+    gi = ctx.irrad_columns(ch); oi = clib.irrad(ch, prec)
+    gs = ctx.sorad_columns(cs); os_ = clib.sorad(cs, prec)
+    assert oi["rc"] == 0 and os_["rc"] == 0
+    for k in ("flxu", "flxd", "flcu", "flcd"):
+        err = np.abs(np.asarray(gi[k], dtype=np.float64) - np.asarray(oi[k], dtype=np.float64)).max()
+        assert err <= (1e-6 if rk == 8 else 5e-2), (k, err)
+    for k in ("flx", "flc", "flxu", "flcu"):
+        err = np.abs(np.asarray(gs[k], dtype=np.float64) - np.asarray(os_[k], dtype=np.float64)).max()
+        assert err <= (1e-9 if rk == 8 else 5e-5), (k, err)
