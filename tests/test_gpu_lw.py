@@ -478,3 +478,26 @@ def test_lw_fp32_is_as_accurate_as_the_reference_precision(gpu_ctx):
     assert np.median(eg) <= 1.25 * np.median(eo) + 1e-6
     assert np.percentile(eg, 99) <= 1.25 * np.percentile(eo, 99) + 1e-5
     assert eg.max() <= max(1.5 * eo.max(), 2e-3)      # measured: GPU 7.7e-5 / 1.1e-3 / 2.2e-3 W m-2, r4 oracle 1.7e-4 / 1.1e-3 / 2.2e-3
+
+
+@pytest.mark.parametrize("nsub,nlay,ncol", [(1, 72, 9), (7, 4, 70), (513, 72, 3), (200, 203, 5), (65, 137, 130)])
+def test_mcica_generator_odd_shapes(gpu_ctx, nsub, nlay, ncol):
+    """The stand-alone generator on shapes that straddle its tiling (k_mcica_sa: 64 (column, sub-column) pairs per chunk, 8 chunks per
+    wavefront, an LDS tile of 64 x nlay; beyond the LDS the lane = column kernel): one sub-column, sub-column counts that are no multiple
+    of anything, the smallest and the largest layer count - fp64 against the pinned oracle, masks bit for bit."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    ctx = gpu_ctx[8]
+    inp = synth.make_columns(ncol, nlay, start=9000 + nsub, cloudy_frac=0.8)
+    for ih in (0, 1):
+        ctx.set_inhomogeneity(ih); clib.set_inhomogeneity(ih, "r8")
+        try:
+            cl, ci, cw = ctx.generate_stochastic_clouds(ncol, nsub, nlay, inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"],
+                                                        inp["ciwp"], inp["clwp"], 1e-20, seed_order=(4, 3, 2, 1))
+            rl, ri, rw = clib.mcica(inp["zm"], inp["alat"], int(inp["dyofyr"]), inp["play"], inp["cldf"], inp["ciwp"], inp["clwp"], nsub,
+                                    seed_order=(4, 3, 2, 1), prec="r8")
+        finally:
+            ctx.set_inhomogeneity(0); clib.set_inhomogeneity(0, "r8")
+        np.testing.assert_array_equal(cl, rl.astype(np.int32))
+        np.testing.assert_allclose(ci, ri, rtol=1e-13, atol=0); np.testing.assert_allclose(cw, rw, rtol=1e-13, atol=0)
+        assert cl.sum() > 0
