@@ -803,9 +803,11 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
                          "columns_per_launch": ncol_k / launches_per_step,
-                         "note": "fused k-distribution + two-stream sweep is FP32/latency bound (~170 FLOP per algorithmic byte, "
-                                 "SURVEY 8(d)); HBM fraction of the compulsory bytes is expected to be small; `traffic` = PMC bytes of this "
-                                 "kernel per step / its launches per step (profiles/r02_traffic.json)" + ("; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own "
+                         "note": "a `launch` here is the kernel's cloud-free and cloudy instantiation launched back to back over the batch "
+                                 "(one HIP-event span; in the rocprofv3 kernel stats: the sum of the two instantiations' average durations); "
+                                 "the fused k-distribution + two-stream sweep moves ~36x its compulsory bytes (parked cells between its two "
+                                 "sweeps) and runs at the HBM rate of that traffic, so the fraction on the compulsory bytes is small; "
+                                 "`traffic` = PMC bytes of this kernel per step / its launches per step (profiles/r02_traffic.json)" + ("; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own "
                                                 "duration from two further steps on one stream" if side is not None else "")},
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,
