@@ -1039,7 +1039,10 @@ template <typename R, typename BAND, bool CLD, bool DBG>
 GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclear, const typename Vec2<R>::T *luts)
 {
     constexpr int NG = BAND::NG, IB = BAND::IB, G0 = BAND::G0;
-    constexpr int W = NG >= 4 ? 4 : 2;
+    // g-points per evaluation of the k-distribution: 4 (one 16-byte piece of each table row); 8 in the cloud-free instantiation for the
+    // bands whose g-point count is a multiple of 8 (half as many serial table-row round trips per layer, 227 instead of 213 VGPRs:
+    // 4.98 -> 4.78 ms per 100 000 clear-sky columns; the cloudy instantiation has no registers for it)
+    constexpr int W = (!CLD && NG % 8 == 0) ? 8 : (NG >= 4 ? 4 : 2);
     constexpr int NQ = (NG + W - 1) / W;
     using R2 = typename Vec2<R>::T;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
