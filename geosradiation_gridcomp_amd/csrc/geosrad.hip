@@ -874,7 +874,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             O.olrb = (R *)out[O_OLRB]; O.dolrb_dTs = (R *)out[O_DOLRB]; O.col0 = c0;
             const size_t lds = lw_bands_lds_bytes<R>();
             // band sweeps.  lw_cols: (layer, g-point) intermediates in LDS, fluxes written directly (lw_cols_kernels.hpp);
-            // lw_bands: lane = column with the parked (a, B-up) pairs in HBM + the band reduction (the RATS passes need its per-band
+            // lw_bands: lane = column with the parked cells (2-byte Pade indices) in HBM + the band reduction (the RATS passes need its per-band
             // partials, so a call with RATS diagnostics takes that path throughout)
             const bool cols = lw_cols_path && !(rats && rats->n > 0);
             span_begin(4, st);

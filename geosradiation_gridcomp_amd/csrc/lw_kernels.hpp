@@ -2,14 +2,15 @@
 //
 // What is computed follows the reference (file:line cited at each kernel; LW = GEOSirrad_GridComp/RRTMG/
 // rrtmg_lw/gcm_model/src); how it is computed is ours:
-//   lane = column, all HBM traffic coalesced over the column dimension, no cross-lane traffic, no LDS
-//   dependence, no MFMA (the path is table interpolation + first-order vertical recurrences).
+//   lane = column, all HBM traffic coalesced over the column dimension, no cross-lane traffic, LDS only as a
+//   read-only copy of the transmittance table, no MFMA (the path is table interpolation + first-order vertical
+//   recurrences).  (The other mapping - lanes = layers, intermediates in LDS - is k_lw_cols, lw_cols_kernels.hpp.)
 //   k_validate_pwv : per column  - input checks, precipitable water, "any cloud" flag
 //   k_setcoef      : per (layer,column) - p/T interpolation record shared by all 16 bands
-//   k_lw_bands     : per (column, band): fused taumol -> rtrnmc; blockIdx.y selects the band body
-//                    (heaviest bands first); down sweep keeps the band's g-point radiances in
-//                    registers and evaluates the k-distribution 4 g-points at a time, up sweep
-//                    re-reads the (absorptivity, source) pairs it parked in HBM
+//   k_lw_bands     : per (256-column block, band) (band_block: XCD-aware grid): fused taumol -> rtrnmc; down sweep
+//                    keeps the band's g-point radiances in registers and evaluates the k-distribution 4 or 8
+//                    g-points at a time, parking the 2-byte table index of every cell in HBM; the up sweep
+//                    re-forms (absorptivity, source) from the parked indices
 //   k_lw_reduce    : per (level,column) - fixed-order sum of the 16 band partials (bitwise reproducible)
 #pragma once
 #include "lw_device.hpp"
@@ -1086,7 +1087,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     // uniform bases
     const size_t bandoff = (size_t)G0 * nlay * n;                         // this band's sub-array of the cell planes
     const R *const taucmc_b = A.taucmc + bandoff;
-    // the parked (a, B-up) pairs are tiled by 256-column block, [block][layer][g][256]: a block's scratch is one contiguous run
+    // the parked cells are tiled by 256-column block, [block][layer][g][256]: a block's scratch is one contiguous run
     const uint32_t npad = ((uint32_t)n + 255u) & ~255u;
     // what is parked per cell between the sweeps: the Pade index of the cell's discretised optical depth, 2 bytes - the up sweep
     // re-forms (absorptivity, source) from it: table look-up + the layer's Planck terms + the Planck fraction, which is re-evaluated
@@ -1125,7 +1126,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     int ltop = -1;   // highest optically cloudy layer: where the clear/total streams part (:297-307)
     R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
 
-    // (a, B-up) pairs of the g-group processed last, waiting to be written (see phase 2 below)
+    // parked cells of the g-group processed last, waiting to be written (see phase 2 below)
     constexpr bool DEFER = !CLD;       // the cloudy instantiation has no registers to spare for it
     PK pend1[W], pend2[W];
     uint32_t poff[W];
@@ -1176,7 +1177,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 eg[j] = lut_at(itg[j]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // phase 2: only now write the PREVIOUS group's (a, B-up) pairs.  Loads and stores share one in-order counter
+            // phase 2: only now write the PREVIOUS group's parked cells.  Loads and stores share one in-order counter
             // (vmcnt) on gfx9: a load issued after a store cannot be consumed before that store is acknowledged, so the
             // stores go behind this group's loads and get a whole group of arithmetic to drain.
             if (npend) {

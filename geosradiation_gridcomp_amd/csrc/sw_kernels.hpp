@@ -4,14 +4,15 @@
 // solar variability, albedo->band map, normFlx), rrtmg_sw_setcoef.F90:23-241, rrtmg_sw_taumol.F90:27-2084,
 // rrtmg_sw_cldprmc.F90:36-418, rrtmg_sw_spcvmc.F90:34-1112 (+ reftra_sw :1115-1370, vrtqdr_sw :1374-1588).
 //
-// Same mapping as the LW path (lane = column, blockIdx.y = band, uniform base + 32-bit byte offset addressing):
+// Same mapping as the LW path (lane = column, one block per (256-column block, band) on the XCD-aware one-dimensional grid of
+// lw_kernels.hpp band_block, uniform base + 32-bit byte offset addressing):
 //   k_sw_validate : per column  - input asserts, cloudy flags, clearCounts of clear columns
 //   k_sw_setcoef  : per (layer,column) - column amounts + p/T interpolation record shared by all 14 bands
 //   k_mcica<.,2>  : per (column, band) - McICA sub-columns + cldprmc_sw (delta-scaled tau, ssa, g) [mcica_kernels.hpp]
 //   k_sw_bands    : per (column, band) - fused taumol_sw -> delta-scaling -> reftra_sw -> vrtqdr_sw:
-//                   sweep A (TOA -> surface) evaluates the layer R/T and the downward adding recurrences and parks
-//                   8 values per cell; sweep B (surface -> TOA) runs the upward recurrences and forms the fluxes.
-//                   Cloudy columns carry the clear-sky and the total-sky problem through the same two sweeps.
+//                   sweep A (surface -> TOA) evaluates the layer R/T and the upward adding recurrences and parks 7 values
+//                   per cell; sweep B (TOA -> surface) runs the downward recurrences in registers and forms the fluxes
+//                   (see sw_band_body).  Cloudy columns carry the clear-sky and the total-sky problem through the same two sweeps.
 //   k_sw_reduce   : per column - fixed-order sum over bands, surface band diagnostics, optional normalisation
 #pragma once
 #include "lw_kernels.hpp"
