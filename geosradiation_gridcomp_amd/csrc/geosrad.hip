@@ -11,6 +11,7 @@
 #include <tuple>
 #include <vector>
 #include <thread>
+#include <atomic>
 #include <functional>
 #include <chrono>
 
@@ -245,6 +246,7 @@ struct geosrad_ctx {
     // the gathering of chunk k+1, the transfers and the kernels of chunk k and the scattering of chunk k-1 overlap.
     struct PipeArr { const void *src; void *dst; size_t rows, ebytes; size_t off; };      // src: copied in; dst: copied back (either may be null)
     int host_chunk = 16384, host_chunk_default = 16384, host_threads = 8;
+    bool host_nt = true;            // non-temporal stores into the staging slots (GEOSRAD_HOST_NT=0: plain memcpy)
     // three staging slots, results copied back to the caller two chunks behind the one being gathered: the host thread then never waits
     // for the GPU in steady state and the H2D engine always has the next chunk queued (two slots in lock-step left it idle while the
     // host gathered: 4.25 instead of 3.4 ms per 16 384-column chunk)
@@ -265,6 +267,19 @@ struct geosrad_ctx {
         if (pipe_d2h) { (void)hipStreamDestroy(pipe_d2h); pipe_d2h = nullptr; }
         pipe_pin_bytes = pipe_dev_bytes = 0;
     }
+    // a row into the write-once staging memory with non-temporal stores: no read-for-ownership of the destination lines (the rows,
+    // 64 KB each, are below the size from which memcpy streams by itself)
+    static void copy_stream(char *dst, const char *src, size_t n)
+    {
+        typedef long long v2a __attribute__((vector_size(16), aligned(16)));
+        typedef long long v2u __attribute__((vector_size(16), aligned(1)));
+        size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+        if (head > n) head = n;
+        memcpy(dst, src, head); dst += head; src += head; n -= head;
+        const size_t nv = n / 16;
+        for (size_t i = 0; i < nv; i++) __builtin_nontemporal_store(*(const v2u *)(src + 16 * i), (v2a *)(dst + 16 * i));
+        memcpy(dst + 16 * nv, src + 16 * nv, n - 16 * nv);
+    }
     // rows of `arrs` (a chunk's nc columns starting at c0 of ncol) between the caller's arrays and a staging slot, on copy threads
     void pipe_copy(std::vector<PipeArr> &arrs, char *slot, size_t slot_base, int ncol, int c0, int nc, bool to_slot)
     {
@@ -279,9 +294,12 @@ struct geosrad_ctx {
                 const PipeArr &a = *items[i].a;
                 const size_t r = items[i].row;
                 char *sl = slot + (a.off - slot_base) + r * (size_t)nc * a.ebytes;      // a chunk's arrays are dense: leading dimension nc
-                if (to_slot) memcpy(sl, (const char *)a.src + (r * (size_t)ncol + (size_t)c0) * a.ebytes, (size_t)nc * a.ebytes);
-                else memcpy((char *)a.dst + (r * (size_t)ncol + (size_t)c0) * a.ebytes, sl, (size_t)nc * a.ebytes);
+                if (to_slot) {
+                    if (host_nt) copy_stream(sl, (const char *)a.src + (r * (size_t)ncol + (size_t)c0) * a.ebytes, (size_t)nc * a.ebytes);
+                    else memcpy(sl, (const char *)a.src + (r * (size_t)ncol + (size_t)c0) * a.ebytes, (size_t)nc * a.ebytes);
+                } else memcpy((char *)a.dst + (r * (size_t)ncol + (size_t)c0) * a.ebytes, sl, (size_t)nc * a.ebytes);
             }
+            if (to_slot && host_nt) std::atomic_thread_fence(std::memory_order_seq_cst);      // the streamed rows are visible before the DMA reads them
         };
         size_t bytes = 0;
         for (auto &it : items) bytes += (size_t)nc * it.a->ebytes;
@@ -2272,6 +2290,7 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
         // tuning of the host-pointer pipeline: columns per staged chunk, copy threads
         if ((e = getenv("GEOSRAD_HOST_CHUNK")) && atoi(e) >= 64) c->host_chunk = c->host_chunk_default = atoi(e);
         if ((e = getenv("GEOSRAD_HOST_THREADS")) && atoi(e) >= 1) c->host_threads = atoi(e) > 64 ? 64 : atoi(e);
+        if ((e = getenv("GEOSRAD_HOST_NT"))) c->host_nt = atoi(e) != 0;
     }
     int rc = c->init();
     if (rc) { delete c; return rc; }
