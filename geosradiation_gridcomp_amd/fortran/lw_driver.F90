@@ -16,6 +16,9 @@ program lw_driver
    integer, allocatable :: cc(:,:)
    logical :: bo(nbndlw)
    character(len=512) :: fin, fout
+   character(len=32) :: frep
+   integer :: nrep
+   integer(8) :: t0, t1, trate
    call get_command_argument(1, fin); call get_command_argument(2, fout)
    open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
    read(u) ncol, nlay, ih, dyofyr, cloudLM, cloudMH
@@ -37,6 +40,18 @@ program lw_driver
    bo = .false.
    call rrtmg_lw(ncol, nlay, 4, .true., play, plev, tlay, tlev, tsfc, emis, h2o, o3, co2, ch4, n2o, o2, c11, c12, c22, ccl4, &
       cldf, ciwp, clwp, rei, rel, 3, 1, tauaer, zm, alat, dyofyr, cloudLM, cloudMH, cc, uflx, dflx, uflxc, dflxc, du, duc, bo, olrb, dolrb)
+   ! optional third argument: repeat the call that many times and report the caller-side time of one call (host arrays in, host arrays out)
+   call get_command_argument(3, frep)
+   if (len_trim(frep) > 0) then
+      read(frep, *) nrep
+      call system_clock(t0, trate)
+      do i = 1, nrep
+         call rrtmg_lw(ncol, nlay, 4, .true., play, plev, tlay, tlev, tsfc, emis, h2o, o3, co2, ch4, n2o, o2, c11, c12, c22, ccl4, &
+            cldf, ciwp, clwp, rei, rel, 3, 1, tauaer, zm, alat, dyofyr, cloudLM, cloudMH, cc, uflx, dflx, uflxc, dflxc, du, duc, bo, olrb, dolrb)
+      end do
+      call system_clock(t1)
+      write(*,'(a,i0,a,f10.3)') 'rrtmg_lw from Fortran: ncol ', ncol, ' ms per call ', 1.0d3 * dble(t1 - t0) / dble(trate) / dble(nrep)
+   end if
    open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
    write(u) real(uflx,8), real(dflx,8), real(uflxc,8), real(dflxc,8), real(du,8), real(duc,8), cc
    close(u)

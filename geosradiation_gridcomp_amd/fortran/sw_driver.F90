@@ -19,6 +19,9 @@ program sw_driver
    real, allocatable, dimension(:,:,:) :: tauaer, ssaaer, asmaer
    integer, allocatable :: cc(:,:)
    character(len=512) :: fin, fout
+   character(len=32) :: frep
+   integer :: nrep
+   integer(8) :: t0, t1, trate
    call get_command_argument(1, fin); call get_command_argument(2, fout)
    open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
    read(u) ncol, nlay, ih, dyofyr, cloudLM, cloudMH, iaer, normFlx, isolvar, scon4
@@ -49,6 +52,20 @@ program sw_driver
       3, 1, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, &
       cloudLM, cloudMH, normFlx, cc, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, &
       c1, c2, c3, c4, c5, c6, c7, c8, .true., drband, dfband, RC=rc)
+   ! optional third argument: repeat the call that many times and report the caller-side time of one call
+   call get_command_argument(3, frep)
+   if (len_trim(frep) > 0) then
+      read(frep, *) nrep
+      call system_clock(t0, trate)
+      do i = 1, nrep
+      call rrtmg_sw(mapl_placeholder, 4, ncol, nlay, real(scon4), 1.0, coszen, isolvar, play, plev, tlay, h2o, o3, co2, ch4, o2, &
+      3, 1, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, &
+      cloudLM, cloudMH, normFlx, cc, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, &
+      c1, c2, c3, c4, c5, c6, c7, c8, .true., drband, dfband, RC=rc)
+      end do
+      call system_clock(t1)
+      write(*,'(a,i0,a,f10.3)') 'rrtmg_sw from Fortran: ncol ', ncol, ' ms per call ', 1.0d3 * dble(t1 - t0) / dble(trate) / dble(nrep)
+   end if
    open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
    write(u) rc, real(swuflx,8), real(swdflx,8), real(swuflxc,8), real(swdflxc,8), real(nirr,8), real(parf,8), real(fswband,8), &
       real(drband,8), real(dfband,8), real(c1,8), cc

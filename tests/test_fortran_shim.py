@@ -267,3 +267,34 @@ def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
     for k in ("FLX", "OLR", "FLNS", "SFCEM"):
         np.testing.assert_array_equal(got[k], u[k].cpu().numpy().astype(np.float64).ravel(), err_msg=k)
     assert (got["OLR"] > 100).all() and (got["SFCEM"] > got["SFCEM_INT"]).all()      # a warmer surface emits more
+
+
+def test_fortran_dropin_rate_at_full_size(tmp_path, capsys):
+    """The drop-in path as a GEOS maintainer gets it: Fortran callers (lw_driver / sw_driver, default real, host arrays) on a C360 tile's
+    per-GPU share, 97 200 columns x 72 layers, cloudy with aerosols, three calls each - the caller-side time of one call includes
+    the transfers both ways.  Prints the times (INTEGRATION.md quotes them) and holds them to a loose bound."""
+    import re
+    from geosradiation_gridcomp_amd import synth
+    ncol, nlay, ih = 97_200, 72, 1
+    inp = synth.make_columns(ncol, nlay, start=0, aerosol=True, cloudy_frac=0.6)
+    env = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        np.array([ncol, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"])], dtype=np.int32).tofile(f)
+        for k in ORDER:
+            np.ascontiguousarray(inp[k], dtype=np.float32).tofile(f)
+    out = subprocess.run([os.path.join(FDIR, "bin", "lw_driver_r4"), str(fin), str(fout), "3"], env=env, check=True, capture_output=True, text=True).stdout
+    lw_ms = float(re.search(r"ms per call\s+([0-9.]+)", out).group(1))
+    flux = np.fromfile(fout, dtype=np.float64, count=(nlay + 1) * ncol).reshape(nlay + 1, ncol)
+    assert np.isfinite(flux).all() and (flux[0] > 100).all()          # upward flux at the surface
+    with open(fin, "wb") as f:
+        np.array([ncol, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]), 10, 1, 0], dtype=np.int32).tofile(f)
+        np.array([1361.0], dtype=np.float32).tofile(f)
+        for k in SW_ORDER:
+            np.ascontiguousarray(inp[k], dtype=np.float32).tofile(f)
+    out = subprocess.run([os.path.join(FDIR, "bin", "sw_driver_r4"), str(fin), str(fout), "3"], env=env, check=True, capture_output=True, text=True).stdout
+    sw_ms = float(re.search(r"ms per call\s+([0-9.]+)", out).group(1))
+    with capsys.disabled():
+        print(f"\nFortran drop-in, {ncol} columns x {nlay} layers, host arrays: rrtmg_lw {lw_ms:.1f} ms, rrtmg_sw {sw_ms:.1f} ms per call "
+              f"= {ncol / (lw_ms + sw_ms) * 1e3:.3g} columns/s for the pair")
+    assert lw_ms < 150 and sw_ms < 200
