@@ -1976,43 +1976,36 @@ template <typename R> struct Ctx : geosrad_ctx {
     int irrad_host(int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb, void *const *aer,
                    void *const *out) override
     {
+        // host arrays: pinned staging + chunk pipeline (host_pipeline), like rrtmg_lw / rrtmg_sw - transfers of a chunk overlap the
+        // kernels of its neighbours (irrad is 0.33 ms of kernels per 1 000 columns against 0.08 ms of transfers)
         HIPCHK(hipSetDevice(device));
         if (m <= 0 || np <= 0 || ns < 1 || nb < 1) return fail(GEOSRAD_EINVAL, "bad m/np/ns/nb");
-        const size_t cl = (size_t)m * np, cv = (size_t)m * (np + 1);
-        size_t insz[C_NIN];
-        for (int k = 0; k < C_NIN; k++) insz[k] = cl;
-        insz[C_PLE] = cv; insz[C_TB] = m; insz[C_CWC] = insz[C_REFF] = cl * 4; insz[C_FS] = insz[C_TG] = insz[C_TV] = (size_t)m * ns;
-        insz[C_EG] = insz[C_EV] = insz[C_RV] = (size_t)m * ns * 10;
-        size_t outsz[CO_NOUT];
-        for (int k = 0; k < CO_NOUT; k++) outsz[k] = cv;
-        outsz[CO_SFCEM] = m; outsz[CO_TAUDIAG] = cl * 10;
-        const size_t aersz = cl * nb;
-        size_t off = 0;
-        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
-        size_t ino[C_NIN], outo[CO_NOUT], aero[3];
-        for (int k = 0; k < C_NIN; k++) { if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array"); ino[k] = take(insz[k]); }
-        for (int k = 0; k < CO_NOUT; k++) { if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array"); outo[k] = take(outsz[k]); }
-        for (int k = 0; k < 3; k++) aero[k] = take(aersz);
-        int rc = ensure_io(off);
-        if (rc) return rc;
-        const void *din[C_NIN]; void *dout[CO_NOUT]; void *daer[3];
+        for (int k = 0; k < C_NIN; k++) if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array");
+        for (int k = 0; k < CO_NOUT; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
+        const size_t L = (size_t)np, E = sizeof(R);
+        std::vector<PipeArr> arrs;
+        int ix_in[C_NIN], ix_aer[3] = {-1, -1, -1}, ix_out[CO_NOUT];
         for (int k = 0; k < C_NIN; k++) {
-            din[k] = d_io + ino[k];
-            HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
+            const size_t rows = k == C_PLE ? L + 1 : k == C_TB ? 1 : (k == C_CWC || k == C_REFF) ? 4 * L
+                              : (k == C_FS || k == C_TG || k == C_TV) ? (size_t)ns : (k == C_EG || k == C_EV || k == C_RV) ? (size_t)ns * 10 : L;
+            ix_in[k] = (int)arrs.size(); arrs.push_back({in[k], nullptr, rows, E, 0});
         }
-        for (int k = 0; k < CO_NOUT; k++) dout[k] = d_io + outo[k];
-        for (int k = 0; k < 3; k++) {
-            daer[k] = (na > 0 && aer[k]) ? d_io + aero[k] : nullptr;
-            if (daer[k]) HIPCHK(hipMemcpyAsync(daer[k], aer[k], aersz * sizeof(R), hipMemcpyHostToDevice, stream));
+        for (int k = 0; k < 3; k++)
+            if (na > 0 && aer[k]) { ix_aer[k] = (int)arrs.size(); arrs.push_back({aer[k], aer[k], L * (size_t)nb, E, 0}); }      // rescaled in place
+        for (int k = 0; k < CO_NOUT; k++) {
+            const size_t rows = k == CO_SFCEM ? 1 : k == CO_TAUDIAG ? 10 * L : L + 1;
+            ix_out[k] = (int)arrs.size(); arrs.push_back({nullptr, out[k], rows, E, 0});
         }
-        rc = irrad_dev(stream, m, np, din, co2, trace, ict, icb, ns, na, nb, daer, dout);
+        auto run = [&](hipStream_t st, int nc, int, char *dev, int) -> int {
+            const void *din[C_NIN]; void *dout[CO_NOUT]; void *daer[3];
+            for (int k = 0; k < C_NIN; k++) din[k] = dev + arrs[ix_in[k]].off;
+            for (int k = 0; k < CO_NOUT; k++) dout[k] = dev + arrs[ix_out[k]].off;
+            for (int k = 0; k < 3; k++) daer[k] = ix_aer[k] >= 0 ? dev + arrs[ix_aer[k]].off : nullptr;
+            return irrad_dev(st, nc, np, din, co2, trace, ict, icb, ns, na, nb, daer, dout);
+        };
+        int rc = host_pipeline(m, arrs, run);
         if (rc) return rc;
-        rc = check(stream);
-        if (rc) return rc;
-        for (int k = 0; k < CO_NOUT; k++) HIPCHK(hipMemcpyAsync(out[k], dout[k], outsz[k] * sizeof(R), hipMemcpyDeviceToHost, stream));
-        for (int k = 0; k < 3; k++) if (daer[k]) HIPCHK(hipMemcpyAsync(aer[k], daer[k], aersz * sizeof(R), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        return GEOSRAD_OK;
+        return check(stream);
     }
 
 
@@ -2123,41 +2116,34 @@ template <typename R> struct Ctx : geosrad_ctx {
     int sorad_host(int m, int np, int nb, const void *const *in, double co2, int ict, int icb, const void *hk_uv, const void *hk_ir,
                    void *const *out, int do_drfband) override
     {
+        // host arrays: pinned staging + chunk pipeline (host_pipeline)
         HIPCHK(hipSetDevice(device));
         if (m <= 0 || np <= 0 || nb < 1) return fail(GEOSRAD_EINVAL, "bad m/np/nb");
-        const size_t cl = (size_t)m * np, cv = (size_t)m * (np + 1);
-        size_t insz[SI_NIN];
-        for (int k = 0; k < SI_NIN; k++) insz[k] = cl;
-        insz[SI_COSZ] = insz[SI_RSUVBM] = insz[SI_RSUVDF] = insz[SI_RSIRBM] = insz[SI_RSIRDF] = m; insz[SI_PL] = cv;
-        insz[SI_CWC] = insz[SI_REFF] = cl * 4; insz[SI_TAUA] = insz[SI_SSAA] = insz[SI_ASYA] = cl * nb;
-        size_t outsz[SOO_NOUT];
-        for (int k = 0; k < SOO_NOUT; k++) outsz[k] = m;
-        outsz[SOO_FLX] = outsz[SOO_FLC] = outsz[SOO_FLXU] = outsz[SOO_FLCU] = cv;
-        outsz[SOO_SFCBAND] = outsz[SOO_DRBAND] = outsz[SOO_DFBAND] = (size_t)m * 8;
-        size_t off = 0;
-        auto take = [&](size_t nreal) { size_t o = off; off += al(nreal * sizeof(R)); return o; };
-        size_t ino[SI_NIN], outo[SOO_NOUT];
-        for (int k = 0; k < SI_NIN; k++) { if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array"); ino[k] = take(insz[k]); }
-        for (int k = 0; k < SOO_NOUT; k++) outo[k] = take(outsz[k]);
-        int rc = ensure_io(off);
-        if (rc) return rc;
-        const void *din[SI_NIN]; void *dout[SOO_NOUT];
+        for (int k = 0; k < SI_NIN; k++) if (!in[k]) return fail(GEOSRAD_EINVAL, "null input array");
+        const size_t L = (size_t)np, E = sizeof(R);
+        std::vector<PipeArr> arrs;
+        int ix_in[SI_NIN], ix_out[SOO_NOUT];
         for (int k = 0; k < SI_NIN; k++) {
-            din[k] = d_io + ino[k];
-            HIPCHK(hipMemcpyAsync(d_io + ino[k], in[k], insz[k] * sizeof(R), hipMemcpyHostToDevice, stream));
+            const size_t rows = (k == SI_COSZ || k == SI_RSUVBM || k == SI_RSUVDF || k == SI_RSIRBM || k == SI_RSIRDF) ? 1 : k == SI_PL ? L + 1
+                              : (k == SI_CWC || k == SI_REFF) ? 4 * L : (k == SI_TAUA || k == SI_SSAA || k == SI_ASYA) ? L * (size_t)nb : L;
+            ix_in[k] = (int)arrs.size(); arrs.push_back({in[k], nullptr, rows, E, 0});
         }
-        for (int k = 0; k < SOO_NOUT; k++) dout[k] = d_io + outo[k];
-        rc = sorad_dev(stream, m, np, nb, din, co2, ict, icb, hk_uv, hk_ir, dout, do_drfband);
-        if (rc) return rc;
-        rc = check(stream);
-        if (rc) return rc;
         for (int k = 0; k < SOO_NOUT; k++) {
-            if (!out[k]) continue;
-            if ((k == SOO_DRBAND || k == SOO_DFBAND) && !do_drfband) continue;
-            HIPCHK(hipMemcpyAsync(out[k], dout[k], outsz[k] * sizeof(R), hipMemcpyDeviceToHost, stream));
+            const size_t rows = (k == SOO_FLX || k == SOO_FLC || k == SOO_FLXU || k == SOO_FLCU) ? L + 1
+                              : (k == SOO_SFCBAND || k == SOO_DRBAND || k == SOO_DFBAND) ? 8 : 1;
+            // an output the caller does not take (or drband / dfband without do_drfband) still has its place on the device
+            void *dst = ((k == SOO_DRBAND || k == SOO_DFBAND) && !do_drfband) ? nullptr : out[k];
+            ix_out[k] = (int)arrs.size(); arrs.push_back({nullptr, dst, rows, E, 0});
         }
-        HIPCHK(hipStreamSynchronize(stream));
-        return GEOSRAD_OK;
+        auto run = [&](hipStream_t st, int nc, int, char *dev, int) -> int {
+            const void *din[SI_NIN]; void *dout[SOO_NOUT];
+            for (int k = 0; k < SI_NIN; k++) din[k] = dev + arrs[ix_in[k]].off;
+            for (int k = 0; k < SOO_NOUT; k++) dout[k] = dev + arrs[ix_out[k]].off;
+            return sorad_dev(st, nc, np, nb, din, co2, ict, icb, hk_uv, hk_ir, dout, do_drfband);
+        };
+        int rc = host_pipeline(m, arrs, run);
+        if (rc) return rc;
+        return check(stream);
     }
 
     // ---- stand-alone McICA generator ---------------------------------------------------------------------------------
