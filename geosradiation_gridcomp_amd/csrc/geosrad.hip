@@ -720,7 +720,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + ws_drvs_bytes[0] + ws_drvs_bytes[1] + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
-    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; R2 *s1, *s2; R *part; };
+    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; uint16_t *s1, *s2; R *part; };
     static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t ws_layout(int nc, int nlay, Ws *w, char *base) const
     {
@@ -740,8 +740,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(NG_LW * cl * sizeof(R)); if (w) w->taucmc = (R *)p;
         const size_t clp = (size_t)nlay * (((size_t)nc + 255) & ~(size_t)255);      // tiled by 256-column block
         // parked cells of the band sweeps: a 2-byte Pade index per (layer, g-point) and stream (lw_kernels.hpp band_body)
-        p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s1 = (R2 *)p;
-        p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s2 = (R2 *)p;
+        p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s1 = (uint16_t *)p;
+        p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s2 = (uint16_t *)p;
         p = take((size_t)6 * NB_LW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
         return off;
     }

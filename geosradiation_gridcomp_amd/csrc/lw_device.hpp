@@ -87,8 +87,8 @@ template <typename R> struct LwArgs {
     uint8_t *laycloudy;          // [nlay][ncol]  optically cloudy for ANY g-point (cldprmc's `cloudy`)
     R *taucmc;                   // [140][nlay][ncol]
     R *alpha, *rcorr;            // [nlay][ncol] inter-layer overlap correlations (cloud_subcol_gen.F90:314-321)
-    typename Vec2<R>::T *s1;     // [140][nlay][ncol] parked cells of the total-sky stream: uint16 Pade indices (typed as pairs for the
-    typename Vec2<R>::T *s2;     //                   -DGEOSRAD_LW_PARK_PAIRS build); s2: the clear-sky stream of cloudy columns
+    uint16_t *s1;                // [140][nlay][ncol] parked cells of the total-sky stream: the Pade index of the cell's discretised optical depth
+    uint16_t *s2;                //                   s2: the clear-sky stream of cloudy columns
     R *part;                     // [6][16][nlay+1][ncol] per-band partial fluxes: dflx,dflxc,uflx,uflxc,duflx,duflxc
     uint32_t *err;               // error bit mask
     R *dbg_taug, *dbg_pfracs;    // optional Fortran (nlay,140,ncol) dumps (nullptr in production)

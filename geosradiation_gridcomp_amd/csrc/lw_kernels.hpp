@@ -311,14 +311,6 @@ template <typename R, int W> GR_DEV void ldw(const R *__restrict__ tab, uint32_t
 // byte offset of row r (0-based) of a [rows][S] table, columns go..go+W-1
 #define ROWB(r) (((uint32_t)(r) * (uint32_t)S + (uint32_t)go) * (uint32_t)sizeof(R))
 
-// Wide evaluations (W > 4: k_lw_cols fetches half or whole rows per lane) must not have the rows of ALL their terms in flight at once
-// (22 rows x W registers): a compiler-level fence after each multi-row term keeps at most one term's rows outstanding.
-template <int W> GR_DEV void row_fence()
-{
-#ifdef LWC_ROW_FENCE
-    if constexpr (W > 4) asm volatile("" ::: "memory");
-#endif
-}
 template <typename R, int W, int S, bool INIT> GR_DEV void axw(R (&acc)[W], R c, const R *__restrict__ tab, int row, int go)
 {
     R r[W];
@@ -341,7 +333,6 @@ template <typename R, int W, int S> GR_DEV void add_linw(R (&acc)[W], R s, R f, 
     linw<R, W, S>(t, f, tab, row, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = acc[j] + s * t[j];
-    row_fence<W>();
 }
 // minor gas on a (species parameter, T) grid, rows [indm][jm], NSP species rows per T (e.g. :546-551)
 template <typename R, int W, int S, int NSP>
@@ -352,7 +343,6 @@ GR_DEV void minor2w(R (&o)[W], const R *__restrict__ tab, int jm, int indm, R fm
     linw<R, W, S>(m2, fm, tab, indm * NSP + (jm - 1), go);
 #pragma unroll
     for (int j = 0; j < W; j++) o[j] = m1[j] + minorfrac * (m2[j] - m1[j]);
-    row_fence<W>();
 }
 
 // binary-species parameter (e.g. LW/rrtmg_lw_taumol.F90:435-441) with the interpolation weights of the
@@ -397,7 +387,6 @@ GR_DEV void major_a(R (&acc)[W], const R *__restrict__ absa, int ind, const Spec
     if (sp.edge) axw<R, W, S, false>(t, sp.c2 * facB, absa, base + 11, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = INIT ? sp.speccomb * t[j] : acc[j] + sp.speccomb * t[j];
-    row_fence<W>();
 }
 // upper-atmosphere binary side, 5 species rows, always linear (e.g. :706-716)
 template <typename R, int W, int S, bool INIT>
@@ -411,7 +400,6 @@ GR_DEV void major_b5(R (&acc)[W], const R *__restrict__ absb, int ind, const Spe
     axw<R, W, S, false>(t, c1 * facB, absb, ind + 5, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = INIT ? sp.speccomb * t[j] : acc[j] + sp.speccomb * t[j];
-    row_fence<W>();
 }
 // single key species: col * 4-point (p,T) interpolation (e.g. :240-244); ind0/ind1 1-based
 template <typename R, int W, int S>
@@ -424,7 +412,6 @@ GR_DEV void major1(R (&acc)[W], const R *__restrict__ tab, int ind0, int ind1, c
     axw<R, W, S, false>(t, L.fac11, tab, ind1, go);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = col * t[j];
-    row_fence<W>();
 }
 // "too much of a minor gas" column adjustment (e.g. :461-468)
 template <typename R> GR_DEV R adjcol(R colx, R coldry, R chiref, R thresh, R a, R pw)
@@ -1091,22 +1078,12 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     const uint32_t npad = ((uint32_t)n + 255u) & ~255u;
     // what is parked per cell between the sweeps: the Pade index of the cell's discretised optical depth, 2 bytes - the up sweep
     // re-forms (absorptivity, source) from it: table look-up + the layer's Planck terms + the Planck fraction, which is re-evaluated
-    // there (a quarter of the bytes of the (a, B-up) pair the first version parked; -DGEOSRAD_LW_PARK_PAIRS builds that version)
-#ifdef GEOSRAD_LW_PARK_PAIRS
-    using PK = R2;
-#define LW_PK(a_, bbu_, it_) R2{(a_), (bbu_)}
-#else
+    // there (a quarter of the bytes of the (a, B-up) pair the first version parked)
     using PK = uint16_t;
-#define LW_PK(a_, bbu_, it_) ((uint16_t)(it_))
-#endif
-    PK *const s1_b = reinterpret_cast<PK *>(A.s1) + (size_t)G0 * nlay * npad;
-    PK *const s2_b = reinterpret_cast<PK *>(A.s2) + (size_t)G0 * nlay * npad;
+    PK *const s1_b = A.s1 + (size_t)G0 * nlay * npad;
+    PK *const s2_b = A.s2 + (size_t)G0 * nlay * npad;
     const uint32_t tbase = (ucol >> 8) * (uint32_t)nlay * (uint32_t)NG * 256u + (ucol & 255u);
-#ifdef GEOSRAD_LW_NOTILE
-#define SCELL(lay, g) (((uint32_t)(lay) * (uint32_t)NG + (uint32_t)(g)) * (uint32_t)npad + ucol)
-#else
 #define SCELL(lay, g) (tbase + ((uint32_t)(lay) * (uint32_t)NG + (uint32_t)(g)) * 256u)
-#endif
     const size_t qs = (size_t)NB_LW * (nlay + 1) * n;                     // one flux kind of `part`
     R *const part = A.part + (size_t)(IB - 1) * (nlay + 1) * n;           // [(kind*qs) + lev*n + col]
 #define PART(kind, lev, val) stg(part + (size_t)(kind) * qs + (size_t)(lev) * n, cb, (R)(val))
@@ -1223,14 +1200,14 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     }
                 }
                 if (!cldcell) rad[g] = radprev + (bbdgas - radprev) * agas;
-                if (DEFER) { pend1[j] = LW_PK(atot, bbutot, itp); poff[j] = scell; npend = j + 1; }
-                else stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(atot, bbutot, itp));
+                if (DEFER) { pend1[j] = (PK)(itp); poff[j] = scell; npend = j + 1; }
+                else stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)(itp));
                 dsum = dsum + sumfac * rad[g];
                 if (CLD && ccol) {
                     if (diverge) {
                         radc[g] = radc[g] + (bbdgas - radc[g]) * agas;
-                        if (DEFER) { pend2[j] = LW_PK(agas, bbugas, itgas); pmask2 |= 1u << j; }
-                        else stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(agas, bbugas, itgas));
+                        if (DEFER) { pend2[j] = (PK)(itgas); pmask2 |= 1u << j; }
+                        else stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)(itgas));
                     } else {
                         radc[g] = rad[g];
                     }
@@ -1322,12 +1299,12 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     atot = cld ? ac : agas; bbutot = cld ? bbut : bbugas; bbd = cld ? bbdtot : bbdgas;
                 }
                 rad[g] = rad[g] + (bbd - rad[g]) * atot;
-                stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(atot, bbutot, itp));
+                stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)(itp));
                 dsum = dsum + sumfac * rad[g];
                 if (CLD) {
                     const R rc = radc[g] + (bbdgas - radc[g]) * agas;
                     radc[g] = diverge ? rc : rad[g];
-                    if (wdv) stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)LW_PK(agas, bbugas, itg[j]));
+                    if (wdv) stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)(itg[j]));
                     dcsum = dcsum + sumfac * radc[g];
                 }
                 if (lay == 0) {
@@ -1386,23 +1363,6 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
             for (int g = 0; g < NG; g++) sg[g] = sv[g];
         }
         const bool own = CLD && ccol && diverge && lay <= ltop;      // above ltop the layer is clear for every g-point: gas == total
-#ifdef GEOSRAD_LW_PARK_PAIRS
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            rad[g] = rad[g] + (sv[g].y - rad[g]) * sv[g].x;
-            dlu[g] = dlu[g] - dlu[g] * sv[g].x;
-            usum = usum + sumfac * rad[g];
-            dusum = dusum + sumfac * dlu[g];
-            if (CLD) {
-                const R gx = own ? sg[g].x : sv[g].x, gy = own ? sg[g].y : sv[g].y;
-                const R rc = radc[g] + (gy - radc[g]) * gx, dc = dclu[g] - dclu[g] * gx;
-                radc[g] = diverge ? rc : rad[g];
-                dclu[g] = diverge ? dc : dlu[g];
-                ucsum = ucsum + sumfac * radc[g];
-                ducsum = ducsum + sumfac * dclu[g];
-            }
-        }
-#else
         // (absorptivity, upward source) of the cell from its parked index: the transmittance table, the layer's Planck terms and
         // the Planck fraction, which the band body evaluates again (its optical-depth terms are dead code here)
         Layer<R> L;
@@ -1436,12 +1396,10 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 }
             }
         }
-#endif
         PART(2, lay + 1, usum);
         if (CLD && ccol) PART(3, lay + 1, ucsum);
         if (dudTs) { PART(4, lay + 1, dusum); if (CLD && ccol) PART(5, lay + 1, ducsum); }
     }
-#undef LW_PK
 #undef PART
 }
 

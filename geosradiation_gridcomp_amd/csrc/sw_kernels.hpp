@@ -582,13 +582,8 @@ GR_DEV void sw_band_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R>
     const uint32_t tbase = (ucol >> 8) * (uint32_t)nlay * (uint32_t)NG * 256u + (ucol & 255u);
     const R *const tcb = A.taucmc + bandoff, *const ocb = A.ssacmc + bandoff, *const gcb = A.asmcmc + bandoff;
 #define CELL(q) (cellb + (size_t)(q) * plane)
-#ifdef SW_EXP_NOPARK      // experiment: the arithmetic of both sweeps without the parked-cell traffic (results are wrong)
-#define PST(q, off, v) ((void)0)
-#define PLD(q, off) (prmu0 * (R)0.5)
-#else
 #define PST(q, off, v) stg_nt(CELL(q), off, v)
 #define PLD(q, off) ldg_nt(CELL(q), off)
-#endif
 #define CT4(lay_, g_) ((tbase + ((uint32_t)(lay_) * (uint32_t)NG + (uint32_t)(g_)) * 256u) * (uint32_t)sizeof(R))
 
     // ---- sweep A: surface -> TOA -----------------------------------------------------------------------
