@@ -2054,13 +2054,13 @@ template <typename R> struct Ctx : geosrad_ctx {
         const int K2 = np + 2;
         const int nc_max = m < chunk ? m : chunk;
         const size_t per = (size_t)nc_max * sizeof(R);
-        // passes: k_sorad_pass (lane = column, the per-level arrays of every pass in HBM scratch planes, 34 x K2 reals per (column, pass))
+        // passes: k_sorad_pass (lane = column, the per-level arrays of every pass in HBM scratch planes, 30 x K2 reals per (column, pass))
         // or k_sorad_col (one block per column, everything on chip, no scratch; GEOSRAD_SORAD_PATH=col)
         // (a layer count whose on-chip arrays exceed the LDS takes the scratch-plane path)
         const bool col_path = sorad_col_path && K2 <= 256 && sorad_col_lds_reals<R>(np) * sizeof(R) <= (size_t)160 * 1024;
         const size_t o_lay = 0, o_swh = o_lay + al(4 * K2 * per), o_colv = o_swh + al(K2 * per), o_cld = o_colv + al(8 * per),
                      o_psum = o_cld + al((size_t)SO_NGRP * 4 * K2 * per), o_scr = o_psum + al((size_t)SO_NPASS * 3 * per),
-                     need = o_scr + (col_path ? 0 : al((size_t)SO_NPASS * 34 * K2 * per));
+                     need = o_scr + (col_path ? 0 : al((size_t)SO_NPASS * SO_NPLANE * K2 * per));
         const size_t so_lds = sorad_col_lds_reals<R>(np) * sizeof(R);
         if (col_path) {
             if (so_lds > so_lds_set) {

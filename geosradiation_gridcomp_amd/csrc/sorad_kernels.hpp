@@ -18,6 +18,7 @@
 namespace geosrad {
 
 constexpr int SO_NPASS = 35;      // 5 + 3 * 10
+constexpr int SO_NPLANE = 30;     // scratch planes of a pass in k_sorad_pass
 constexpr int SO_NGRP = 4;        // cloud optics groups: 0 = UV/PAR, 1..3 = NIR bands
 
 template <typename R> struct SoradDev {
@@ -37,7 +38,7 @@ template <typename R> struct SoradArgs {
     R *swh;          // [K2][m]    cumulative scaled water vapour (index k = 1..np+1)
     R *colv;         // [8][m]: cc1, cc2, cc3, wvtoa, o3toa, scal0, ntop (as real), spare
     R *cld;          // [SO_NGRP][4][K2][m]: tauclb, tauclf, asycl, ssacl
-    R *scr;          // [SO_NPASS][34][K2][m]: per-pass planes of k_sorad_pass (null on the k_sorad_col path)
+    R *scr;          // [SO_NPASS][SO_NPLANE][K2][m]: per-pass planes of k_sorad_pass (null on the k_sorad_col path)
     R *psum;         // [SO_NPASS][3][m]: fsdir, fsdif and the all-sky net flux at the surface of the pass
 };
 template <typename R> struct SoradOut { R *flx, *flc, *fdiruv, *fdifuv, *fdirpar, *fdifpar, *fdirir, *fdifir, *flxu, *flcu, *flx_sfc_band, *drband, *dfband; };
@@ -216,9 +217,8 @@ __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const Sorad
 // k_sorad_pass: one thread per (column, spectral pass).  Scratch planes of the pass (index q, level k):
 //   0..9  : rr, tt, td, rs, ts of the clear (q = 2 f) and cloudy (q = 2 f + 1) portion of layer k (k = 0 above the model top,
 //           np+1 = surface)
-//   10..21: tda, tta, rsa (ih, im) composites from the top       q = 10 + 4 f + 2 (ih-1) + (im-1)
-//   22..29: rra, rxa (im, is) composites from the surface        q = 22 + 4 f + 2 (im-1) + (is-1)
-//   30..33: fall, fclr, fupa, fupc
+//   10..25: rra, rxa composites from the surface of the sky situations' variants at the level (q = 10 + 2 v, 11 + 2 v; see CLDFLX below)
+//   26..29: fall, fclr, fupa, fupc
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp)
@@ -235,14 +235,9 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
     const R cz = A.cosz[i], dsm = (R)0.602;
     const R cc1 = A.colv[0 * (size_t)m + i], cc2 = A.colv[1 * (size_t)m + i], cc3 = A.colv[2 * (size_t)m + i];
     const R wvtoa = A.colv[3 * (size_t)m + i], o3toa = A.colv[4 * (size_t)m + i];
-    R *S = A.scr + (size_t)pass * 34 * K2 * m + i;
+    R *S = A.scr + (size_t)pass * SO_NPLANE * K2 * m + i;
 #define P(q, k) S[((size_t)(q) * K2 + (k)) * m]
 #define LY(f, j, k) P(2 * (f) + (j) - 1, k)              // f: 0 rr 1 tt 2 td 3 rs 4 ts;  j: 1 clear, 2 cloudy
-#define TDA(k, a, b) P(10 + 2 * ((a) - 1) + (b) - 1, k)
-#define TTA(k, a, b) P(14 + 2 * ((a) - 1) + (b) - 1, k)
-#define RSA(k, a, b) P(18 + 2 * ((a) - 1) + (b) - 1, k)
-#define RRA(k, a, b) P(22 + 2 * ((a) - 1) + (b) - 1, k)
-#define RXA(k, a, b) P(26 + 2 * ((a) - 1) + (b) - 1, k)
     // The sweeps below are first-order recurrences over the levels: each step loads a layer's five properties and stores the new
     // composites.  gfx9 tracks loads and stores with one in-order counter, so a load issued after a store cannot be consumed before
     // that store is acknowledged: every sweep therefore requests the NEXT level's properties before it stores the current results.
@@ -309,141 +304,116 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         }
     }
 
-    // ---- CLDFLX (:689-872): composites from the top over the high and middle groups ---------------------------------------
+    // ---- CLDFLX (:689-872) ---------------------------------------------------------------------------------------------
+    // The reference builds the composites piecewise (from the top through the high group per ih, on through the middle group per
+    // (ih, im), ...) and re-walks the low / high groups for every sky situation.  Here every sky situation of non-zero weight
+    // s = (ih, im, is) is ONE chain each way over all levels - the same operations on the same values in the same order, so the same
+    // bits - and the level is the outer loop:
+    //   sweep U (surface -> top): the composites from the surface (rra, rxa) of all situations, parked per level.  Situations that
+    //     share the portions below a level share the values: 2 variants in the low group, 4 in the middle, 8 in the high group are
+    //     stored (planes 10 + 2 v, 11 + 2 v).
+    //   sweep D (top -> surface): the composites from the top (tda, tta, rsa) stay in registers; at every level the fluxes of all
+    //     situations are formed and summed in the reference's order (ih, im, is); the four flux planes are written once.
+    // Per level and pass: 10 + 4..16 loads and 4..16 stores in U, 10 + 4..16 loads and 4 stores in D - the first version, which walked
+    // situation by situation, read ~80 and wrote ~48 values per level (profiles/r01_v7_chou_pmc_traffic.md: 138 x the algorithmic bytes).
     const int nh = cc1 > 0 ? 2 : 1, nm = cc2 > 0 ? 2 : 1, ns = cc3 > 0 ? 2 : 1;       // portions of non-zero weight
-    for (int ih = 1; ih <= nh; ih++) {
-        R tda = LY(2, ih, 0), tta = LY(1, ih, 0), rsa = LY(3, ih, 0);
-        // (ih, 2) copies feed the cloudy middle portion only
-        TDA(0, ih, 1) = tda; TTA(0, ih, 1) = tta; RSA(0, ih, 1) = rsa;
-        if (nm == 2) { TDA(0, ih, 2) = tda; TTA(0, ih, 2) = tta; RSA(0, ih, 2) = rsa; }
-        L5 nx = ld5(ih, 1);
-        for (int k = 1; k <= ict - 1; k++) {
-            const L5 c = nx;
-            if (k + 1 <= ict - 1) nx = ld5(ih, k + 1);
-            const R rr = c.rr, tt = c.tt, td = c.td, rs = c.rs, ts = c.ts;
-            const R denm = ts / ((R)1. - rsa * rs);
-            const R ntta = tda * tt + (tda * rsa * rr + tta - tda) * denm;
-            const R nrsa = rs + ts * rsa * denm;
-            tda = tda * td; tta = ntta; rsa = nrsa;
-            TDA(k, ih, 1) = tda; TTA(k, ih, 1) = tta; RSA(k, ih, 1) = rsa;
-            if (nm == 2) { TDA(k, ih, 2) = tda; TTA(k, ih, 2) = tta; RSA(k, ih, 2) = rsa; }
-        }
-        for (int im = 1; im <= nm; im++) {
-            R a = TDA(ict - 1, ih, im), b = TTA(ict - 1, ih, im), c = RSA(ict - 1, ih, im);
-            L5 nx = ld5(im, ict);
-            for (int k = ict; k <= icb - 1; k++) {
-                const L5 l = nx;
-                if (k + 1 <= icb - 1) nx = ld5(im, k + 1);
-                const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
-                const R denm = ts / ((R)1. - c * rs);
-                const R nb = a * tt + (a * c * rr + b - a) * denm;
-                const R nc = rs + ts * c * denm;
-                a = a * td; b = nb; c = nc;
-                TDA(k, ih, im) = a; TTA(k, ih, im) = b; RSA(k, ih, im) = c;
+    // situation s = 4 (ih-1) + 2 (im-1) + (is-1); the portion it uses in layer k; the variant of its surface-side composites at level k
+    auto portion = [&](int s, int k) { return 1 + (k < ict ? (s >> 2) : (k < icb ? ((s >> 1) & 1) : (s & 1))); };
+    auto variant = [&](int s, int k) { return k < ict ? s : (k < icb ? (s & 3) : (s & 1)); };
+    uint32_t act = 0;
+    for (int ih = 1; ih <= nh; ih++) for (int im = 1; im <= nm; im++) for (int is = 1; is <= ns; is++) act |= 1u << (4 * (ih - 1) + 2 * (im - 1) + (is - 1));
+#define RRAV(k, v) P(10 + 2 * (v), k)
+#define RXAV(k, v) P(11 + 2 * (v), k)
+    // ---- sweep U ----
+    {
+        R rra[8], rxa[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { rra[s] = 0; rxa[s] = 0; }
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            if ((act >> s) & 1u) { rra[s] = LY(0, 1 + (s & 1), np + 1); rxa[s] = LY(3, 1 + (s & 1), np + 1); }
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+            if ((act >> v) & 1u) { RRAV(np + 1, v) = rra[v]; RXAV(np + 1, v) = rxa[v]; }
+        L5 n1 = ld5(1, np), n2 = ld5(2, np);
+        for (int k = np; k >= 1; k--) {
+            const L5 l1 = n1, l2 = n2;
+            if (k - 1 >= 1) { n1 = ld5(1, k - 1); n2 = ld5(2, k - 1); }      // (before this level's stores: in-order memory counter)
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                if (!((act >> s) & 1u)) continue;
+                const L5 &l = portion(s, k) == 1 ? l1 : l2;
+                const R denm = l.ts / ((R)1. - l.rs * rxa[s]);
+                const R nrra = l.rr + (l.td * rra[s] + (l.tt - l.td) * rxa[s]) * denm;
+                rxa[s] = l.rs + l.ts * rxa[s] * denm; rra[s] = nrra;
             }
+            const int nv = k < ict ? 8 : (k < icb ? 4 : 2);
+#pragma unroll
+            for (int v = 0; v < 8; v++)
+                if (v < nv && ((act >> v) & 1u)) { RRAV(k, v) = rra[v]; RXAV(k, v) = rxa[v]; }
         }
     }
-    // composites from the surface over the low and middle groups
-    for (int is = 1; is <= ns; is++) {
-        R rra = LY(0, is, np + 1), rxa = LY(3, is, np + 1);
-        RRA(np + 1, 1, is) = rra; RXA(np + 1, 1, is) = rxa;
-        if (nm == 2) { RRA(np + 1, 2, is) = rra; RXA(np + 1, 2, is) = rxa; }
-        L5 nx = ld5(is, np);
-        for (int k = np; k >= icb; k--) {
-            const L5 l = nx;
-            if (k - 1 >= icb) nx = ld5(is, k - 1);
-            const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
-            const R denm = ts / ((R)1. - rs * rxa);
-            const R nrra = rr + (td * rra + (tt - td) * rxa) * denm;
-            rxa = rs + ts * rxa * denm; rra = nrra;
-            RRA(k, 1, is) = rra; RXA(k, 1, is) = rxa;
-            if (nm == 2) { RRA(k, 2, is) = rra; RXA(k, 2, is) = rxa; }
-        }
-        for (int im = 1; im <= nm; im++) {
-            R a = RRA(icb, im, is), b = RXA(icb, im, is);
-            L5 nx = ld5(im, icb - 1);
-            for (int k = icb - 1; k >= ict; k--) {
-                const L5 l = nx;
-                if (k - 1 >= ict) nx = ld5(im, k - 1);
-                const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
-                const R denm = ts / ((R)1. - rs * b);
-                const R na = rr + (td * a + (tt - td) * b) * denm;
-                b = rs + ts * b * denm; a = na;
-                RRA(k, im, is) = a; RXA(k, im, is) = b;
+    // ---- sweep D ----
+    R fsdir = 0, fsdif = 0, fall_sfc = 0;
+    {
+        R tda[8], tta[8], rsa[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { tda[s] = 0; tta[s] = 0; rsa[s] = 0; }
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            if ((act >> s) & 1u) { const int j = 1 + (s >> 2); tda[s] = LY(2, j, 0); tta[s] = LY(1, j, 0); rsa[s] = LY(3, j, 0); }
+        for (int k = 1; k <= np + 1; k++) {
+            // everything this level needs is requested before anything is stored
+            L5 l1{}, l2{};
+            if (k <= np) { l1 = ld5(1, k); l2 = ld5(2, k); }
+            const int nv = k < ict ? 8 : (k < icb ? 4 : 2);
+            R bra[8], bxa[8];
+#pragma unroll
+            for (int v = 0; v < 8; v++) { bra[v] = 0; bxa[v] = 0; if (v < nv && ((act >> v) & 1u)) { bra[v] = RRAV(k, v); bxa[v] = RXAV(k, v); } }
+            R fall = 0, fclr = 0, fupa = 0, fupc = 0;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {      // the reference's order: ih outermost, is innermost
+                if (!((act >> s) & 1u)) continue;
+                const R ch = (s >> 2) ? cc1 : (R)1.0 - cc1;
+                const R cm = ((s >> 1) & 1) ? ch * cc2 : ch * ((R)1.0 - cc2);
+                const R ct = (s & 1) ? cm * cc3 : cm * ((R)1.0 - cc3);
+                const int v = variant(s, k);
+                const R rra = bra[v], rxa = bxa[v];
+                const R denm = (R)1. / ((R)1. - rsa[s] * rxa);
+                const R fdndir = tda[s];
+                const R xx4 = tda[s] * rra, yy = tta[s] - tda[s];
+                const R fdndif = (xx4 * rsa[s] + yy) * denm;
+                const R fupdif = (xx4 + yy * rxa) * denm;
+                const R flxdn = fdndir + fdndif - fupdif;
+                // the first sky situation (all-clear portions) starts the weighted sums: 0 + x * ct, as the reference's zeroed arrays give
+                if (s == 0) { fupc = fupdif; fclr = flxdn; fupa = (R)0 + fupdif * ct; fall = (R)0 + flxdn * ct; }
+                else { fupa = fupa + fupdif * ct; fall = fall + flxdn * ct; }
+                if (k == np + 1) { fsdir = fsdir + fdndir * ct; fsdif = fsdif + fdndif * ct; }
             }
-        }
-    }
-    // integration over the sky situations of non-zero weight
-    R fsdir = 0, fsdif = 0;
-    for (int ih = 1; ih <= nh; ih++) {
-        const R ch = ih == 1 ? (R)1.0 - cc1 : cc1;
-        for (int im = 1; im <= nm; im++) {
-            const R cm = im == 1 ? ch * ((R)1.0 - cc2) : ch * cc2;
-            for (int is = 1; is <= ns; is++) {
-                const R ct = is == 1 ? cm * ((R)1.0 - cc3) : cm * cc3;
-                {   // add one layer at a time, going down through the low group
-                    R a = TDA(icb - 1, ih, im), b = TTA(icb - 1, ih, im), c = RSA(icb - 1, ih, im);
-                    L5 nx = ld5(is, icb);
-                    for (int k = icb; k <= np; k++) {
-                        const L5 l = nx;
-                        if (k + 1 <= np) nx = ld5(is, k + 1);
-                        const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
-                        const R denm = ts / ((R)1. - c * rs);
-                        const R nb = a * tt + (a * rr * c + b - a) * denm;
-                        const R nc = rs + ts * c * denm;
-                        a = a * td; b = nb; c = nc;
-                        TDA(k, ih, im) = a; TTA(k, ih, im) = b; RSA(k, ih, im) = c;
-                    }
+            P(26, k) = fall; P(27, k) = fclr; P(28, k) = fupa; P(29, k) = fupc;
+            if (k == np + 1) fall_sfc = fall;
+            if (k <= np) {
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    if (!((act >> s) & 1u)) continue;
+                    const L5 &l = portion(s, k) == 1 ? l1 : l2;
+                    const R denm = l.ts / ((R)1. - rsa[s] * l.rs);
+                    // (the reference writes the product in this term as tda * rsa * rr above the low group and tda * rr * rsa inside it)
+                    const R ntta = k < icb ? tda[s] * l.tt + (tda[s] * rsa[s] * l.rr + tta[s] - tda[s]) * denm
+                                           : tda[s] * l.tt + (tda[s] * l.rr * rsa[s] + tta[s] - tda[s]) * denm;
+                    const R nrsa = l.rs + l.ts * rsa[s] * denm;
+                    tda[s] = tda[s] * l.td; tta[s] = ntta; rsa[s] = nrsa;
                 }
-                {   // going up through the high group
-                    R a = RRA(ict, im, is), b = RXA(ict, im, is);
-                    L5 nx = ld5(ih, ict - 1);
-                    for (int k = ict - 1; k >= 0; k--) {
-                        const L5 l = nx;
-                        if (k - 1 >= 0) nx = ld5(ih, k - 1);
-                        const R rr = l.rr, tt = l.tt, td = l.td, rs = l.rs, ts = l.ts;
-                        const R denm = ts / ((R)1. - rs * b);
-                        const R na = rr + (td * a + (tt - td) * b) * denm;
-                        b = rs + ts * b * denm; a = na;
-                        RRA(k, im, is) = a; RXA(k, im, is) = b;
-                    }
-                }
-                R fdndir = 0, fdndif = 0;
-                const bool first = ih == 1 && im == 1 && is == 1;
-                auto ldf = [&](int k) { L5 l; l.rr = TDA(k - 1, ih, im); l.tt = TTA(k - 1, ih, im); l.td = RSA(k - 1, ih, im); l.rs = RRA(k, im, is); l.ts = RXA(k, im, is); return l; };
-                L5 nx = ldf(1);
-                R a32 = 0, a30 = 0;
-                if (!first) { a32 = P(32, 1); a30 = P(30, 1); }
-                for (int k = 1; k <= np + 1; k++) {      // Eqs. (6.15), (6.16)
-                    const L5 l = nx;
-                    const R p32 = a32, p30 = a30;
-                    if (k + 1 <= np + 1) { nx = ldf(k + 1); if (!first) { a32 = P(32, k + 1); a30 = P(30, k + 1); } }
-                    const R tda = l.rr, tta = l.tt, rsa = l.td, rra = l.rs, rxa = l.ts;
-                    const R denm = (R)1. / ((R)1. - rsa * rxa);
-                    fdndir = tda;
-                    const R xx4 = tda * rra, yy = tta - tda;
-                    fdndif = (xx4 * rsa + yy) * denm;
-                    const R fupdif = (xx4 + yy * rxa) * denm;
-                    const R flxdn = fdndir + fdndif - fupdif;
-                    // the first sky situation (all-clear portions) starts the weighted sums: 0 + x * ct, as the reference's zeroed arrays give
-                    if (first) { P(33, k) = fupdif; P(31, k) = flxdn; P(32, k) = (R)0 + fupdif * ct; P(30, k) = (R)0 + flxdn * ct; }
-                    else { P(32, k) = p32 + fupdif * ct; P(30, k) = p30 + flxdn * ct; }
-                }
-                fsdir = fsdir + fdndir * ct;
-                fsdif = fsdif + fdndif * ct;
             }
         }
     }
     A.psum[((size_t)pass * 3 + 0) * m + i] = fsdir;
     A.psum[((size_t)pass * 3 + 1) * m + i] = fsdif;
-    A.psum[((size_t)pass * 3 + 2) * m + i] = P(30, np + 1);      // all-sky net flux at the surface (read back from this thread's own plane)
+    A.psum[((size_t)pass * 3 + 2) * m + i] = fall_sfc;      // all-sky net flux at the surface
+#undef RRAV
+#undef RXAV
 #undef P
 #undef LY
-#undef TDA
-#undef TTA
-#undef RSA
-#undef RRA
-#undef RXA
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -459,7 +429,7 @@ __global__ void __launch_bounds__(256) k_sorad_sum(SoradArgs<R> A, SoradOut<R> O
 #pragma unroll 5
     for (int p = 0; p < SO_NPASS; p++) {
         const R hk = A.hk[p];
-        const R *q = A.scr + (((size_t)p * 34 + 30) * K2 + k) * m + i;
+        const R *q = A.scr + (((size_t)p * SO_NPLANE + 26) * K2 + k) * m + i;
         s0 = s0 + q[0] * hk; s1 = s1 + q[(size_t)K2 * m] * hk; s2 = s2 + q[(size_t)2 * K2 * m] * hk; s3 = s3 + q[(size_t)3 * K2 * m] * hk;
     }
     const size_t o = (size_t)(k - 1) * ld + i;
