@@ -779,8 +779,13 @@ def main():
                 traffic = t["traffic_bytes"] / launches_per_step if t else None
             except (OSError, KeyError, ValueError):
                 traffic = None
-        elif a.scheme == "chou" and (ncol, nlay, a.cloudy, aerosol, a.real) == (20_000, 72, 0.6, True, 4):
-            traffic = {"k_chou_bands": 3.3e9}.get(kname)     # profiles/r01_v7_chou_pmc_traffic.md
+        elif a.scheme in ("chou", "irrad", "sorad") and default_paths and (ncol, nlay, a.cloudy, aerosol, a.real) == (100_000, 72, 0.6, True, 4):
+            try:      # profiles/r02_chou_100k_pmc_traffic_counters.txt
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")) as fh:
+                    t = json.load(fh)["chou_100000_72_0.6_aer_f32"].get(kname)
+                traffic = t["traffic_bytes"] / launches_per_step if t else None
+            except (OSError, KeyError, ValueError):
+                traffic = None
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
                    "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
                    "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]
