@@ -37,7 +37,7 @@ template <typename R> hipError_t lw_cols_launch(hipStream_t st, const LwArgs<R> 
     if (dbg) return lwc_launch_one<R, true, true, CMIN>(st, A, O, T);          // test hook: any layer count, speed irrelevant
 #endif
     const int C = lwc_columns_per_block<R>(A.nlay);
-#ifdef LWC_FAST_BUILD          // kernel experiments (variants/mk.sh): only the instantiations of <= 72 layers
+#ifdef LWC_FAST_BUILD          // kernel experiments (A/B builds): only the instantiations of <= 72 layers
     if (C != CMAX) return hipErrorInvalidValue;
     return lwc_launch_c<R, CMAX>(st, A, O, T);
 #else
