@@ -317,8 +317,8 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
     //     situations are formed and summed in the reference's order (ih, im, is); the four flux planes are written once.
     // Per level and pass: 10 + 4..16 loads and 4..16 stores in U, 10 + 4..16 loads and 4 stores in D - the first version, which walked
     // situation by situation, read ~80 and wrote ~48 values per level (profiles/r01_v7_chou_pmc_traffic.md: 138 x the algorithmic bytes).
-    // (Computing the layers inside sweep U, which would save their read-back there, puts deledd's registers on top of the chains':
-    // 214 instead of 97 VGPRs, 21.4 instead of 19.4 ms per 100 000 columns.)
+    // (Computing the layers inside sweep U, which would save their read-back there, is slower: 21.4 instead of 19.4 ms per 100 000
+    // columns, with 214 VGPRs as well as - one portion at a time, scheduling barriers between the deledd calls - with 115.)
     const int nh = cc1 > 0 ? 2 : 1, nm = cc2 > 0 ? 2 : 1, ns = cc3 > 0 ? 2 : 1;       // portions of non-zero weight
     // situation s = 4 (ih-1) + 2 (im-1) + (is-1); the portion it uses in layer k; the variant of its surface-side composites at level k
     auto portion = [&](int s, int k) { return 1 + (k < ict ? (s >> 2) : (k < icb ? ((s >> 1) & 1) : (s & 1))); };
