@@ -412,6 +412,145 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
         "roofline": roof, "kernels_ms_per_step": kms, "cpu_baseline": cpu}))
 
 
+def committed_counters(ckey, kname):
+    """PMC figures of the dominant kernel for the exact configuration they were collected on (separate rocprofv3 --pmc passes, FETCH_SIZE
+    x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; profiles/tools/save_final.py builds the file from the counter dumps of the round's
+    final build).  bench.py cannot collect counters itself: they need the profiler around the process."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r03_counters.json", "r02_traffic.json"):
+        try:
+            with open(os.path.join(here, name)) as fh:
+                t = json.load(fh)[ckey].get(kname)
+            if t:
+                return t, "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def roofline_note(kname, two_streams):
+    """what a `launch` of the dominant kernel is and why its fraction of the HBM peak on the compulsory bytes is what it is"""
+    if kname in ("k_lw_bands", "k_sw_bands"):
+        note = ("a `launch` here is the kernel's cloud-free and cloudy instantiation launched back to back over the batch (one HIP-event "
+                "span; in the rocprofv3 kernel stats: the sum of the two instantiations' average durations); the fused k-distribution + "
+                "vertical-sweep kernel parks per-cell state between its two sweeps, so its HBM traffic is a multiple of the compulsory "
+                "bytes and the fraction on the compulsory bytes is small by construction (~170 FLOP per compulsory byte); `traffic` = PMC "
+                "bytes of this kernel per step / its launches per step (profiles/, see roofline.traffic_source)")
+    elif kname == "k_chou_bands":
+        note = ("irrad's level-pair integration (irrad.F90:960-1294), one wavefront per (column, band): O(np^2) transmittance products per "
+                "column from LDS-resident layer terms - latency / LDS bound, the compulsory bytes are a small part of its work")
+    else:
+        note = ("sorad's spectral passes (sorad.F90:470-1423), lane = column: deledd + CLDFLX adding with the per-level arrays of a pass in "
+                "HBM scratch planes - bound by that scratch traffic, a multiple of the compulsory bytes")
+    if two_streams:
+        note += "; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own duration from two further steps on one stream"
+    return note
+
+
+PARITY_COLS = 256
+PARITY_LW = ("uflx", "dflx", "uflxc", "dflxc")
+PARITY_SW = ("swuflx", "swdflx", "swuflxc", "swdflxc")
+
+
+def lwsw_f64_leg(inp, dev, local_rank, aerosol, do_lw, do_sw, cloudy, steps=5, warmup=3):
+    """The default workload once more with real_kind 8 - the instantiation that meets BASELINE.json's 1e-6 W m-2 - on two HIP streams
+    like the headline; returns (ms per step, the first PARITY_COLS columns of its fluxes on the host)."""
+    import torch
+    from geosradiation_gridcomp_amd.api import Context
+    nlay, ncol = inp["play"].shape
+    tdt = torch.float64
+    names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + LW_IN2D + (["tauaer"] if aerosol else [])
+    if do_sw:
+        names += SW_IN + (SW_AER if aerosol else [])
+    d = {k: torch.from_numpy(np.ascontiguousarray(inp[k])).to(dev, dtype=tdt) for k in names}
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs", "swuflx", "swdflx", "swuflxc", "swdflxc"):
+        d[k] = torch.zeros((nlay + 1, ncol), device=dev, dtype=tdt)
+    for k in SW_OUT1:
+        d[k] = torch.zeros(ncol, device=dev, dtype=tdt)
+    d["fswband"] = torch.zeros((14, ncol), device=dev, dtype=tdt)
+    d["clearCounts"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
+    d["clearCounts_sw"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
+    ptr = {k: v.data_ptr() for k, v in d.items()}
+    ctx = Context(8, device=local_rank)
+    ctx.set_inhomogeneity(1 if cloudy > 0 else 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream() if (do_lw and do_sw) else None
+    sw_stream = side.cuda_stream if side is not None else stream
+    doy, lm, mh = int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"])
+
+    def step():
+        if do_lw:
+            ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
+        if do_sw:
+            ctx.rrtmg_sw_dev(sw_stream, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 10 if aerosol else 0, lm, mh, normFlx=1)
+
+    for _ in range(warmup):
+        step()
+    ctx.check(stream)
+    if side is not None:
+        ctx.check(sw_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ctx.check(stream)
+    ns = min(PARITY_COLS, ncol)
+    sample = {k: d[k][..., :ns].cpu().numpy() for k in PARITY_LW + PARITY_SW + ("clearCounts", "clearCounts_sw")}
+    ctx.close()
+    del d
+    torch.cuda.empty_cache()
+    return ms, sample
+
+
+def lwsw_parity(inp_s, got4, got8, masks4, aerosol, do_lw, do_sw, cloudy):
+    """In-run parity of the timed build: the first PARITY_COLS columns of the batch the timed steps computed (a column's arithmetic does
+    not depend on its batch), against oracle/liboracle.so - the CHECKER, single-threaded, after the timed regions.  LW in W m-2;
+    SW as the timed call returns it (normFlx = 1: fractions of the column's TOA flux) and, through the oracle's un-normalised TOA flux,
+    in W m-2.  Columns whose clearCounts differ from the oracle's (fp32 only: a McICA overlap decision hanging on the last bit of an
+    exp()) are counted and left out of the SW / total-sky figures, as in tests/test_gpu_sw.py."""
+    from oracle import clib
+    ih = 1 if cloudy > 0 else 0
+    out = {}
+    for rk, prec, got in ((4, "f32", got4), (8, "f64", got8)):
+        if got is None:
+            continue
+        clib.lib(); clib.set_inhomogeneity(ih, prec)
+        res = {"columns": int(inp_s["play"].shape[1]), "oracle": "oracle/liboracle.so (" + prec + ")"}
+        if do_lw:
+            o = clib.rrtmg_lw(inp_s, prec)
+            same = (got["clearCounts"] == o["clearCounts"]).all(axis=0)
+            e_clr = max(float(np.abs(got[k].astype(np.float64) - o[k].astype(np.float64)).max()) for k in ("uflxc", "dflxc"))
+            e_tot = max(float(np.abs(got[k].astype(np.float64) - o[k].astype(np.float64))[:, same].max()) for k in ("uflx", "dflx"))
+            res["lw_max_abs_Wm2"] = max(e_clr, e_tot)
+            res["lw_columns_with_other_clearCounts"] = int((~same).sum())
+        if do_sw:
+            q = clib.rrtmg_sw(inp_s, prec=prec, iaer=10 if aerosol else 0, normFlx=1)
+            q0 = clib.rrtmg_sw(inp_s, prec=prec, iaer=10 if aerosol else 0, normFlx=0)
+            toa = q0["swdflx"][-1].astype(np.float64)
+            same = (got["clearCounts_sw"] == q["clearCounts"]).all(axis=0)
+            rel = np.zeros(res["columns"])
+            for k in PARITY_SW:
+                dk = np.abs(got[k].astype(np.float64) - q[k].astype(np.float64)).max(axis=0)
+                rel = np.maximum(rel, dk if k.endswith("c") else np.where(same, dk, 0.0))
+            res["sw_max_rel_toa"] = float(rel.max())
+            res["sw_max_abs_Wm2"] = float((rel * toa).max())
+            res["sw_columns_with_other_clearCounts"] = int((~same).sum())
+        if rk == 4 and masks4 is not None:
+            flips = cells = 0
+            for nsub, so, m in masks4:
+                rl, _, _ = clib.mcica(inp_s["zm"], inp_s["alat"], int(inp_s["dyofyr"]), inp_s["play"], inp_s["cldf"], inp_s["ciwp"],
+                                      inp_s["clwp"], nsub, seed_order=so, prec=prec)
+                flips += int((m != rl.astype(np.int32)).sum())
+                cells += int((inp_s["cldf"] > 0).sum()) * nsub
+            res["mcica_mask_flip_rate"] = flips / max(cells, 1)
+            res["mcica_cells_with_a_decision"] = cells
+        clib.set_inhomogeneity(0, prec)
+        out["f32" if rk == 4 else "f64"] = res
+    return out
+
+
 def _mcica_cpu_worker(args):
     start, ncol, nlay, nsub, cloudy = args
     from geosradiation_gridcomp_amd import synth
@@ -530,6 +669,8 @@ def main():
     ap.add_argument("--rats", type=int, default=0, help="gridcomp: RATS diagnostics for the first N gases of gridcomp.RAT_GAS (0-8)")
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-f64", action="store_true", help="lwsw / lw / sw at --real 4: skip the real_kind 8 leg (3 + 5 steps after the timed region)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figures (256 columns of the timed batch against the oracle) and the f64 leg")
     ap.add_argument("--host-api", action="store_true",
                     help="lwsw / lw / sw: also time the drop-in host-pointer entry points (geosrad_rrtmg_lw / _sw: pinned staging, chunk-pipelined "
                          "H2D / kernels / D2H) on the same columns and report the PCIe-inclusive rate next to the device-resident one")
@@ -749,6 +890,36 @@ def main():
                     "note": "geosrad_rrtmg_lw + geosrad_rrtmg_sw on host arrays, one after the other (numpy -> ctypes, pageable caller memory): "
                             "copy threads -> pinned staging -> H2D | kernels | D2H on three streams, chunks of 16 384 columns"}
 
+    # ---- the tolerance-qualifying precision and the in-run parity figures (N = 1, RRTMG schemes, every column lit) ---------------------
+    f64_leg = parity = None
+    want_parity = rank == 0 and world == 1 and (do_lw or do_sw) and lit is None and a.coherent == 1 and not a.no_parity
+    if want_parity:
+        ns = min(PARITY_COLS, ncol)
+        keys = (PARITY_LW if do_lw else ()) + (PARITY_SW if do_sw else ()) + (("clearCounts",) if do_lw else ()) + (("clearCounts_sw",) if do_sw else ())
+        got4 = got8 = None
+        inp_s = synth.make_columns(ns, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
+        got = {k: d[k][..., :ns].cpu().numpy() for k in keys}
+        masks4 = None
+        if a.real == 4:
+            got4 = got
+            if a.cloudy > 0:       # the generator's decisions themselves (stand-alone API, LW and SW seedings) for the flip rate
+                masks4 = [(nsub, so, ctx.generate_stochastic_clouds(ns, nsub, nlay, inp_s["zm"], inp_s["alat"], doy, inp_s["play"], inp_s["cldf"],
+                                                                    inp_s["ciwp"], inp_s["clwp"], 1e-20, seed_order=so)[0])
+                          for nsub, so in ((140, (1, 2, 3, 4)), (112, (4, 3, 2, 1))) if (do_lw if nsub == 140 else do_sw)]
+        else:
+            got8 = got
+        if a.real == 4 and not a.no_f64:
+            ctx.close()                     # the fp64 workspace of 97 200 columns is ~100 GB: release the fp32 one first
+            del d
+            torch.cuda.empty_cache()
+            ms8, got8 = lwsw_f64_leg(inp, dev, local_rank, aerosol, do_lw, do_sw, a.cloudy)
+            f64_leg = {"value": ncol / (ms8 * 1e-3), "unit": "columns/s", "ms_per_step": ms8, "steps": 5, "warmup": 3, "dtype": "f64",
+                       "note": "same workload and columns, real_kind 8 (the instantiation that meets BASELINE.json's 1e-6 W m-2), two HIP "
+                               "streams, timed after the f32 region"}
+        parity = lwsw_parity(inp_s, got4, got8, masks4, aerosol, do_lw, do_sw, a.cloudy)
+        if f64_leg is not None and "f64" in parity:
+            f64_leg["max_abs_err_vs_oracle_Wm2"] = max(parity["f64"].get("lw_max_abs_Wm2", 0.0), parity["f64"].get("sw_max_abs_Wm2", 0.0))
+
     if rank == 0:
         total_cols = world * ncol * a.steps
         value = total_cols / elapsed
@@ -769,23 +940,23 @@ def main():
         achieved = abytes * (ncol_k / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
         # separate rocprofv3 --pmc runs): only quoted for the exact configuration those passes were collected on
-        traffic = None
+        traffic = traffic_source = compute = None
         default_paths = not (os.environ.get("GEOSRAD_LW_PATH") or os.environ.get("GEOSRAD_SORAD_PATH") or os.environ.get("GEOSRAD_LIB"))
+        ckey = None
         if a.scheme == "lwsw" and default_paths and (ncol, ncol_sw, nlay, a.cloudy, aerosol, a.real) == (97_200, 97_200, 72, 0.6, True, 4):
-            # profiles/r02_traffic.json: the shipped build's counters, the kernel's launches of one step summed -> per launch here
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")) as fh:
-                    t = json.load(fh)["lwsw_97200_72_0.6_aer_f32"].get(kname)
-                traffic = t["traffic_bytes"] / launches_per_step if t else None
-            except (OSError, KeyError, ValueError):
-                traffic = None
+            ckey = "lwsw_97200_72_0.6_aer_f32"
         elif a.scheme in ("chou", "irrad", "sorad") and default_paths and (ncol, nlay, a.cloudy, aerosol, a.real) == (100_000, 72, 0.6, True, 4):
-            try:      # profiles/r02_chou_100k_pmc_traffic_counters.txt
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")) as fh:
-                    t = json.load(fh)["chou_100000_72_0.6_aer_f32"].get(kname)
-                traffic = t["traffic_bytes"] / launches_per_step if t else None
-            except (OSError, KeyError, ValueError):
-                traffic = None
+            ckey = "chou_100000_72_0.6_aer_f32"
+        if ckey is not None:
+            t, traffic_source = committed_counters(ckey, kname)
+            if t is not None:
+                traffic = t["traffic_bytes"] / launches_per_step
+                if "valu_util" in t:
+                    # the fused path is ~170 FLOP per compulsory byte, so the vector-ALU side is the second roofline
+                    compute = {"kernel": kname, "valu_util": t["valu_util"], "lane_ops_per_column": t.get("lane_ops_per_column"),
+                               "valu_insts_per_step": t.get("valu_insts"), "wait_frac": t.get("wait_frac"), "source": traffic_source,
+                               "note": "valu_util = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES-normalised wave issue capacity of the kernel's launches "
+                                       "(profiles/tools/valu.py); lane_ops_per_column = SQ_INSTS_VALU x 64 lanes / columns"}
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
                    "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
                    "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]
@@ -805,18 +976,21 @@ def main():
                        "cloudy_fraction": a.cloudy, "aerosol": aerosol, "hip_streams": 2 if side is not None else 1,
                        "sharding": "independent column batches per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": ms / max(n, 1), "launches": n,
                          "columns_per_launch": ncol_k / launches_per_step,
-                         "note": "a `launch` here is the kernel's cloud-free and cloudy instantiation launched back to back over the batch "
-                                 "(one HIP-event span; in the rocprofv3 kernel stats: the sum of the two instantiations' average durations); "
-                                 "the fused k-distribution + two-stream sweep moves ~36x its compulsory bytes (parked cells between its two "
-                                 "sweeps) and runs at the HBM rate of that traffic, so the fraction on the compulsory bytes is small; "
-                                 "`traffic` = PMC bytes of this kernel per step / its launches per step (profiles/r02_traffic.json)" + ("; the timed steps run LW and SW on two streams, avg_launch_ms is this kernel's own "
-                                                "duration from two further steps on one stream" if side is not None else "")},
+                         "note": roofline_note(kname, side is not None)},
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,
         }
+        if compute is not None:
+            out["roofline_compute"] = compute
+        if f64_leg is not None:
+            out["f64"] = f64_leg
+        if parity is not None:
+            out["parity"] = parity.get("f32" if a.real == 4 else "f64")
+            if a.real == 4 and "f64" in parity:
+                out["f64"]["parity"] = parity["f64"]
         if host_api is not None:
             out["host_api"] = host_api
         print(json.dumps(out))

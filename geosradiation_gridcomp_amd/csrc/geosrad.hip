@@ -253,7 +253,8 @@ struct geosrad_ctx {
     static constexpr int PIPE_SLOTS = 3, PIPE_LAG = 2;
     char *pipe_pin[PIPE_SLOTS][2] = {};      // [slot][0 = to the device, 1 = from the device]
     char *pipe_dev[PIPE_SLOTS] = {};
-    size_t pipe_pin_bytes = 0, pipe_dev_bytes = 0;
+    size_t pipe_pin_bytes[2] = {0, 0}, pipe_dev_bytes = 0;      // [0] holds a chunk's inputs, [1] its outputs only
+    uint32_t *pipe_err = nullptr;            // pinned: the solver's device error word as of each slot's copy-back
     hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr;
     hipEvent_t pipe_ev[PIPE_SLOTS][3] = {};      // per slot: h2d, compute, d2h done
     void pipe_release()
@@ -265,7 +266,8 @@ struct geosrad_ctx {
         }
         if (pipe_h2d) { (void)hipStreamDestroy(pipe_h2d); pipe_h2d = nullptr; }
         if (pipe_d2h) { (void)hipStreamDestroy(pipe_d2h); pipe_d2h = nullptr; }
-        pipe_pin_bytes = pipe_dev_bytes = 0;
+        if (pipe_err) { (void)hipHostFree(pipe_err); pipe_err = nullptr; }
+        pipe_pin_bytes[0] = pipe_pin_bytes[1] = pipe_dev_bytes = 0;
     }
     // a row into the write-once staging memory with non-temporal stores: no read-for-ownership of the destination lines (the rows,
     // 64 KB each, are below the size from which memcpy streams by itself)
@@ -315,8 +317,12 @@ struct geosrad_ctx {
     }
     // arrs must be ordered: copied in only, copied both ways, copied back only.  run(stream, nc, c0, device base of the slot) enqueues
     // the solver for one chunk whose arrays lie at dev + a.off, dense with leading dimension nc (slots are sized for
-    // cn = min(ncol, host_chunk) columns).
-    int host_pipeline(int ncol, std::vector<PipeArr> &arrs, const std::function<int(hipStream_t, int, int, char *, int)> &run)
+    // cn = min(ncol, host_chunk) columns).  err_dev: the solver's device-side input-assertion word (null: the scheme has none); it
+    // comes back with every chunk's outputs, and a chunk whose word is set is NOT scattered into the caller's arrays - the pipeline
+    // drains and returns GEOSRAD_EINPUT for the caller's check() to turn into the reference's message (the reference stops before it
+    // computes anything; here the chunks before the offending one have been delivered).
+    int host_pipeline(int ncol, std::vector<PipeArr> &arrs, const std::function<int(hipStream_t, int, int, char *, int)> &run,
+                      const uint32_t *err_dev = nullptr)
     {
         const int cn = ncol < host_chunk ? ncol : host_chunk;
         size_t off = 0, in_end = 0, out_begin = (size_t)-1;
@@ -333,19 +339,29 @@ struct geosrad_ctx {
             PIPECHK(hipStreamCreateWithFlags(&pipe_h2d, hipStreamNonBlocking));
             PIPECHK(hipStreamCreateWithFlags(&pipe_d2h, hipStreamNonBlocking));
             for (int s = 0; s < PIPE_SLOTS; s++) for (int e = 0; e < 3; e++) PIPECHK(hipEventCreateWithFlags(&pipe_ev[s][e], hipEventDisableTiming));
+            PIPECHK(hipHostMalloc((void **)&pipe_err, PIPE_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
         }
-        if (total > pipe_dev_bytes || total > pipe_pin_bytes) {
+        if (total > pipe_dev_bytes || in_bytes > pipe_pin_bytes[0] || out_bytes > pipe_pin_bytes[1]) {
             PIPECHK(hipDeviceSynchronize());
+            const size_t want_dev = total > pipe_dev_bytes ? total : pipe_dev_bytes;
+            const size_t want_pin[2] = {in_bytes > pipe_pin_bytes[0] ? in_bytes : pipe_pin_bytes[0], out_bytes > pipe_pin_bytes[1] ? out_bytes : pipe_pin_bytes[1]};
+            pipe_dev_bytes = pipe_pin_bytes[0] = pipe_pin_bytes[1] = 0;      // a failure below leaves "nothing allocated", not stale sizes
             for (int s = 0; s < PIPE_SLOTS; s++) {
                 if (pipe_dev[s]) { (void)hipFree(pipe_dev[s]); pipe_dev[s] = nullptr; }
                 for (int d = 0; d < 2; d++) if (pipe_pin[s][d]) { (void)hipHostFree(pipe_pin[s][d]); pipe_pin[s][d] = nullptr; }
-                if (hipMalloc((void **)&pipe_dev[s], total) != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the host-API staging slot failed");
-                for (int d = 0; d < 2; d++)
-                    if (hipHostMalloc((void **)&pipe_pin[s][d], total, hipHostMallocDefault) != hipSuccess)
-                        return fail(GEOSRAD_ENOMEM, "hipHostMalloc of the pinned host-API staging slot failed");
             }
-            pipe_dev_bytes = pipe_pin_bytes = total;
+            for (int s = 0; s < PIPE_SLOTS; s++) {
+                if (hipMalloc((void **)&pipe_dev[s], want_dev) != hipSuccess) { pipe_release(); return fail(GEOSRAD_ENOMEM, "hipMalloc of the host-API staging slot failed"); }
+                for (int d = 0; d < 2; d++)
+                    if (hipHostMalloc((void **)&pipe_pin[s][d], want_pin[d] ? want_pin[d] : 256, hipHostMallocDefault) != hipSuccess) {
+                        pipe_release();
+                        return fail(GEOSRAD_ENOMEM, "hipHostMalloc of the pinned host-API staging slot failed");
+                    }
+            }
+            pipe_dev_bytes = want_dev; pipe_pin_bytes[0] = want_pin[0]; pipe_pin_bytes[1] = want_pin[1];
         }
+        for (int s = 0; s < PIPE_SLOTS; s++) pipe_err[s] = 0;
+        bool input_error = false;
         const int nchunks = (ncol + cn - 1) / cn;
         const bool trace = getenv("GEOSRAD_HOST_TRACE") != nullptr;
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -367,7 +383,8 @@ struct geosrad_ctx {
                 if (rc) { (void)hipDeviceSynchronize(); return rc; }
                 PIPECHK(hipEventRecord(pipe_ev[s][1], stream));
                 PIPECHK(hipStreamWaitEvent(pipe_d2h, pipe_ev[s][1], 0));
-                if (out_bytes) PIPECHK(hipMemcpyAsync(pipe_pin[s][1] + out_begin, pipe_dev[s] + out_begin, out_bytes, hipMemcpyDeviceToHost, pipe_d2h));
+                if (out_bytes) PIPECHK(hipMemcpyAsync(pipe_pin[s][1], pipe_dev[s] + out_begin, out_bytes, hipMemcpyDeviceToHost, pipe_d2h));
+                if (err_dev) PIPECHK(hipMemcpyAsync(&pipe_err[s], err_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, pipe_d2h));
                 PIPECHK(hipEventRecord(pipe_ev[s][2], pipe_d2h));
                 t_e += now() - t0;
             }
@@ -376,10 +393,12 @@ struct geosrad_ctx {
                 double t0 = now();
                 PIPECHK(hipEventSynchronize(pipe_ev[s][2]));
                 double t1 = now(); t_w += t1 - t0;
-                pipe_copy(arrs, pipe_pin[s][1], 0, ncol, c0, nc, false);
+                if (err_dev && pipe_err[s]) { input_error = true; break; }      // this chunk (or one enqueued behind it) tripped an input assertion
+                pipe_copy(arrs, pipe_pin[s][1], out_begin, ncol, c0, nc, false);
                 t_s += now() - t1;
             }
         }
+        if (input_error) { PIPECHK(hipDeviceSynchronize()); return GEOSRAD_EINPUT; }
         if (trace)
             fprintf(stderr, "geosrad host pipeline: %d columns, %d chunks of %d, %.1f MB in / %.1f MB out per chunk: total %.1f ms = gather %.1f + "
                             "scatter %.1f + enqueue %.1f + waiting for the GPU %.1f\n", ncol, nchunks, cn, in_bytes / 1e6, out_bytes / 1e6,
@@ -407,7 +426,7 @@ struct geosrad_ctx {
     virtual int mcica_dev(hipStream_t st, int ncol, int nsubcol, int nlay, const void *zmid, const void *alat, int doy, const void *play,
                           const void *cldfrac, const void *ciwp, const void *clwp, double cwp_tiny, const int32_t *so,
                           int32_t *cldy, void *ciwp_s, void *clwp_s) = 0;
-    virtual int check(hipStream_t st) = 0;
+    virtual int check(hipStream_t st, int which = -1) = 0;      // which: -1 either solver's assertions, 0 RRTMG_LW (+ McICA), 1 RRTMG_SW
     virtual int set_tables_sw(const void *blob, size_t n) = 0;
     virtual int set_tables_chou_lw(const void *blob, size_t n) = 0;
     virtual int set_tables_chou_sw(const void *blob, size_t n) = 0;
@@ -1377,17 +1396,22 @@ template <typename R> struct Ctx : geosrad_ctx {
         return GEOSRAD_OK;
     }
 
-    int check(hipStream_t st) override
+    int check(hipStream_t st, int which = -1) override
     {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamSynchronize(st));
         uint32_t e2[2] = {0, 0};
         HIPCHK(hipMemcpy(e2, d_err, 8, hipMemcpyDeviceToHost));
-        if (!e2[0] && !e2[1]) return GEOSRAD_OK;
         // slot 0 = RRTMG_LW (+ McICA), slot 1 = RRTMG_SW; the Chou schemes have no input assertions (neither has the reference).
-        // Only the slot that is reported is cleared: with the two solvers on two streams the other one's flag stays up for the
-        // check of its own stream.
-        HIPCHK(hipMemset(d_err + (e2[1] ? 1 : 0), 0, 4));
+        // The host-pointer entry points look at their own solver's slot only (a flag left by an unchecked `_dev` call of the other
+        // solver is that call's to report); geosrad_check reports either.  Only the slot that is reported is cleared - with the two
+        // solvers on two streams the other one's flag stays up for the check of its own stream - and it is cleared in stream order
+        // on `st`, so a kernel of the other solver running on another stream cannot lose a bit to it.
+        if (which == 0) e2[1] = 0;
+        if (which == 1) e2[0] = 0;
+        if (!e2[0] && !e2[1]) return GEOSRAD_OK;
+        HIPCHK(hipMemsetAsync(d_err + (e2[1] ? 1 : 0), 0, 4, st));
+        HIPCHK(hipStreamSynchronize(st));
         if (e2[1]) {   // RRTMG_SW input assertions (SW/rrtmg_sw_rad.F90:365-383)
             static const char *SW_NEG_NAMES[12] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cld", "ciwp", "clwp", "rei", "rel"};
             for (int k = 0; k < 12; k++)
@@ -1407,6 +1431,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (e & (1u << ERR_LIQ_RADIUS_LO)) return fail(GEOSRAD_EINPUT, "cldprmc: liqflag 1: excessive low-radius extrapolation forbidden!");
         return fail(GEOSRAD_EINPUT, "device-side input check failed");
     }
+
+    // host-pointer entry points start from a clean slot of their own solver (stream-ordered on the internal stream)
+    int clear_slot(int which) { HIPCHK(hipMemsetAsync(d_err + which, 0, 4, stream)); return GEOSRAD_OK; }
 
     int ensure_io(size_t bytes)
     {
@@ -1456,9 +1483,11 @@ template <typename R> struct Ctx : geosrad_ctx {
                 return lw_dev(st, nc, nlay, dudTs, din, iceflg, liqflg, dyofyr, cloudLM, cloudMH, (int32_t *)(dev + arrs[ix_cc].off), dout,
                               band_output, nullptr, nullptr, nullptr);
             };
-            int rc = host_pipeline(ncol, arrs, run);
+            int rc = clear_slot(0);
             if (rc) return rc;
-            return check(stream);
+            rc = host_pipeline(ncol, arrs, run, d_err);
+            if (rc && rc != GEOSRAD_EINPUT) return rc;
+            return check(stream, 0);
         }
         const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
         size_t insz[I_NIN];
@@ -1493,7 +1522,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         rc = lw_dev(stream, ncol, nlay, dudTs, din, iceflg, liqflg, dyofyr, cloudLM, cloudMH, (int32_t *)(d_io + cco), dout_eff,
                     band_output, taug ? d_io + dbgo[0] : nullptr, taug ? d_io + dbgo[1] : nullptr, nullptr);
         if (rc) return rc;
-        rc = check(stream);
+        rc = check(stream, 0);
         if (rc) return rc;
         bool any_bo = false;
         if (band_output) for (int b = 0; b < 16; b++) any_bo |= band_output[b] != 0;
@@ -1818,9 +1847,11 @@ template <typename R> struct Ctx : geosrad_ctx {
                 return sw_dev(st, nc, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
                               (int32_t *)(dev + arrs[ix_cc].off), dout, do_drfband, bndscl, indsolvar, nullptr);
             };
-            int rc = host_pipeline(ncol, arrs, run);
+            int rc = clear_slot(1);
             if (rc) return rc;
-            return check(stream);
+            rc = host_pipeline(ncol, arrs, run, d_err + 1);
+            if (rc && rc != GEOSRAD_EINPUT) return rc;
+            return check(stream, 1);
         }
         const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
         size_t insz[S_NIN];
@@ -1856,7 +1887,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         rc = sw_dev(stream, ncol, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
                     (int32_t *)(d_io + cco), dout, do_drfband, bndscl, indsolvar, dbg ? ddbg : nullptr);
         if (rc) return rc;
-        rc = check(stream);
+        rc = check(stream, 1);
         if (rc) return rc;
         for (int k = 0; k < SO_NOUT; k++) {
             if (!out[k]) continue;
@@ -2005,7 +2036,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         };
         int rc = host_pipeline(m, arrs, run);
         if (rc) return rc;
-        return check(stream);
+        HIPCHK(hipStreamSynchronize(stream));      // the Chou schemes have no input assertions (neither has the reference)
+        return GEOSRAD_OK;
     }
 
 
@@ -2143,7 +2175,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         };
         int rc = host_pipeline(m, arrs, run);
         if (rc) return rc;
-        return check(stream);
+        HIPCHK(hipStreamSynchronize(stream));      // the Chou schemes have no input assertions (neither has the reference)
+        return GEOSRAD_OK;
     }
 
     // ---- stand-alone McICA generator ---------------------------------------------------------------------------------

@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(256) k_lit_pack(int pdim, int udim, const int3
                                                   const R *__restrict__ unpacked, R *__restrict__ packed)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
-    if (m >= *nlit) return;
+    if (m >= *nlit || m >= pdim) return;             // a packed buffer shorter than NumLit holds the first pdim lit columns
     packed[(size_t)l * pdim + m] = unpacked[(size_t)l * udim + idx[m]];
 }
 template <typename R>
@@ -775,8 +775,8 @@ __global__ void __launch_bounds__(256) k_lit_unpack(int pdim, int udim, const in
     const int i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
     if (i >= udim) return;
     const int m = pos[i];
-    if (m >= 0) unpacked[(size_t)l * udim + i] = packed[(size_t)l * pdim + m];
-    else if (use_default) unpacked[(size_t)l * udim + i] = dflt;
+    if (m >= 0 && m < pdim) unpacked[(size_t)l * udim + i] = packed[(size_t)l * pdim + m];
+    else if (m < 0 && use_default) unpacked[(size_t)l * udim + i] = dflt;
 }
 
 }  // namespace geosrad

@@ -13,12 +13,10 @@ static hipError_t lwc_launch_one(hipStream_t st, const LwArgs<R> &A, const LwOut
     const unsigned ngroups = (unsigned)((A.ncol + C - 1) / C);
     const unsigned grid = 8u * ((ngroups + 7u) / 8u);
     const size_t lds = lwc_lds_bytes<R, CLD>(A.nlay, C);
-    static size_t lds_set = 0;                  // per instantiation: the dynamic-LDS limit granted so far
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_lw_cols<R, CLD, DBG, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set = lds;
-    }
+    // the dynamic-LDS limit is a per-device attribute of the function: set on every launch (cheap), so that a second context on another
+    // GPU of the same process gets it too
+    hipError_t e = hipFuncSetAttribute((const void *)k_lw_cols<R, CLD, DBG, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_lw_cols<R, CLD, DBG, C>), dim3(grid), dim3(nwt + 64u), lds, st, A, O, T);
     return hipGetLastError();
 }

@@ -269,10 +269,12 @@ def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
     assert (got["OLR"] > 100).all() and (got["SFCEM"] > got["SFCEM_INT"]).all()      # a warmer surface emits more
 
 
-def test_fortran_dropin_rate_at_full_size(tmp_path, capsys):
+def test_fortran_dropin_rate_at_full_size(tmp_path, capsys, gpu_ctx):
     """The drop-in path as a GEOS maintainer gets it: Fortran callers (lw_driver / sw_driver, default real, host arrays) on a C360 tile's
     per-GPU share, 97 200 columns x 72 layers, cloudy with aerosols, three calls each - the caller-side time of one call includes
-    the transfers both ways.  Prints the times (INTEGRATION.md quotes them) and holds them to a loose bound."""
+    the transfers both ways.  Prints the times (INTEGRATION.md quotes them; no wall-clock bound is asserted: the box is shared) and
+    holds every flux profile of a 700-column slice, which straddles two 16 384-column chunks of the host pipeline, to the bits the
+    Python binding returns for those columns alone."""
     import re
     from geosradiation_gridcomp_amd import synth
     ncol, nlay, ih = 97_200, 72, 1
@@ -285,8 +287,19 @@ def test_fortran_dropin_rate_at_full_size(tmp_path, capsys):
             np.ascontiguousarray(inp[k], dtype=np.float32).tofile(f)
     out = subprocess.run([os.path.join(FDIR, "bin", "lw_driver_r4"), str(fin), str(fout), "3"], env=env, check=True, capture_output=True, text=True).stdout
     lw_ms = float(re.search(r"ms per call\s+([0-9.]+)", out).group(1))
-    flux = np.fromfile(fout, dtype=np.float64, count=(nlay + 1) * ncol).reshape(nlay + 1, ncol)
-    assert np.isfinite(flux).all() and (flux[0] > 100).all()          # upward flux at the surface
+    flux = np.fromfile(fout, dtype=np.float64, count=6 * (nlay + 1) * ncol).reshape(6, nlay + 1, ncol)
+    assert np.isfinite(flux).all() and (flux[0, 0] > 100).all()          # upward flux at the surface
+    sl = slice(16_384 - 350, 16_384 + 350)
+    shard = {k: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v) for k, v in inp.items()}
+    ctx = gpu_ctx[4]
+    ctx.set_inhomogeneity(ih)
+    try:
+        pl = ctx.rrtmg_lw_columns(shard)
+        ps = ctx.rrtmg_sw_columns(shard, iaer=10, normFlx=1, do_drfband=True)
+    finally:
+        ctx.set_inhomogeneity(0)
+    for i, k in enumerate(FLUX):
+        np.testing.assert_array_equal(flux[i][:, sl], pl[k].astype(np.float64), err_msg=k)
     with open(fin, "wb") as f:
         np.array([ncol, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]), 10, 1, 0], dtype=np.int32).tofile(f)
         np.array([1361.0], dtype=np.float32).tofile(f)
@@ -294,7 +307,13 @@ def test_fortran_dropin_rate_at_full_size(tmp_path, capsys):
             np.ascontiguousarray(inp[k], dtype=np.float32).tofile(f)
     out = subprocess.run([os.path.join(FDIR, "bin", "sw_driver_r4"), str(fin), str(fout), "3"], env=env, check=True, capture_output=True, text=True).stdout
     sw_ms = float(re.search(r"ms per call\s+([0-9.]+)", out).group(1))
+    raw = np.fromfile(fout, dtype=np.uint8)
+    assert int(raw[:4].view(np.int32)[0]) == 0
+    swf = raw[4: 4 + 4 * (nlay + 1) * ncol * 8].view(np.float64).reshape(4, nlay + 1, ncol)
+    for i, k in enumerate(("swuflx", "swdflx", "swuflxc", "swdflxc")):
+        np.testing.assert_array_equal(swf[i][:, sl], ps[k].astype(np.float64), err_msg=k)
+    assert np.isfinite(swf).all() and np.abs(swf[1, nlay] - 1.0).max() <= 2e-6          # normalised: TOA down = 1
     with capsys.disabled():
         print(f"\nFortran drop-in, {ncol} columns x {nlay} layers, host arrays: rrtmg_lw {lw_ms:.1f} ms, rrtmg_sw {sw_ms:.1f} ms per call "
               f"= {ncol / (lw_ms + sw_ms) * 1e3:.3g} columns/s for the pair")
-    assert lw_ms < 150 and sw_ms < 200
+    assert lw_ms > 0 and sw_ms > 0

@@ -2,7 +2,9 @@
 against the oracle on a few of the columns:
   configs[4]: C720 tile / 8 GPUs = 388 800 columns x 137 layers.  The RRTMGP source and coefficient files are not in the reference
               repository, so the RRTMG kernels run this size as the HBM-pressure / deep-atmosphere stand-in.
-  configs[2]: 100 000 columns through the Chou-Suarez pair irrad + sorad in ONE launch each (tests/test_gpu_chou.py)."""
+  configs[3]: C360 tile / 8 GPUs = 97 200 columns x 72 layers, full LW + SW with McICA clouds + aerosols (bench.py's headline), also
+              with RRTMG_SW on the lit half only (SURVEY 8d cfg 4).
+  configs[2]: 100 000 columns through the Chou-Suarez pair irrad + sorad in ONE launch each, through the device entry points."""
 import numpy as np
 import pytest
 from tests.conftest import sub_columns
@@ -70,9 +72,50 @@ def test_c720_share_137_layers(gpu_ctx):
         assert (np.abs(sw1[k][:, :12].astype(np.float64) - q[k]) <= 5e-3)[:, same].all(), k
 
 
+CH_IN = ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg", "tv", "ev", "rv",
+         "taua", "ssaa", "asya")
+CH_OUT = ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts")
+SO_IN = ("cosz", "pl", "ta", "wa", "oa", "cwc", "fcld", "reff", "taua", "ssaa", "asya", "rsuvbm", "rsuvdf", "rsirbm", "rsirdf")
+
+
+def _irrad_dev(ctx, ch):
+    """irrad through the DEVICE entry point: the whole batch in one launch of every kernel (the host-pointer entry point walks it in
+    16 384-column chunks).  Returns host copies of the outputs."""
+    import torch
+    n1, m = ch["ple"].shape
+    d = {k: torch.from_numpy(np.ascontiguousarray(ch[k], dtype=ctx.dtype)).cuda() for k in CH_IN}
+    for k in CH_OUT:
+        d[k] = torch.zeros((n1, m), dtype=d["ple"].dtype, device="cuda")
+    d["sfcem"] = torch.zeros(m, dtype=d["ple"].dtype, device="cuda")
+    d["taudiag"] = torch.zeros((10, n1 - 1, m), dtype=d["ple"].dtype, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.irrad_dev(st, m, n1 - 1, {k: v.data_ptr() for k, v in d.items()}, ch["co2"], True, ch["ict"], ch["icb"], ch["ns"], ch["na"], ch["nb"])
+    ctx.check(st)
+    return {k: d[k].cpu().numpy() for k in CH_OUT + ("sfcem", "taudiag")}
+
+
+def _sorad_dev(ctx, cs):
+    import torch
+    n1, m = cs["pl"].shape
+    d = {k: torch.from_numpy(np.ascontiguousarray(cs[k], dtype=ctx.dtype)).cuda() for k in SO_IN}
+    for k in ("flx", "flc", "flxu", "flcu"):
+        d[k] = torch.zeros((n1, m), dtype=d["pl"].dtype, device="cuda")
+    for k in ("fdiruv", "fdifuv", "fdirpar", "fdifpar", "fdirir", "fdifir"):
+        d[k] = torch.zeros(m, dtype=d["pl"].dtype, device="cuda")
+    for k in ("flx_sfc_band", "drband", "dfband"):
+        d[k] = torch.zeros((8, m), dtype=d["pl"].dtype, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.sorad_dev(st, m, n1 - 1, 8, {k: v.data_ptr() for k, v in d.items()}, cs["co2"], cs["ict"], cs["icb"], cs["hk_uv"], cs["hk_ir"],
+                  do_drfband=True)
+    ctx.check(st)
+    return {k: d[k].cpu().numpy() for k in ("flx", "flc", "flxu", "flcu", "flx_sfc_band", "drband", "dfband")}
+
+
 def test_chou_pair_100k_columns(gpu_ctx):
-    """BASELINE configs[2]'s size for the Chou-Suarez pair: 100 000 columns through irrad and through sorad in one call each
-    (no shrinking of the batch); properties, a shard computed alone (bitwise), spot parity against the plain-C oracle."""
+    """BASELINE configs[2]'s size for the Chou-Suarez pair: 100 000 columns through geosrad_irrad_dev and geosrad_sorad_dev, i.e. ONE
+    launch of every kernel over the whole batch (k_chou_bands over 100 000 x 10 wavefronts, k_sorad_pass with its 30 scratch planes
+    of 100 000 columns); properties, a shard computed alone through the same entry points (bitwise), the chunked host-pointer entry
+    points on the shard (bitwise again), spot parity against the plain-C oracle."""
     from geosradiation_gridcomp_amd import synth
     from oracle import clib
     ctx = gpu_ctx[4]
@@ -80,8 +123,8 @@ def test_chou_pair_100k_columns(gpu_ctx):
     inp = synth.make_columns(n, nlay, start=2_000_000, cloudy_frac=0.6, aerosol=True)
     ch = synth.chou_lw_inputs(inp, aerosol=True)
     cs = synth.chou_sw_inputs(inp, aerosol=True)
-    a = ctx.irrad_columns(ch)
-    s = ctx.sorad_columns(cs, do_drfband=True)
+    a = _irrad_dev(ctx, ch)
+    s = _sorad_dev(ctx, cs)
     for k in ("flxu", "flxd", "flcu", "flcd", "dfdts", "sfcem"):
         assert np.isfinite(a[k]).all(), k
     for k in ("flx", "flc", "flxu", "flcu", "flx_sfc_band"):
@@ -96,16 +139,151 @@ def test_chou_pair_100k_columns(gpu_ctx):
 
     def shard(d):
         return {k: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == n else v) for k, v in d.items()}
-    a1 = ctx.irrad_columns(shard(ch)); s1 = ctx.sorad_columns(shard(cs), do_drfband=True)
+    a1 = _irrad_dev(ctx, shard(ch)); s1 = _sorad_dev(ctx, shard(cs))
+    ah = ctx.irrad_columns(shard(ch)); sh = ctx.sorad_columns(shard(cs), do_drfband=True)
     for k in ("flxu", "flxd", "flcu", "flcd", "dfdts"):
         np.testing.assert_array_equal(a1[k], a[k][..., sl], err_msg=k)
+        np.testing.assert_array_equal(ah[k], a1[k], err_msg=k)
     for k in ("flx", "flc", "flxu", "flcu", "flx_sfc_band", "drband"):
         np.testing.assert_array_equal(s1[k], s[k][..., sl], err_msg=k)
+        np.testing.assert_array_equal(sh[k], s1[k], err_msg=k)
     o = clib.irrad(sub_columns_any(shard(ch), 24, 200), "r4"); q = clib.sorad(sub_columns_any(shard(cs), 24, 200), "r4")
     for k in ("flxu", "flxd", "flcu", "flcd"):
         assert np.abs(a1[k][:, :24].astype(np.float64) - o[k]).max() <= 2e-2, k
     for k in ("flx", "flc", "flxu", "flcu"):
         assert np.abs(s1[k][:, :24].astype(np.float64) - q[k]).max() <= 2e-5, k
+
+
+LW_NAMES = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr",
+            "cfc12vmr", "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel", "tauaer"]
+SW_NAMES = ["coszen", "asdir", "asdif", "aldir", "aldif", "tauaer_sw", "ssaaer_sw", "asmaer_sw"]
+SW_1D = ["nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "cotdtp", "cotdhp", "cotdmp", "cotdlp", "cotntp", "cotnhp", "cotnmp", "cotnlp"]
+SW_PACK_IN = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat"] + SW_NAMES
+SW_FLUX = ["swuflx", "swdflx", "swuflxc", "swdflxc"]
+
+
+def _lwsw_dev(ctx, inp, day=None):
+    """RRTMG_LW + RRTMG_SW through the device entry points on the whole batch in one call each (what bench.py times).  `day`: boolean
+    mask of the lit columns - RRTMG_SW then runs on the packed daytime columns (lit index + PackIt / UnPackIt on the device, as
+    SORADCORE does, SOL:3686, :7753-7799) and the night columns of its outputs hold 0."""
+    import torch
+    nlay, ncol = inp["play"].shape
+    tdt = torch.float32 if ctx.real_kind == 4 else torch.float64
+    d = {k: torch.from_numpy(np.ascontiguousarray(inp[k])).to("cuda", dtype=tdt) for k in LW_NAMES + SW_NAMES}
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs") + tuple(SW_FLUX):
+        d[k] = torch.zeros((nlay + 1, ncol), device="cuda", dtype=tdt)
+    for k in SW_1D:
+        d[k] = torch.zeros(ncol, device="cuda", dtype=tdt)
+    d["fswband"] = torch.zeros((14, ncol), device="cuda", dtype=tdt)
+    d["clearCounts"] = torch.zeros((4, ncol), device="cuda", dtype=torch.int32)
+    d["clearCounts_sw"] = torch.zeros((4, ncol), device="cuda", dtype=torch.int32)
+    ptr = {k: v.data_ptr() for k, v in d.items()}
+    st = torch.cuda.current_stream().cuda_stream
+    doy, lm, mh = int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"])
+    ctx.rrtmg_lw_dev(st, ncol, nlay, True, ptr, 3, 1, doy, lm, mh)
+    if day is None:
+        ctx.rrtmg_sw_dev(st, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 10, lm, mh, normFlx=1)
+    else:
+        nlit = int(day.sum())
+        zth = torch.from_numpy(np.where(day, inp["coszen"], -0.5)).to("cuda", dtype=tdt)
+        idx = torch.zeros(ncol, device="cuda", dtype=torch.int32); pos = torch.zeros_like(idx); cnt = torch.zeros(1, device="cuda", dtype=torch.int32)
+        assert ctx.lit_index_dev(st, ncol, zth.data_ptr(), idx.data_ptr(), pos.data_ptr(), cnt.data_ptr()) == nlit
+        outs = SW_FLUX + ["fswband"] + SW_1D
+        p = {k: torch.zeros(d[k].shape[:-1] + (nlit,), device="cuda", dtype=tdt) for k in SW_PACK_IN + outs}
+        p["clearCounts_sw"] = torch.zeros((4, nlit), device="cuda", dtype=torch.int32)
+        nlev = lambda k: int(np.prod(d[k].shape[:-1])) if d[k].dim() > 1 else 1
+        for k in SW_PACK_IN:
+            ctx.lit_pack_dev(st, nlit, ncol, nlev(k), idx.data_ptr(), cnt.data_ptr(), ptr[k], p[k].data_ptr())
+        ctx.rrtmg_sw_dev(st, nlit, nlay, 1361.0, 1.0, 0, {k: v.data_ptr() for k, v in p.items()}, 3, 1, doy, 10, lm, mh, normFlx=1)
+        for k in outs:
+            ctx.lit_unpack_dev(st, nlit, ncol, nlev(k), pos.data_ptr(), p[k].data_ptr(), ptr[k], default=0.0)
+        d["clearCounts_sw_packed"] = p["clearCounts_sw"]
+    ctx.check(st)
+    out = {k: d[k].cpu().numpy() for k in d if k not in LW_NAMES + SW_NAMES}
+    if day is not None:                      # clearCounts of the packed daytime columns back on their columns (night: 0)
+        out["clearCounts_sw"][:, day] = out.pop("clearCounts_sw_packed")
+    return out
+
+
+@pytest.mark.parametrize("lit", [1.0, 0.5])
+def test_c360_share_lw_sw(gpu_ctx, lit):
+    """BASELINE configs[3] at its per-GPU size, the workload bench.py's headline times: 97 200 columns (C360 tile / 8) x 72 layers, 60 %
+    of the columns cloudy (McICA, ih = 1), aerosols, RRTMG_LW + RRTMG_SW through the `_dev` entry points in one call each.  lit = 0.5
+    is SURVEY 8(d)'s cfg 4 (SW on the lit half, packed on the device).  Checked: size-independent properties, a shard computed alone
+    (bitwise), and 32 of its columns against the oracle in both precisions (fp64: the 1e-6 W m-2 of BASELINE.json)."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    n, nlay = 97_200, 72
+    inp = synth.make_columns(n, nlay, start=3_600_000, cloudy_frac=0.6, aerosol=True)
+    day = None
+    if lit < 1.0:
+        h = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
+        day = (h.astype(np.float64) / float(1 << 24)) < lit
+        assert 0.45 * n < day.sum() < 0.55 * n
+    lit_cols = np.ones(n, bool) if day is None else day
+    ctx = gpu_ctx[4]
+    ctx.set_inhomogeneity(1)
+    try:
+        g = _lwsw_dev(ctx, inp, day)
+        sl = slice(48_211, 48_211 + 333)                 # ragged: not a multiple of the 256-column block
+        shard = {k: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == n else v) for k, v in inp.items()}
+        g1 = _lwsw_dev(ctx, shard, None if day is None else day[sl])
+    finally:
+        ctx.set_inhomogeneity(0)
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs", "clearCounts", "fswband") + tuple(SW_FLUX + SW_1D):
+        assert np.isfinite(g[k]).all(), k
+        np.testing.assert_array_equal(g1[k], g[k][..., sl], err_msg=k)          # a column never depends on its batch or its neighbours
+    # physics that needs no oracle
+    clear = ~(inp["cldf"] > 0).any(axis=0)
+    assert 0.35 * n < clear.sum() < 0.45 * n
+    np.testing.assert_array_equal(g["uflx"][:, clear], g["uflxc"][:, clear])
+    np.testing.assert_array_equal(g["swuflx"][:, clear], g["swuflxc"][:, clear])
+    np.testing.assert_array_equal(g["swdflx"][:, clear], g["swdflxc"][:, clear])
+    assert (g["clearCounts"][:, clear] == 140).all()
+    assert (g["clearCounts"][0, ~clear] < 140).mean() > 0.9                     # cloudy columns do have cloudy sub-columns
+    assert (g["dflx"][nlay] == 0).all() and (g["uflx"][nlay] > 50).all() and (g["uflx"][nlay] < 450).all()
+    assert (g["uflx"][0] > g["uflx"][nlay]).mean() > 0.99                       # surface emission exceeds the OLR
+    np.testing.assert_allclose(g["swdflx"][nlay][lit_cols], 1.0, rtol=2e-6)     # normalised fluxes: TOA down = S0 mu0 / (S0 mu0) = 1
+    if day is not None:
+        for k in SW_FLUX + ["fswband"] + SW_1D:
+            assert (g[k][..., ~day] == 0).all(), k                              # UnPackIt's default on the night side
+    net = g["swdflx"].astype(np.float64) - g["swuflx"]
+    assert ((np.diff(net, axis=0) < -1e-3).any(axis=0)).mean() <= 1e-3          # the atmosphere only absorbs (fp32 singularity aside)
+    netl = g["uflx"].astype(np.float64) - g["dflx"]
+    assert (netl[nlay] > 0).all() and (g["duflx_dTs"][0] > 0).all()
+    sfc = (g["nirr"] + g["nirf"] + g["parr"] + g["parf"] + g["uvrr"] + g["uvrf"]).astype(np.float64)
+    np.testing.assert_allclose(sfc[lit_cols], g["swdflx"][0][lit_cols], rtol=2e-4, atol=1e-6)     # surface down = its spectral partition
+    # oracle spot check: 32 columns of the shard, both precisions
+    m = 32
+    s32 = sub_columns(shard, m)
+    d32 = None if day is None else day[sl][:m]
+    for rk, kind, tl, ts in ((4, "r4", 2e-3, 5e-4), (8, "r8", 1e-6, 1e-9)):
+        c = gpu_ctx[rk]
+        c.set_inhomogeneity(1); clib.set_inhomogeneity(1, kind)
+        try:
+            gg = {k: v[..., :m] for k, v in g1.items()} if rk == 4 else _lwsw_dev(c, s32, d32)
+            r = clib.rrtmg_lw(s32, kind); q = clib.rrtmg_sw(s32, prec=kind, iaer=10, normFlx=1)
+            q0 = clib.rrtmg_sw(s32, prec=kind, iaer=10, normFlx=0)
+        finally:
+            c.set_inhomogeneity(0); clib.set_inhomogeneity(0, kind)
+        assert r["rc"] == 0 and q["rc"] == 0
+        same = (gg["clearCounts"] == r["clearCounts"]).all(axis=0)
+        assert same.all() if rk == 8 else same.sum() >= m - 2
+        for k in ("uflx", "dflx", "uflxc", "dflxc"):
+            err = np.abs(gg[k].astype(np.float64) - r[k].astype(np.float64))[:, same].max()
+            assert err <= tl, (rk, k, err)
+        lit32 = np.ones(m, bool) if d32 is None else d32
+        if rk == 8:      # W m-2, as BASELINE.json states the tolerance: normalised difference x the column's TOA flux
+            toa = q0["swdflx"][nlay].astype(np.float64)
+            for k in SW_FLUX:
+                err = (np.abs(gg[k].astype(np.float64) - q[k].astype(np.float64)) * toa)[:, lit32].max()
+                assert err <= 1e-6, (k, err)
+        else:
+            ok = lit32 & (g1["clearCounts_sw"][:, :m] == q["clearCounts"]).all(axis=0)
+            assert ok.sum() >= lit32.sum() - 2
+            for k in SW_FLUX:
+                err = np.abs(gg[k].astype(np.float64) - q[k].astype(np.float64))[:, ok]
+                assert (err <= 10 * ts).all() and (err <= ts).mean() > 0.99, (k, err.max())
 
 
 def sub_columns_any(d, m, ncol):

@@ -141,6 +141,47 @@ def test_sw_reference_error_stops_become_errors(gpu_ctx):
     assert np.isfinite(o["swuflx"]).all()
 
 
+def test_host_entry_points_error_slots(gpu_ctx):
+    """Error flags of the host-pointer entry points (chunk pipeline): a chunk that trips an input assertion is not scattered into the
+    caller's arrays; a flag left behind by an UNCHECKED `_dev` call of the other solver is neither reported by nor lost to a host call;
+    the context works afterwards."""
+    import torch
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import GeosradInputError
+    ctx = gpu_ctx[4]
+    n, nlay = 40_000, 72                                    # three chunks of the host pipeline (16 384 columns each)
+    inp = synth.make_columns(n, nlay, start=77_000)
+    good = ctx.rrtmg_lw_columns(inp)
+    bad = dict(inp); bad["tlay"] = inp["tlay"].copy(); bad["tlay"][5, 39_000] = -3.0          # in the last chunk
+    out = {k: np.full_like(v, -777.0) if v.dtype.kind == "f" else v.copy() for k, v in good.items()}
+    with pytest.raises(GeosradInputError, match="negative values in input: tlay"):
+        ctx.rrtmg_lw_columns(bad, out=out)
+    assert (out["uflx"][:, 32_768:] == -777.0).all()        # the offending chunk was not delivered
+    np.testing.assert_array_equal(out["uflx"][:, :16_384], good["uflx"][:, :16_384])      # the first chunk was, before the error was seen
+    # an unchecked RRTMG_SW `_dev` error must not surface in (or be cleared by) an RRTMG_LW host call
+    small = synth.make_columns(64, nlay, start=5)
+    tdt = torch.float32
+    names = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat", "coszen",
+             "asdir", "asdif", "aldir", "aldif"]
+    d = {k: torch.from_numpy(np.ascontiguousarray(small[k])).to("cuda", dtype=tdt) for k in names}
+    d["tlay"][3, 2] = -1.0
+    for k in SWFLUX:
+        d[k] = torch.zeros((nlay + 1, 64), device="cuda", dtype=tdt)
+    for k in SFC + COT:
+        d[k] = torch.zeros(64, device="cuda", dtype=tdt)
+    d["fswband"] = torch.zeros((14, 64), device="cuda", dtype=tdt)
+    d["clearCounts_sw"] = torch.zeros((4, 64), device="cuda", dtype=torch.int32)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.rrtmg_sw_dev(st, 64, nlay, 1361.0, 1.0, 0, {k: v.data_ptr() for k, v in d.items()}, 3, 1, int(small["dyofyr"]), 0,
+                     int(small["cloudLM"]), int(small["cloudMH"]))
+    torch.cuda.synchronize()
+    again = ctx.rrtmg_lw_columns(inp)                       # LW host call: clean, although the SW slot is up
+    np.testing.assert_array_equal(again["uflx"], good["uflx"])
+    with pytest.raises(GeosradInputError, match="negative values in input: tlay"):
+        ctx.check(st)                                       # the `_dev` caller's own check still finds it
+    ctx.check(st)                                           # ... once
+
+
 @pytest.mark.parametrize("ncol", [1, 257])
 def test_sw_ragged_sizes(gpu_ctx, ncol):
     from geosradiation_gridcomp_amd import synth
