@@ -26,6 +26,7 @@
 #include "sorad_kernels.hpp"
 #include "gridcomp_kernels.hpp"
 #include "lw_cols.hpp"
+#include "sw_quads.hpp"
 
 using namespace geosrad;
 
@@ -204,6 +205,7 @@ struct geosrad_ctx {
     int device = 0, real_kind = 4, chunk = 131072;
     bool sorad_col_path = false;    // Chou-Suarez sorad passes: HBM scratch planes, lane = column (default) | GEOSRAD_SORAD_PATH=col: on chip
     bool lw_cols_path = false;      // RRTMG_LW band sweeps: parked cells in HBM (default) | GEOSRAD_LW_PATH=cols: on-chip intermediates
+    bool sw_quads_path = false;     // RRTMG_SW band sweeps: lane = (column, band) k_sw_bands (default) | GEOSRAD_SW_PATH=quads: lane = (column, quad of g-points)
     std::string last_error;
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     // optional per-kernel timing with HIP events recorded on the launch stream (geosrad_profile*)
@@ -251,6 +253,7 @@ struct geosrad_ctx {
     // for the GPU in steady state and the H2D engine always has the next chunk queued (two slots in lock-step left it idle while the
     // host gathered: 4.25 instead of 3.4 ms per 16 384-column chunk)
     static constexpr int PIPE_SLOTS = 3, PIPE_LAG = 2;
+    static constexpr int PIPE_FLAGGED = -77;      // host_pipeline: a chunk came back with the device error word set (the caller's check() names it)
     char *pipe_pin[PIPE_SLOTS][2] = {};      // [slot][0 = to the device, 1 = from the device]
     char *pipe_dev[PIPE_SLOTS] = {};
     size_t pipe_pin_bytes[2] = {0, 0}, pipe_dev_bytes = 0;      // [0] holds a chunk's inputs, [1] its outputs only
@@ -319,7 +322,7 @@ struct geosrad_ctx {
     // the solver for one chunk whose arrays lie at dev + a.off, dense with leading dimension nc (slots are sized for
     // cn = min(ncol, host_chunk) columns).  err_dev: the solver's device-side input-assertion word (null: the scheme has none); it
     // comes back with every chunk's outputs, and a chunk whose word is set is NOT scattered into the caller's arrays - the pipeline
-    // drains and returns GEOSRAD_EINPUT for the caller's check() to turn into the reference's message (the reference stops before it
+    // drains and returns PIPE_FLAGGED for the caller's check() to turn into the reference's message (the reference stops before it
     // computes anything; here the chunks before the offending one have been delivered).
     int host_pipeline(int ncol, std::vector<PipeArr> &arrs, const std::function<int(hipStream_t, int, int, char *, int)> &run,
                       const uint32_t *err_dev = nullptr)
@@ -398,7 +401,7 @@ struct geosrad_ctx {
                 t_s += now() - t1;
             }
         }
-        if (input_error) { PIPECHK(hipDeviceSynchronize()); return GEOSRAD_EINPUT; }
+        if (input_error) { PIPECHK(hipDeviceSynchronize()); return PIPE_FLAGGED; }
         if (trace)
             fprintf(stderr, "geosrad host pipeline: %d columns, %d chunks of %d, %.1f MB in / %.1f MB out per chunk: total %.1f ms = gather %.1f + "
                             "scatter %.1f + enqueue %.1f + waiting for the GPU %.1f\n", ncol, nchunks, cn, in_bytes / 1e6, out_bytes / 1e6,
@@ -1486,7 +1489,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             int rc = clear_slot(0);
             if (rc) return rc;
             rc = host_pipeline(ncol, arrs, run, d_err);
-            if (rc && rc != GEOSRAD_EINPUT) return rc;
+            if (rc && rc != PIPE_FLAGGED) return rc;
             return check(stream, 0);
         }
         const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
@@ -1632,9 +1635,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(NG_SW * cl * sizeof(R)); if (w) w->asmcmc = (R *)p;
         p = take((size_t)3 * NG_SW * nc * sizeof(R)); if (w) w->cotsum = (R *)p;
         p = take((size_t)14 * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
-        p = take((size_t)4 * NB_SW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
-        p = take((size_t)3 * NB_SW * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
-        p = take((size_t)8 * 3 * nc * sizeof(R)); if (w) w->cot = (R *)p;
+        p = take((size_t)4 * SWQ_SLOTS * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;      // per band (14) or per quad (32 slots)
+        p = take((size_t)3 * SWQ_SLOTS * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
+        p = take((size_t)8 * 6 * nc * sizeof(R)); if (w) w->cot = (R *)p;
         return off;
     }
     int ensure_ws_sw(int nc, int nlay)
@@ -1774,11 +1777,15 @@ template <typename R> struct Ctx : geosrad_ctx {
             span_begin(8, st);
             if (dbg) {
                 hipLaunchKernelGGL((k_sw_bands<R, true, true>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
+            } else if (sw_quads_path) {
+                hipError_t e = sw_quads_launch<R>(st, A, h_S, SV);
+                if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_launch: ") + hipGetErrorString(e));
             } else {
                 hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
                 hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
             }
             span_end(st);
+            const bool quads = sw_quads_path && !dbg;
             SwOut<R> O{};
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
             O.swuflx = Q(SO_UFLX); O.swdflx = Q(SO_DFLX); O.swuflxc = Q(SO_UFLXC); O.swdflxc = Q(SO_DFLXC);
@@ -1786,15 +1793,23 @@ template <typename R> struct Ctx : geosrad_ctx {
             O.fswband = Q(SO_FSWBAND);
             for (int k = 0; k < 8; k++) O.cot[k] = Q(SO_COT0 + k);
             O.drband = Q(SO_DRBAND); O.dfband = Q(SO_DFBAND);
-            span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, O); span_end(st);
+            span_begin(9, st);
+            if (quads) { hipError_t e = sw_quads_reduce<R>(st, A, O); if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_reduce: ") + hipGetErrorString(e)); }
+            else hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, O);
+            span_end(st);
             if (sw_na_out && !dbg) {
                 // the GridComp's "no-aerosol" diagnostics (GEOS_SolarGridComp.F90:3249-3259 calls the whole of SORADCORE a second
                 // time): same columns, same clouds (McICA is seeded by the pressures), same gas optical depths - only the band
                 // sweeps and the reduction are repeated, without the aerosol terms; validation, setcoef and McICA are shared
                 A.iaer = 0; A.do_drfband = 0;
                 span_begin(8, st);
-                hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
-                hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
+                if (quads) {
+                    hipError_t e = sw_quads_launch<R>(st, A, h_S, SV);
+                    if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_launch: ") + hipGetErrorString(e));
+                } else {
+                    hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
+                    hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
+                }
                 span_end(st);
                 SwOut<R> N{};
                 auto QN = [&](int k) { return (R *)sw_na_out[k] + c0; };
@@ -1802,7 +1817,10 @@ template <typename R> struct Ctx : geosrad_ctx {
                 N.nirr = QN(SO_NIRR); N.nirf = QN(SO_NIRF); N.parr = QN(SO_PARR); N.parf = QN(SO_PARF); N.uvrr = QN(SO_UVRR); N.uvrf = QN(SO_UVRF);
                 N.fswband = QN(SO_FSWBAND);
                 for (int k = 0; k < 8; k++) N.cot[k] = QN(SO_COT0 + k);
-                span_begin(9, st); hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, N); span_end(st);
+                span_begin(9, st);
+                if (quads) { hipError_t e = sw_quads_reduce<R>(st, A, N); if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_reduce: ") + hipGetErrorString(e)); }
+                else hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, N);
+                span_end(st);
             }
         }
         HIPCHK(hipGetLastError());
@@ -1850,7 +1868,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             int rc = clear_slot(1);
             if (rc) return rc;
             rc = host_pipeline(ncol, arrs, run, d_err + 1);
-            if (rc && rc != GEOSRAD_EINPUT) return rc;
+            if (rc && rc != PIPE_FLAGGED) return rc;
             return check(stream, 1);
         }
         const size_t cl = (size_t)ncol * nlay, cv = (size_t)ncol * (nlay + 1);
@@ -2305,6 +2323,8 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
     {   // A/B switch for the measurements in profiles/: GEOSRAD_LW_PATH=cols | bands
         const char *e = getenv("GEOSRAD_LW_PATH");
         if (e) c->lw_cols_path = !strcmp(e, "cols");
+        e = getenv("GEOSRAD_SW_PATH");
+        if (e) c->sw_quads_path = !strcmp(e, "quads");
         if ((e = getenv("GEOSRAD_SORAD_PATH"))) c->sorad_col_path = !strcmp(e, "col");
         // tuning of the host-pointer pipeline: columns per staged chunk, copy threads
         if ((e = getenv("GEOSRAD_HOST_CHUNK")) && atoi(e) >= 64) c->host_chunk = c->host_chunk_default = atoi(e);

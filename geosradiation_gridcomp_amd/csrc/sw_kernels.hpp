@@ -386,6 +386,10 @@ template <> GR_DEV bool sw_conservative<double>(double zw, double zg)
 }
 template <> GR_DEV bool sw_conservative<float>(float zw, float zg)
 {
+    // zwo = w / (1 - (1 - w) q^2), q = g / (1 - g): for q^2 <= 1 (g <= 1/2 - every delta-scaled asymmetry factor, g / (1 + g), is) zwo <= 1
+    // and zwo >= c needs w (1 - c q^2) >= c (1 - q^2), i.e. w >= c; so w < 0.99 with g < 0.49 can never be conservative: decided
+    // without the double-precision arithmetic below (exactly the same predicate, cheaper for most cells)
+    if (zw < 0.99f && zg < 0.49f) return false;
     // (float)x >= c  <=>  x >= midpoint(prev(c), c) =: m   (c = 0.9999995f = 1 - 8 * 2^-24; ulp below 1 is 2^-24)
     const double m = (double)0.9999995f - 0.5 * 5.9604644775390625e-08;
     const double w = zw, g = zg, omg = 1.0 - g;
@@ -395,7 +399,17 @@ template <> GR_DEV bool sw_conservative<float>(float zw, float zg)
 }
 
 // layer reflectance / transmittance, PIFM two-stream (SW/rrtmg_sw_spcvmc.F90:1236-1362)
-template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R rmuz, R &ref, R &refd, R &tra, R &trad)
+// exp(-5): the clamped exponential of reftra, evaluated by the same instruction as the unclamped ones (not folded by the compiler)
+template <typename R> GR_DEV R sw_exp_m5()
+{
+    R five = (R)5.;
+    asm volatile("" : "+v"(five));
+    return f_exp<R>(-five);
+}
+
+// dbt = exp(-zto1 / prmuz), the direct-beam transmittance of the layer (spcvmc :449-456, :547-559), comes out of the same call: where
+// reftra's own exp(-min(zto1 / prmuz, 5)) is not replaced by its series (<= od_lo) or clamped, it IS that exponential
+template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R rmuz, R &ref, R &refd, R &tra, R &trad, R &dbt)
 {
     // rmuz = 1 / prmuz (hoisted by the caller)
     const R eps = (R)1.e-08, od_lo = (R)0.06;
@@ -406,8 +420,9 @@ template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R rmuz,
     const R zgamma4 = (R)1. - zgamma3;
     if (sw_conservative<R>(zw, zg)) {
         const R za = zgamma1 * prmuz, za1 = za - zgamma3, zgt = zgamma1 * zto1;
-        R ze1 = zto1 * rmuz; ze1 = ze1 > (R)500. ? (R)500. : ze1;
-        const R ze2 = f_exp<R>(-ze1);
+        const R zx = zto1 * rmuz;
+        dbt = f_exp<R>(-zx);
+        const R ze2 = zx > (R)500. ? f_exp<R>(-(R)500.) : dbt;
         const R r1 = f_rcp<R>((R)1. + zgt);
         ref = (zgt - za1 * ((R)1. - ze2)) * r1;
         tra = (R)1. - ref;
@@ -425,10 +440,12 @@ template <typename R> GR_DEV void sw_reftra(R zto1, R zw, R zg, R prmuz, R rmuz,
         const R rzrkg = f_rcp<R>(zrkg);
         const R zbeta = (zgamma1 - zrk) * rzrkg;
         R ze1 = zrk * zto1; ze1 = ze1 > (R)5. ? (R)5. : ze1;
-        R ze2 = zto1 * rmuz; ze2 = ze2 > (R)5. ? (R)5. : ze2;
+        const R zx = zto1 * rmuz;
+        const R ze2 = zx > (R)5. ? (R)5. : zx;
+        dbt = f_exp<R>(-zx);
         const R zem1 = ze1 <= od_lo ? (R)1. - ze1 + (R)0.5 * ze1 * ze1 : f_exp<R>(-ze1);
         const R zep1 = f_rcp<R>(zem1);
-        const R zem2 = ze2 <= od_lo ? (R)1. - ze2 + (R)0.5 * ze2 * ze2 : f_exp<R>(-ze2);
+        const R zem2 = ze2 <= od_lo ? (R)1. - ze2 + (R)0.5 * ze2 * ze2 : (zx > (R)5. ? sw_exp_m5<R>() : dbt);
         const R zep2 = f_rcp<R>(zem2);
         const R zdenr = zr4 * zep1 + zr5 * zem1;           // zdent == zdenr (zt4 = zr4, zt5 = zr5)
         if (zdenr >= -eps && zdenr <= eps) { ref = eps; tra = zem2; }
@@ -458,8 +475,7 @@ template <typename R> GR_DEV void sw_cell_clear(R tg, R tr, R ta, R om, R as, R 
     zomco = f_div<R>(zomco - zwf, (R)1. - zwf);
     zgco = f_div<R>(zgco - zf, (R)1. - zf);
     c.tau = ztauo; c.om = zomco; c.g = zgco;
-    sw_reftra<R>(ztauo, zomco, zgco, prmu0, rmu0, c.ref, c.refd, c.tra, c.trad);
-    c.dbt = f_exp<R>(-ztauo * rmu0);
+    sw_reftra<R>(ztauo, zomco, zgco, prmu0, rmu0, c.ref, c.refd, c.tra, c.trad, c.dbt);
 }
 // total sky of a cloudy cell: the (already delta-scaled) cloud optics added to the clear-sky ones (:512-536, 541, 547-559)
 template <typename R> GR_DEV void sw_cell_cloud(const SwCell<R> &c, R tc, R oc, R gc, R prmu0, R rmu0, SwCell<R> &t)
@@ -469,8 +485,7 @@ template <typename R> GR_DEV void sw_cell_cloud(const SwCell<R> &c, R tc, R oc, 
     const R t2 = c.tau + tc;
     g2 = f_div<R>(g2, o2); o2 = f_div<R>(o2, t2);
     t.tau = t2; t.om = o2; t.g = g2;
-    sw_reftra<R>(t2, o2, g2, prmu0, rmu0, t.ref, t.refd, t.tra, t.trad);
-    t.dbt = f_exp<R>(-t2 * rmu0);
+    sw_reftra<R>(t2, o2, g2, prmu0, rmu0, t.ref, t.refd, t.tra, t.trad, t.dbt);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -257,7 +257,9 @@ def test_c360_share_lw_sw(gpu_ctx, lit):
     m = 32
     s32 = sub_columns(shard, m)
     d32 = None if day is None else day[sl][:m]
-    for rk, kind, tl, ts in ((4, "r4", 2e-3, 5e-4), (8, "r8", 1e-6, 1e-9)):
+    # fp32 LW bound: 4e-3 W m-2 on cloudy columns with aerosol (sums of 140 fp32 terms of up to 450 W m-2; the reference's own default-real
+    # and real-8 builds differ by up to 2.2e-3 on such columns, tests/test_gpu_lw.py::test_lw_fp32_is_as_accurate_as_the_reference_precision)
+    for rk, kind, tl, ts in ((4, "r4", 4e-3, 5e-4), (8, "r8", 1e-6, 1e-9)):
         c = gpu_ctx[rk]
         c.set_inhomogeneity(1); clib.set_inhomogeneity(1, kind)
         try:
