@@ -26,7 +26,7 @@
 #include "sorad_kernels.hpp"
 #include "gridcomp_kernels.hpp"
 #include "lw_cols.hpp"
-#include "sw_quads.hpp"
+#include "sw_reform.hpp"
 
 using namespace geosrad;
 
@@ -205,7 +205,7 @@ struct geosrad_ctx {
     int device = 0, real_kind = 4, chunk = 131072;
     bool sorad_col_path = false;    // Chou-Suarez sorad passes: HBM scratch planes, lane = column (default) | GEOSRAD_SORAD_PATH=col: on chip
     bool lw_cols_path = false;      // RRTMG_LW band sweeps: parked cells in HBM (default) | GEOSRAD_LW_PATH=cols: on-chip intermediates
-    bool sw_quads_path = false;     // RRTMG_SW band sweeps: lane = (column, band) k_sw_bands (default) | GEOSRAD_SW_PATH=quads: lane = (column, quad of g-points)
+    int sw_path = 2;                // RRTMG_SW band sweeps: k_sw_reform (2, default) | GEOSRAD_SW_PATH=bands: k_sw_bands, the first mapping (0)
     std::string last_error;
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
     // optional per-kernel timing with HIP events recorded on the launch stream (geosrad_profile*)
@@ -1635,8 +1635,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(NG_SW * cl * sizeof(R)); if (w) w->asmcmc = (R *)p;
         p = take((size_t)3 * NG_SW * nc * sizeof(R)); if (w) w->cotsum = (R *)p;
         p = take((size_t)14 * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
-        p = take((size_t)4 * SWQ_SLOTS * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;      // per band (14) or per quad (32 slots)
-        p = take((size_t)3 * SWQ_SLOTS * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
+        p = take((size_t)4 * SWR_SLOTS_MAX * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;      // per band (14) or per quad (32 slots)
+        p = take((size_t)3 * SWR_SLOTS_MAX * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
         p = take((size_t)8 * 6 * nc * sizeof(R)); if (w) w->cot = (R *)p;
         return off;
     }
@@ -1695,6 +1695,11 @@ template <typename R> struct Ctx : geosrad_ctx {
         return sw_run(st, ncol, nlay, scon, adjes, isolvar, in, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx, clearCounts, out,
                       do_drfband, bndscl, indsolvar, dbg, nullptr);
     }
+
+    // RRTMG_SW band sweeps: fp32 re-forms the cell optics in its second sweep (k_sw_reform, 12 parked bytes per cell); in fp64 the second
+    // two-stream (IEEE divisions, double-precision exp / sqrt) costs more than the 32 parked bytes it would save (32.5 against 29.4 ms per
+    // 97 200 columns), so the fp64 instantiation keeps the first mapping (k_sw_bands); GEOSRAD_SW_PATH=bands selects it for fp32 too
+    bool sw_reform_on() const { return sw_path == 2 && sizeof(R) == 4; }
 
     // sw_na_out (SwOutIx order, all of SO_UFLX .. SO_COT0 + 7 non-null) requests an additional pass without the aerosol terms
     int sw_run(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
@@ -1777,15 +1782,14 @@ template <typename R> struct Ctx : geosrad_ctx {
             span_begin(8, st);
             if (dbg) {
                 hipLaunchKernelGGL((k_sw_bands<R, true, true>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
-            } else if (sw_quads_path) {
-                hipError_t e = sw_quads_launch<R>(st, A, h_S, SV);
-                if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_launch: ") + hipGetErrorString(e));
+            } else if (sw_reform_on()) {
+                hipError_t e = sw_reform_launch<R>(st, A, h_S, SV);
+                if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_reform_launch: ") + hipGetErrorString(e));
             } else {
                 hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
                 hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
             }
             span_end(st);
-            const bool quads = sw_quads_path && !dbg;
             SwOut<R> O{};
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };
             O.swuflx = Q(SO_UFLX); O.swdflx = Q(SO_DFLX); O.swuflxc = Q(SO_UFLXC); O.swdflxc = Q(SO_DFLXC);
@@ -1794,7 +1798,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             for (int k = 0; k < 8; k++) O.cot[k] = Q(SO_COT0 + k);
             O.drband = Q(SO_DRBAND); O.dfband = Q(SO_DFBAND);
             span_begin(9, st);
-            if (quads) { hipError_t e = sw_quads_reduce<R>(st, A, O); if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_reduce: ") + hipGetErrorString(e)); }
+            if (sw_reform_on() && !dbg) { hipError_t e = sw_reform_reduce<R>(st, A, O); if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_reform_reduce: ") + hipGetErrorString(e)); }
             else hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, O);
             span_end(st);
             if (sw_na_out && !dbg) {
@@ -1803,9 +1807,9 @@ template <typename R> struct Ctx : geosrad_ctx {
                 // sweeps and the reduction are repeated, without the aerosol terms; validation, setcoef and McICA are shared
                 A.iaer = 0; A.do_drfband = 0;
                 span_begin(8, st);
-                if (quads) {
-                    hipError_t e = sw_quads_launch<R>(st, A, h_S, SV);
-                    if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_launch: ") + hipGetErrorString(e));
+                if (sw_reform_on()) {
+                    hipError_t e = sw_reform_launch<R>(st, A, h_S, SV);
+                    if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_reform_launch: ") + hipGetErrorString(e));
                 } else {
                     hipLaunchKernelGGL((k_sw_bands<R, false, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
                     hipLaunchKernelGGL((k_sw_bands<R, true, false>), dim3(band_grid(nc, NB_SW)), blk, 0, st, A, h_S, SV);
@@ -1818,7 +1822,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 N.fswband = QN(SO_FSWBAND);
                 for (int k = 0; k < 8; k++) N.cot[k] = QN(SO_COT0 + k);
                 span_begin(9, st);
-                if (quads) { hipError_t e = sw_quads_reduce<R>(st, A, N); if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_quads_reduce: ") + hipGetErrorString(e)); }
+                if (sw_reform_on()) { hipError_t e = sw_reform_reduce<R>(st, A, N); if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("sw_reform_reduce: ") + hipGetErrorString(e)); }
                 else hipLaunchKernelGGL(k_sw_reduce<R>, dim3(gx, nlay + 2), blk, 0, st, A, N);
                 span_end(st);
             }
@@ -2324,7 +2328,7 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
         const char *e = getenv("GEOSRAD_LW_PATH");
         if (e) c->lw_cols_path = !strcmp(e, "cols");
         e = getenv("GEOSRAD_SW_PATH");
-        if (e) c->sw_quads_path = !strcmp(e, "quads");
+        if (e) c->sw_path = !strcmp(e, "bands") ? 0 : 2;
         if ((e = getenv("GEOSRAD_SORAD_PATH"))) c->sorad_col_path = !strcmp(e, "col");
         // tuning of the host-pointer pipeline: columns per staged chunk, copy threads
         if ((e = getenv("GEOSRAD_HOST_CHUNK")) && atoi(e) >= 64) c->host_chunk = c->host_chunk_default = atoi(e);

@@ -1,0 +1,12 @@
+// sw_reform.hpp -- host-side entry of the default RRTMG_SW band sweeps (sw_reform_kernels.hpp), a translation unit of its own
+// (sw_reform.hip, built per precision like geosrad.hip).
+#pragma once
+#include "sw_kernels.hpp"
+
+namespace geosrad {
+constexpr int SWR_SLOTS_MAX = 32;        // partial-flux slots per column the workspace provides (sw_reform_kernels.hpp SWR_NSLOT <= this)
+// lane = (column, unit of g-points), second sweep re-forming the cell optics: the cloud-free and the cloudy instantiation of k_sw_reform
+// on `st`; partials per unit: sw_reform_reduce (k_swr_reduce) sums them into the caller's flux arrays and surface diagnostics
+template <typename R> hipError_t sw_reform_launch(hipStream_t st, const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV);
+template <typename R> hipError_t sw_reform_reduce(hipStream_t st, const SwArgs<R> &A, const SwOut<R> &O);
+}  // namespace geosrad
