@@ -551,6 +551,84 @@ def lwsw_parity(inp_s, got4, got8, masks4, aerosol, do_lw, do_sw, cloudy):
     return out
 
 
+LW_FILE_ORDER = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr",
+                 "cfc12vmr", "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel", "tauaer", "zm", "alat"]
+SW_FILE_ORDER = ["coszen", "play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel",
+                 "zm", "alat", "tauaer_sw", "ssaaer_sw", "asmaer_sw", "asdir", "asdif", "aldir", "aldif"]
+
+
+def bench_ranks_per_gpu(a):
+    """--ranks-per-gpu K1,K2,...: what the MPI ranks of a GEOS job sharing one GPU get (GEOS_SolarGridComp.F90:3701-3709 balances the
+    work of many ranks per node; each is its own process with its own context).  For every K the batch is cut into K shards and K
+    CHILD processes - started before anything in this process touches the GPU - each run the Fortran callers of the drop-in
+    (fortran/lw_driver.F90, sw_driver.F90: the reference's module names and argument lists, host arrays in and out) on one shard,
+    concurrently; a child picks its device from its node-local rank (OMPI_COMM_WORLD_LOCAL_RANK is set to its index: on this box every
+    rank maps to the one GPU).  Reported: the caller-side time of one rrtmg_lw / rrtmg_sw call of the slowest rank, the aggregate rate."""
+    import re
+    import subprocess
+    import tempfile
+    from geosradiation_gridcomp_amd import synth
+    fdir = os.path.join(ROOT, "geosradiation_gridcomp_amd", "fortran", "bin")
+    exe_lw, exe_sw = os.path.join(fdir, "lw_driver_r4"), os.path.join(fdir, "sw_driver_r4")
+    if not (os.path.exists(exe_lw) and os.path.exists(exe_sw)):
+        sys.exit("bench.py --ranks-per-gpu: the Fortran drivers are not built (python -c 'import __graft_entry__ as g; g.build()')")
+    ncol, nlay, aerosol = a.ncol, a.nlay, not a.no_aerosol
+    inp = synth.make_columns(ncol, nlay, start=0, cloudy_frac=a.cloudy, aerosol=True)
+    if not aerosol:
+        for k in ("tauaer", "tauaer_sw"):
+            inp[k] = np.zeros_like(inp[k])
+    ih = 1 if a.cloudy > 0 else 0
+    env0 = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
+    env0.pop("GEOSRAD_DEVICE", None)
+    reps = max(3, a.steps)
+    res = {}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        for K in [int(x) for x in a.ranks_per_gpu.split(",")]:
+            per = (ncol + K - 1) // K
+            files = []
+            for r in range(K):
+                sl = slice(r * per, min(ncol, (r + 1) * per))
+                n = sl.stop - sl.start
+                cut = lambda v: np.ascontiguousarray(v[..., sl], dtype=np.float32)
+                fl, fs = os.path.join(tmp, f"lw_{K}_{r}.bin"), os.path.join(tmp, f"sw_{K}_{r}.bin")
+                with open(fl, "wb") as f:
+                    np.array([n, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"])], dtype=np.int32).tofile(f)
+                    for k in LW_FILE_ORDER:
+                        cut(inp[k]).tofile(f)
+                with open(fs, "wb") as f:
+                    np.array([n, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]), 10 if aerosol else 0, 1, 0], dtype=np.int32).tofile(f)
+                    np.array([1361.0], dtype=np.float32).tofile(f)
+                    for k in SW_FILE_ORDER:
+                        cut(inp[k]).tofile(f)
+                files.append((fl, fs, n))
+            out = {}
+            for which, exe, ix in (("rrtmg_lw", exe_lw, 0), ("rrtmg_sw", exe_sw, 1)):
+                t0 = time.perf_counter()
+                procs = [subprocess.Popen([exe, files[r][ix], os.path.join(tmp, f"out_{r}.bin"), str(reps)], stdout=subprocess.PIPE, text=True,
+                                          env=dict(env0, OMPI_COMM_WORLD_LOCAL_RANK=str(r))) for r in range(K)]
+                ms = []
+                for pr in procs:
+                    txt = pr.communicate()[0]
+                    if pr.returncode != 0:
+                        sys.exit(f"bench.py --ranks-per-gpu: {which} rank failed (rc {pr.returncode}): {txt[-300:]}")
+                    ms.append(float(re.search(r"ms per call\s+([0-9.]+)", txt).group(1)))
+                out[which] = {"ms_per_call_slowest_rank": max(ms), "ms_per_call_mean": sum(ms) / len(ms), "wall_s_incl_file_io_and_init": time.perf_counter() - t0}
+            tot = out["rrtmg_lw"]["ms_per_call_slowest_rank"] + out["rrtmg_sw"]["ms_per_call_slowest_rank"]
+            out["columns_per_rank"] = per
+            out["aggregate_columns_per_s"] = ncol / (tot * 1e-3)
+            res[str(K)] = out
+            for fl, fs, _ in files:
+                os.remove(fl); os.remove(fs)
+    best = max(res.values(), key=lambda v: v["aggregate_columns_per_s"])
+    print(json.dumps({
+        "metric": "columns/sec (LW+SW, 72 layers)", "value": best["aggregate_columns_per_s"], "unit": "columns/s", "n_gpus": 1, "steps": reps,
+        "warmup": 1, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Fortran drop-in (rrtmg_lw + rrtmg_sw, host arrays, PCIe included), {ncol} columns x {nlay} layers cut into K shards, "
+                               f"K processes sharing one GPU, McICA clouds on {100 * a.cloudy:.0f} % of the columns, aerosols {'on' if aerosol else 'off'}",
+                   "columns": ncol, "layers": nlay},
+        "ranks_per_gpu": res}))
+
+
 def _mcica_cpu_worker(args):
     start, ncol, nlay, nsub, cloudy = args
     from geosradiation_gridcomp_amd import synth
@@ -674,6 +752,9 @@ def main():
     ap.add_argument("--host-api", action="store_true",
                     help="lwsw / lw / sw: also time the drop-in host-pointer entry points (geosrad_rrtmg_lw / _sw: pinned staging, chunk-pipelined "
                          "H2D / kernels / D2H) on the same columns and report the PCIe-inclusive rate next to the device-resident one")
+    ap.add_argument("--ranks-per-gpu", default="",
+                    help="K1,K2,...: for each K, K child processes (Fortran drop-in callers, host arrays) share the GPU on 1/K of the batch each; "
+                         "aggregate columns/s per K (what the MPI ranks of a node get)")
     ap.add_argument("--control-path-only", action="store_true",
                     help="no GPU work: launcher, rank -> shard, barrier, MAX over ranks and rank 0's JSON line only (CPU rehearsal / tests)")
     a = ap.parse_args()
@@ -694,6 +775,8 @@ def main():
 
     if a.control_path_only:
         return control_path_only(a, rank, world)
+    if a.ranks_per_gpu:
+        return bench_ranks_per_gpu(a)
 
     cpu = None
     if a.lit < 1.0:

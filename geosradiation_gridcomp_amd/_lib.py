@@ -13,7 +13,7 @@ SO = os.environ.get("GEOSRAD_LIB") or os.path.join(CSRC, "libgeosrad.so")   # ov
 DATA = os.path.join(HERE, "data")
 
 EXPORTS = [
-    "geosrad_create", "geosrad_destroy", "geosrad_last_error", "geosrad_real_kind", "geosrad_set_chunk",
+    "geosrad_create", "geosrad_create_multi", "geosrad_pick_device", "geosrad_destroy", "geosrad_last_error", "geosrad_real_kind", "geosrad_set_chunk",
     "geosrad_workspace_bytes", "geosrad_set_tables_lw", "geosrad_load_tables_lw", "geosrad_set_inhomogeneity",
     "geosrad_load_inhomogeneity", "geosrad_set_corr_lengths", "geosrad_rrtmg_lw", "geosrad_rrtmg_lw_dev",
     "geosrad_check", "geosrad_profile", "geosrad_profile_read", "geosrad_kernel_name", "geosrad_rrtmg_lw_taumol", "geosrad_mcica", "geosrad_clearcounts",
@@ -81,5 +81,7 @@ def lib():
         L.geosrad_workspace_bytes.argtypes = [ctypes.c_void_p]
         L.geosrad_kernel_name.restype = ctypes.c_char_p
         L.geosrad_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
+        L.geosrad_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]
+        L.geosrad_pick_device.argtypes = [ctypes.c_int]
         _lib = L
     return _lib

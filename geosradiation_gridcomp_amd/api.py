@@ -49,12 +49,19 @@ def _p(a):
 class Context:
     """One (GPU, precision) instance of the solver: replaces the reference's module-level state."""
 
-    def __init__(self, real_kind=4, device=0, tables=True):
+    def __init__(self, real_kind=4, device=0, tables=True, devices=None):
+        """device: HIP device index, or -1 = the library's choice for this process (GEOSRAD_DEVICE, else the launcher's node-local MPI
+        rank modulo the device count: geosrad_pick_device).  devices = [ids]: a multi-device context (geosrad_create_multi) - the
+        host-array entry points then split their columns into one contiguous shard per entry, processed concurrently."""
         self.L = _lib.lib()
         self.real_kind = int(real_kind)
         self.dtype = np.float32 if self.real_kind == 4 else np.float64
         self.h = ctypes.c_void_p()
-        rc = self.L.geosrad_create(ctypes.byref(self.h), int(device), self.real_kind)
+        if devices is not None:
+            ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self.L.geosrad_create_multi(ctypes.byref(self.h), ids, len(devices), self.real_kind)
+        else:
+            rc = self.L.geosrad_create(ctypes.byref(self.h), int(device), self.real_kind)
         if rc:
             raise GeosradError({2: "no usable HIP device (the product has no CPU fallback)"}.get(rc, f"geosrad_create rc={rc}"))
         if tables:

@@ -248,6 +248,7 @@ struct geosrad_ctx {
     // the gathering of chunk k+1, the transfers and the kernels of chunk k and the scattering of chunk k-1 overlap.
     struct PipeArr { const void *src; void *dst; size_t rows, ebytes; size_t off; };      // src: copied in; dst: copied back (either may be null)
     int host_chunk = 16384, host_chunk_default = 16384, host_threads = 8;
+    size_t host_ld = 0;             // leading dimension (columns) of the caller's arrays when the call covers a shard of them (multi-device context); 0: ncol
     bool host_nt = true;            // non-temporal stores into the staging slots (GEOSRAD_HOST_NT=0: plain memcpy)
     // three staging slots, results copied back to the caller two chunks behind the one being gathered: the host thread then never waits
     // for the GPU in steady state and the H2D engine always has the next chunk queued (two slots in lock-step left it idle while the
@@ -328,6 +329,7 @@ struct geosrad_ctx {
                       const uint32_t *err_dev = nullptr)
     {
         const int cn = ncol < host_chunk ? ncol : host_chunk;
+        const int ld_host = host_ld ? (int)host_ld : ncol;
         size_t off = 0, in_end = 0, out_begin = (size_t)-1;
         for (auto &a : arrs) {
             a.off = off;
@@ -376,7 +378,7 @@ struct geosrad_ctx {
                 double t0 = now();
                 if (k >= PIPE_SLOTS) PIPECHK(hipEventSynchronize(pipe_ev[s][0]));   // the slot's previous transfer has left the staging memory
                 double t1 = now(); t_w += t1 - t0;
-                pipe_copy(arrs, pipe_pin[s][0], 0, ncol, c0, nc, true);
+                pipe_copy(arrs, pipe_pin[s][0], 0, ld_host, c0, nc, true);
                 t0 = now(); t_g += t0 - t1;
                 if (k >= PIPE_SLOTS) PIPECHK(hipStreamWaitEvent(pipe_h2d, pipe_ev[s][2], 0));   // ... and its previous chunk has been copied out of the device slot
                 if (in_bytes) PIPECHK(hipMemcpyAsync(pipe_dev[s], pipe_pin[s][0], in_bytes, hipMemcpyHostToDevice, pipe_h2d));
@@ -397,7 +399,7 @@ struct geosrad_ctx {
                 PIPECHK(hipEventSynchronize(pipe_ev[s][2]));
                 double t1 = now(); t_w += t1 - t0;
                 if (err_dev && pipe_err[s]) { input_error = true; break; }      // this chunk (or one enqueued behind it) tripped an input assertion
-                pipe_copy(arrs, pipe_pin[s][1], out_begin, ncol, c0, nc, false);
+                pipe_copy(arrs, pipe_pin[s][1], out_begin, ld_host, c0, nc, false);
                 t_s += now() - t1;
             }
         }
@@ -2314,14 +2316,178 @@ geosrad_ctx *geosrad_new_ctx_f64() { return new Ctx<double>(); }
 // ---------------------------------------------------------------------------------------------------
 // extern "C"
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// A context over several devices (`geosrad_create(ctx**, device_ids, ndev, kind)`; 2a: "splitting that batch ... ways").
+// It owns one single-device context per entry of device_ids; the host-pointer solver entry points cut [0, ncol) into ndev contiguous
+// shards and run one child's pipeline per shard concurrently (one host thread each; a child reads / writes its shard of the
+// caller's arrays in place: base pointer + shard start, leading dimension = the full ncol).  Columns are independent, so the
+// result is bitwise the single-device one (tested with device_ids = {0, 0}).  Table / parameter setters go to every child;
+// the `_dev` entry points (device pointers belong to ONE device) are refused.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct MultiCtx final : geosrad_ctx {
+    std::vector<geosrad_ctx *> kid;
+    ~MultiCtx() override { for (auto *k : kid) { (void)hipSetDevice(k->device); delete k; } }
+    int init() override { return GEOSRAD_OK; }
+    int all(const std::function<int(geosrad_ctx *)> &f)
+    {
+        for (auto *k : kid) { const int rc = f(k); if (rc) { last_error = k->last_error; return rc; } }
+        return GEOSRAD_OK;
+    }
+    int nodev(const char *what) { return fail(GEOSRAD_EINVAL, std::string(what) + ": device-pointer entry points need a single-device context (geosrad_create)"); }
+    // shard s of n columns: [start, start + count)
+    static void shard(int n, int nk, int s, int &start, int &count) { const int per = (n + nk - 1) / nk; start = s * per; count = start >= n ? 0 : (n - start < per ? n - start : per); }
+    // fn(child, first column, columns) per shard, concurrently; the first failing shard's status and message
+    int run_shards(int ncol, const std::function<int(geosrad_ctx *, int, int)> &fn)
+    {
+        const int nk = (int)kid.size();
+        std::vector<int> rc(nk, GEOSRAD_OK);
+        std::vector<std::thread> th;
+        for (int s = 0; s < nk; s++) {
+            int c0, nc; shard(ncol, nk, s, c0, nc);
+            if (nc <= 0) continue;
+            th.emplace_back([&, s, c0, nc] { kid[s]->host_ld = (size_t)ncol; rc[s] = fn(kid[s], c0, nc); kid[s]->host_ld = 0; });
+        }
+        for (auto &t : th) t.join();
+        for (int s = 0; s < nk; s++) if (rc[s]) { last_error = kid[s]->last_error; return rc[s]; }
+        return GEOSRAD_OK;
+    }
+    static const void *off(const void *p, size_t bytes) { return p ? (const char *)p + bytes : nullptr; }
+    static void *off(void *p, size_t bytes) { return p ? (char *)p + bytes : nullptr; }
+
+    int set_tables_lw(const void *b, size_t n) override { return all([&](geosrad_ctx *k) { return k->set_tables_lw(b, n); }); }
+    int set_tables_sw(const void *b, size_t n) override { return all([&](geosrad_ctx *k) { return k->set_tables_sw(b, n); }); }
+    int set_tables_chou_lw(const void *b, size_t n) override { return all([&](geosrad_ctx *k) { return k->set_tables_chou_lw(b, n); }); }
+    int set_tables_chou_sw(const void *b, size_t n) override { return all([&](geosrad_ctx *k) { return k->set_tables_chou_sw(b, n); }); }
+    int set_inhomogeneity(int ih, const void *b, size_t n) override { return all([&](geosrad_ctx *k) { return k->set_inhomogeneity(ih, b, n); }); }
+    int set_corr(const double *a, const double *r) override { return all([&](geosrad_ctx *k) { return k->set_corr(a, r); }); }
+    size_t workspace_bytes() const override { size_t t = 0; for (auto *k : kid) t += k->workspace_bytes(); return t; }
+    int check(hipStream_t, int which) override { return all([&](geosrad_ctx *k) { (void)hipSetDevice(k->device); return k->check(k->stream, which); }); }
+
+    int lw_host(int ncol, int nlay, int dudTs, const void *const *in, int iceflg, int liqflg, int dyofyr, int cloudLM, int cloudMH,
+                int32_t *clearCounts, void *const *out, const int32_t *band_output, void *taug, void *pfracs) override
+    {
+        if (taug || pfracs) return fail(GEOSRAD_EINVAL, "stage dumps need a single-device context");
+        const size_t E = (size_t)real_kind;
+        return run_shards(ncol, [&](geosrad_ctx *k, int c0, int nc) {
+            const void *i2[I_NIN]; void *o2[O_NOUT];
+            for (int j = 0; j < I_NIN; j++) i2[j] = off(in[j], (size_t)c0 * E);
+            for (int j = 0; j < O_NOUT; j++) o2[j] = off(out[j], (size_t)c0 * E * ((j == O_OLRB || j == O_DOLRB) ? 16 : 1));
+            return k->lw_host(nc, nlay, dudTs, i2, iceflg, liqflg, dyofyr, cloudLM, cloudMH, clearCounts ? clearCounts + c0 : nullptr, o2,
+                              band_output, nullptr, nullptr);
+        });
+    }
+    int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg, int dyofyr,
+                int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband, const void *bndscl,
+                const void *indsolvar, void *const *dbg) override
+    {
+        if (dbg) return fail(GEOSRAD_EINVAL, "stage dumps need a single-device context");
+        const size_t E = (size_t)real_kind;
+        return run_shards(ncol, [&](geosrad_ctx *k, int c0, int nc) {
+            const void *i2[S_NIN]; void *o2[SO_NOUT];
+            for (int j = 0; j < S_NIN; j++) i2[j] = off(in[j], (size_t)c0 * E);
+            for (int j = 0; j < SO_NOUT; j++) o2[j] = off(out[j], (size_t)c0 * E);
+            return k->sw_host(nc, nlay, scon, adjes, isolvar, i2, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
+                              clearCounts ? clearCounts + c0 : nullptr, o2, do_drfband, bndscl, indsolvar, nullptr);
+        });
+    }
+    int irrad_host(int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb, void *const *aer,
+                   void *const *out) override
+    {
+        const size_t E = (size_t)real_kind;
+        return run_shards(m, [&](geosrad_ctx *k, int c0, int nc) {
+            const void *i2[C_NIN]; void *a2[3], *o2[CO_NOUT];
+            for (int j = 0; j < C_NIN; j++) i2[j] = off(in[j], (size_t)c0 * E);
+            for (int j = 0; j < 3; j++) a2[j] = off(aer[j], (size_t)c0 * E);
+            for (int j = 0; j < CO_NOUT; j++) o2[j] = off(out[j], (size_t)c0 * E);
+            return k->irrad_host(nc, np, i2, co2, trace, ict, icb, ns, na, nb, a2, o2);
+        });
+    }
+    int sorad_host(int m, int np, int nb, const void *const *in, double co2, int ict, int icb, const void *hk_uv, const void *hk_ir,
+                   void *const *out, int do_drfband) override
+    {
+        const size_t E = (size_t)real_kind;
+        return run_shards(m, [&](geosrad_ctx *k, int c0, int nc) {
+            const void *i2[SI_NIN]; void *o2[SOO_NOUT];
+            for (int j = 0; j < SI_NIN; j++) i2[j] = off(in[j], (size_t)c0 * E);
+            for (int j = 0; j < SOO_NOUT; j++) o2[j] = off(out[j], (size_t)c0 * E);
+            return k->sorad_host(nc, np, nb, i2, co2, ict, icb, hk_uv, hk_ir, o2, do_drfband);
+        });
+    }
+    int mcica_host(int, int, int, const void *, const void *, int, const void *, const void *, const void *, const void *, double,
+                   const int32_t *, int32_t *, void *, void *) override { return fail(GEOSRAD_EINVAL, "geosrad_mcica needs a single-device context"); }
+    int lw_dev(hipStream_t, int, int, int, const void *const *, int, int, int, int, int, int32_t *, void *const *, const int32_t *, void *, void *,
+               const LwRats *) override { return nodev("geosrad_rrtmg_lw_dev"); }
+    int mcica_dev(hipStream_t, int, int, int, const void *, const void *, int, const void *, const void *, const void *, const void *, double,
+                  const int32_t *, int32_t *, void *, void *) override { return nodev("geosrad_mcica_dev"); }
+    int sorad_dev(hipStream_t, int, int, int, const void *const *, double, int, int, const void *, const void *, void *const *, int) override { return nodev("geosrad_sorad_dev"); }
+    int irrad_dev(hipStream_t, int, int, const void *const *, double, int, int, int, int, int, int, void *const *, void *const *) override { return nodev("geosrad_irrad_dev"); }
+    int sw_dev(hipStream_t, int, int, double, double, int, const void *const *, int, int, int, int, int, int, int, int32_t *, void *const *, int,
+               const void *, const void *, void *const *) override { return nodev("geosrad_rrtmg_sw_dev"); }
+    int lw_driver_dev(hipStream_t, int, int, int, const void *const *, const double *, int, int, int, int, int, const int32_t *, void *const *, int,
+                      const int32_t *, void *const *) override { return nodev("geosrad_lw_driver_rrtmg_dev"); }
+    int sw_driver_dev(hipStream_t, int, int, int, const void *const *, const double *, int, int, double, double, int, int, int, int, int, int,
+                      const void *, const void *, void *const *) override { return nodev("geosrad_sw_driver_rrtmg_dev"); }
+    int lw_chou_post_dev(hipStream_t, int, int, const void *const *, void *const *) override { return nodev("geosrad_lw_chou_post_dev"); }
+    int lw_update_flx_dev(hipStream_t, int, int, int, int, int, double, const void *const *, void *const *) override { return nodev("geosrad_lw_update_flx_dev"); }
+    int lw_update_rats_dev(hipStream_t, int, int, int, const void *const *, void *const *) override { return nodev("geosrad_lw_update_rats_dev"); }
+    int lw_update_bands_dev(hipStream_t, int, const int32_t *, const double *, const double *, double, const void *, const void *, const void *,
+                            const void *, void *, void *) override { return nodev("geosrad_lw_update_bands_dev"); }
+    int sw_update_export_dev(hipStream_t, int, int, int, const void *const *, void *const *) override { return nodev("geosrad_sw_update_export_dev"); }
+    int sw_update_surface_dev(hipStream_t, int, int, double, const void *const *, void *const *) override { return nodev("geosrad_sw_update_surface_dev"); }
+    int rad_tendencies_dev(hipStream_t, int, int, double, double, const void *const *, void *const *) override { return nodev("geosrad_rad_tendencies_dev"); }
+    int lit_index_dev(hipStream_t, int, const void *, int32_t *, int32_t *, int32_t *, int *) override { return nodev("geosrad_lit_index_dev"); }
+    int lit_pack_dev(hipStream_t, int, int, int, const int32_t *, const int32_t *, const void *, void *) override { return nodev("geosrad_lit_pack_dev"); }
+    int lit_unpack_dev(hipStream_t, int, int, int, const int32_t *, const void *, void *, int, double) override { return nodev("geosrad_lit_unpack_dev"); }
+};
+}  // namespace
+
 extern "C" {
+
+// Which device a process should use when nothing says so explicitly: GEOSRAD_DEVICE if set, else the node-local MPI rank the launcher
+// exports (Open MPI, Slurm, MVAPICH2, Intel MPI / MPICH Hydra) modulo the number of visible devices - 96 ranks of a GEOS job on an
+// 8-GPU node then share the GPUs 12 to one without any configuration (the reference balances its ranks' work, not its devices:
+// GEOS_SolarGridComp.F90:3701-3709).  Pure function of the environment and ndev (no HIP call): 0 when nothing is set.
+int geosrad_pick_device(int ndev)
+{
+    if (ndev <= 0) return 0;
+    static const char *vars[] = {"GEOSRAD_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID",
+                                 "PMI_LOCAL_RANK"};
+    for (const char *v : vars) {
+        const char *e = getenv(v);
+        if (!e || !*e) continue;
+        char *end = nullptr;
+        const long r = strtol(e, &end, 10);
+        if (end == e || r < 0) continue;
+        return (int)(r % ndev);
+    }
+    return 0;
+}
+
+int geosrad_create_multi(geosrad_ctx **out, const int *device_ids, int ndev, int real_kind)
+{
+    if (!out || !device_ids || ndev < 1 || (real_kind != 4 && real_kind != 8)) return GEOSRAD_EINVAL;
+    *out = nullptr;
+    MultiCtx *m = new MultiCtx();
+    m->real_kind = real_kind; m->device = device_ids[0];
+    for (int k = 0; k < ndev; k++) {
+        geosrad_ctx *c = nullptr;
+        const int rc = geosrad_create(&c, device_ids[k], real_kind);
+        if (rc) { delete m; return rc; }
+        m->kid.push_back(c);
+    }
+    *out = m;
+    return GEOSRAD_OK;
+}
 
 int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
 {
     if (!out || (real_kind != 4 && real_kind != 8)) return GEOSRAD_EINVAL;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return GEOSRAD_ENODEV;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GEOSRAD_ENODEV;
+    if (device_id == GEOSRAD_DEVICE_AUTO) device_id = geosrad_pick_device(ndev);
+    if (device_id < 0 || device_id >= ndev) return GEOSRAD_ENODEV;
     geosrad_ctx *c = real_kind == 4 ? geosrad_new_ctx_f32() : geosrad_new_ctx_f64();
     c->device = device_id; c->real_kind = real_kind;
     {   // A/B switch for the measurements in profiles/: GEOSRAD_LW_PATH=cols | bands
@@ -2347,6 +2513,7 @@ int geosrad_real_kind(const geosrad_ctx *c) { return c ? c->real_kind : 0; }
 int geosrad_set_chunk(geosrad_ctx *c, int n)
 {
     if (!c || n < 64) return GEOSRAD_EINVAL;
+    if (auto *m = dynamic_cast<MultiCtx *>(c)) { for (auto *k : m->kid) (void)geosrad_set_chunk(k, n); return GEOSRAD_OK; }
     c->chunk = n;
     c->host_chunk = n < c->host_chunk_default ? n : c->host_chunk_default;      // the host-pointer pipeline never stages more than a batch
     return GEOSRAD_OK;

@@ -1111,6 +1111,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     uint32_t pmask2 = 0;
     // ---- downward sweep, top layer -> surface ------------------------------------------------------
     R plk_up = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)nlay * ld, cba));   // level above the current layer
+#pragma nounroll
     for (int lay = nlay - 1; lay >= 0; lay--) {
         Layer<R> L;
         load_layer<R>(A, lay, col, pc, L);
@@ -1349,6 +1350,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
         for (int l = nlay - 1; l >= 0; l--)
             if (__ballot(ccol && diverge && ltop == l) != 0) { wtop = l; break; }
     }
+#pragma nounroll
     for (int lay = 0; lay < nlay; lay++) {
         usum = 0; ucsum = 0; dusum = 0; ducsum = 0;
         PK sv[NG], sg[NG];

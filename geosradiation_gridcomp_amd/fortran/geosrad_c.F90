@@ -112,18 +112,15 @@ module geosrad_c
 
 contains
 
-   ! the process-wide context, created on first use on device GEOSRAD_DEVICE (default 0) in the default real kind
+   ! the process-wide context, created on first use in the default real kind on the device the library picks for this process
+   ! (GEOSRAD_DEVICE_AUTO = -1: GEOSRAD_DEVICE if set, else the launcher's node-local MPI rank - OMPI_COMM_WORLD_LOCAL_RANK, SLURM_LOCALID,
+   ! MV2_COMM_WORLD_LOCAL_RANK, ... - modulo the number of visible devices, so the ranks of a node spread over its GPUs unconfigured)
    function geosrad_ctx_handle() result(h)
       type(c_ptr) :: h
       integer(c_int) :: rc
-      integer :: dev, stat
-      character(len=16) :: buf
       real :: x
       if (.not. c_associated(ctx)) then
-         dev = 0
-         call get_environment_variable('GEOSRAD_DEVICE', buf, status=stat)
-         if (stat == 0) read(buf, *, iostat=stat) dev
-         rc = geosrad_create(ctx, int(dev, c_int), int(kind(x), c_int))
+         rc = geosrad_create(ctx, -1_c_int, int(kind(x), c_int))
          if (rc /= 0) then
             write(error_unit,*) 'geosrad_create failed, rc =', rc, ' (no usable HIP device? there is no CPU fallback)'
             error stop 'geosrad: cannot create context'

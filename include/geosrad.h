@@ -59,8 +59,18 @@ enum {
 #define GEOSRAD_NB_LW 16
 #define GEOSRAD_NG_LW 140
 
-/* ---- context ------------------------------------------------------------------------------------ */
+/* ---- context ------------------------------------------------------------------------------------
+ * The reference keeps its state in module variables of the process; here it lives in a context.  One context = one HIP
+ * device (geosrad_create) or several (geosrad_create_multi, SURVEY 8b: the host-pointer solver entry points then cut [0, ncol) into
+ * contiguous shards, one per device, processed concurrently; results bitwise those of one device).
+ * device_id = GEOSRAD_DEVICE_AUTO: the device geosrad_pick_device chooses - GEOSRAD_DEVICE if set, else the launcher's node-local
+ * MPI rank (OMPI_COMM_WORLD_LOCAL_RANK, SLURM_LOCALID, MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID, PMI_LOCAL_RANK) modulo the number
+ * of visible devices - what the Fortran drop-in uses, so the ranks of a GEOS job (GEOS_SolarGridComp.F90:3701-3709 balances their
+ * work) spread over a node's GPUs without configuration. */
+#define GEOSRAD_DEVICE_AUTO (-1)
 int geosrad_create(geosrad_ctx **ctx, int device_id, int real_kind /* 4 | 8 */);
+int geosrad_create_multi(geosrad_ctx **ctx, const int *device_ids, int ndev, int real_kind);
+int geosrad_pick_device(int ndev);      /* pure function of the environment; no device needed */
 int geosrad_destroy(geosrad_ctx *ctx);
 const char *geosrad_last_error(const geosrad_ctx *ctx);
 int geosrad_real_kind(const geosrad_ctx *ctx);

@@ -317,3 +317,19 @@ def test_fortran_dropin_rate_at_full_size(tmp_path, capsys, gpu_ctx):
         print(f"\nFortran drop-in, {ncol} columns x {nlay} layers, host arrays: rrtmg_lw {lw_ms:.1f} ms, rrtmg_sw {sw_ms:.1f} ms per call "
               f"= {ncol / (lw_ms + sw_ms) * 1e3:.3g} columns/s for the pair")
     assert lw_ms > 0 and sw_ms > 0
+
+
+def test_ranks_sharing_one_gpu(capsys):
+    """bench.py --ranks-per-gpu: K Fortran caller processes (the drop-in's host-array entry points, device chosen from the node-local
+    rank) share the GPU on 1/K of a batch each, as the MPI ranks of a node do.  A small batch here; the full-size figures are in
+    profiles/ (r03_ranks_per_gpu.md)."""
+    import json
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ranks-per-gpu", "1,2,3", "--ncol", "12000", "--steps", "3"],
+                         check=True, capture_output=True, text=True).stdout
+    d = json.loads(out.strip().splitlines()[-1])
+    assert set(d["ranks_per_gpu"]) == {"1", "2", "3"}
+    for k, v in d["ranks_per_gpu"].items():
+        assert v["columns_per_rank"] == -(-12000 // int(k)) and v["aggregate_columns_per_s"] > 1e4
+    with capsys.disabled():
+        print("\nranks sharing one GPU, 12 000 columns: " + ", ".join(f"K={k}: {v['aggregate_columns_per_s']:.3g} col/s" for k, v in d["ranks_per_gpu"].items()))

@@ -501,3 +501,44 @@ def test_mcica_generator_odd_shapes(gpu_ctx, nsub, nlay, ncol):
         np.testing.assert_array_equal(cl, rl.astype(np.int32))
         np.testing.assert_allclose(ci, ri, rtol=1e-13, atol=0); np.testing.assert_allclose(cw, rw, rtol=1e-13, atol=0)
         assert cl.sum() > 0
+
+
+def test_multi_device_context_is_bitwise_the_single_device_one(gpu_ctx):
+    """geosrad_create_multi: the host-array entry points cut the columns into one contiguous shard per listed device and run
+    the shards concurrently (in place in the caller's arrays: leading dimension = the full column count).  With device_ids = {0, 0}
+    on the one GPU there is: RRTMG_LW, RRTMG_SW, irrad and sorad must return the bits of the single-device context, on a ragged
+    column count that straddles the 16 384-column chunks of the host pipeline."""
+    from geosradiation_gridcomp_amd import synth
+    from geosradiation_gridcomp_amd.api import Context, GeosradError
+    n, nlay = 33_001, 72
+    inp = synth.make_columns(n, nlay, start=910_000, cloudy_frac=0.5, aerosol=True)
+    one = gpu_ctx[4]
+    two = Context(4, devices=[0, 0])
+    try:
+        one.set_inhomogeneity(1); two.set_inhomogeneity(1)
+        a = one.rrtmg_lw_columns(inp, band_output=np.ones(16, np.int32)); b = two.rrtmg_lw_columns(inp, band_output=np.ones(16, np.int32))
+        for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs", "clearCounts", "olrb", "dolrb_dTs"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        a = one.rrtmg_sw_columns(inp, iaer=10, normFlx=1, do_drfband=True); b = two.rrtmg_sw_columns(inp, iaer=10, normFlx=1, do_drfband=True)
+        for k in ("swuflx", "swdflx", "swuflxc", "swdflxc", "nirr", "parf", "fswband", "drband", "dfband", "clearCounts", "cotdtp"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        m = 20_011
+        small = {k: (np.ascontiguousarray(v[..., :m]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == n else v) for k, v in inp.items()}
+        ch = synth.chou_lw_inputs(small, aerosol=True); cs = synth.chou_sw_inputs(small, aerosol=True)
+        a = one.irrad_columns(ch); b = two.irrad_columns(ch)
+        for k in ("flxu", "flxd", "flcu", "flcd", "dfdts", "sfcem", "taudiag", "taua"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        a = one.sorad_columns(cs, do_drfband=True); b = two.sorad_columns(cs, do_drfband=True)
+        for k in ("flx", "flc", "flxu", "flcu", "fdiruv", "flx_sfc_band", "drband"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        # input assertions still surface, with the reference's message
+        bad = dict(inp); bad["tlay"] = inp["tlay"].copy(); bad["tlay"][3, n - 5] = -1.0
+        from geosradiation_gridcomp_amd.api import GeosradInputError
+        with pytest.raises(GeosradInputError, match="negative values in input: tlay"):
+            two.rrtmg_lw_columns(bad)
+        # device-pointer entry points belong to one device
+        with pytest.raises(GeosradError, match="single-device"):
+            two.rrtmg_lw_dev(0, 8, nlay, True, {}, 3, 1, 1, 10, 20)
+    finally:
+        one.set_inhomogeneity(0)
+        two.close()

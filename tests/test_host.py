@@ -28,6 +28,28 @@ def test_no_device_is_an_error_not_a_fallback():
         Context(4)
 
 
+def test_device_choice_follows_the_local_mpi_rank():
+    """geosrad_pick_device: GEOSRAD_DEVICE wins; else the launcher's node-local rank modulo the device count (96 ranks on an 8-GPU node
+    share the GPUs 12 to one); nothing set -> device 0.  Pure function of the environment: runs without a GPU, in a child process each
+    (getenv is read by the C library)."""
+    import subprocess
+    import sys
+    _lib.build()
+    code = "import ctypes,sys; L=ctypes.CDLL(sys.argv[1]); print(L.geosrad_pick_device(int(sys.argv[2])))"
+    base = {k: v for k, v in os.environ.items() if k not in ("GEOSRAD_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID",
+                                                             "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "PMI_LOCAL_RANK")}
+
+    def pick(ndev, **env):
+        return int(subprocess.check_output([sys.executable, "-c", code, _lib.SO, str(ndev)], env=dict(base, **env)).split()[-1])
+    assert pick(8) == 0
+    assert pick(8, OMPI_COMM_WORLD_LOCAL_RANK="5") == 5
+    assert pick(8, OMPI_COMM_WORLD_LOCAL_RANK="95") == 95 % 8
+    assert pick(8, SLURM_LOCALID="11") == 3
+    assert pick(4, MV2_COMM_WORLD_LOCAL_RANK="6") == 2
+    assert pick(8, GEOSRAD_DEVICE="2", OMPI_COMM_WORLD_LOCAL_RANK="5") == 2          # the explicit choice wins
+    assert pick(8, SLURM_LOCALID="x7") == 0 and pick(0, SLURM_LOCALID="3") == 0      # unparsable / no device: 0
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "geosradiation_gridcomp_amd")
     for dirpath, _, files in os.walk(pkg):
