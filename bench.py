@@ -583,7 +583,10 @@ def bench_ranks_per_gpu(a):
     reps = max(3, a.steps)
     res = {}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
-        for K in [int(x) for x in a.ranks_per_gpu.split(",")]:
+        ks = [int(x) for x in a.ranks_per_gpu.split(",")]
+        if max(ks) > 6:
+            sys.exit("bench.py --ranks-per-gpu: at most 6 processes may share the GPU of a box of this pool")
+        for K in ks:
             per = (ncol + K - 1) // K
             files = []
             for r in range(K):

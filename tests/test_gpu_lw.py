@@ -538,7 +538,7 @@ def test_multi_device_context_is_bitwise_the_single_device_one(gpu_ctx):
             two.rrtmg_lw_columns(bad)
         # device-pointer entry points belong to one device
         with pytest.raises(GeosradError, match="single-device"):
-            two.rrtmg_lw_dev(0, 8, nlay, True, {}, 3, 1, 1, 10, 20)
+            two.rrtmg_lw_dev(0, 8, nlay, True, {"clearCounts": 64}, 3, 1, 1, 10, 20)      # (never dereferenced)
     finally:
         one.set_inhomogeneity(0)
         two.close()
