@@ -15,6 +15,7 @@
 #include <functional>
 #include <chrono>
 
+#include <dlfcn.h>
 #include <cstddef>
 #include <cstdint>
 #include "../../include/geosrad.h"
@@ -194,6 +195,36 @@ template <typename R> struct TableStage {
     }
 };
 
+// roctx ranges with the reference's MAPL timer names around the kernel groups (the names of GEOS_IrradGridComp.F90:1138-1155 and
+// rrtmg_sw_rad.F90:1181-1200 / rrtmg_sw_spcvmc.F90:382-567 survive on the GPU timeline: `rocprofv3 --marker-trace`).  Off unless
+// GEOSRAD_ROCTX=1; the marker library is looked up at run time (no link dependency).  A fused kernel group carries the names of all the
+// reference stages it covers, nested.
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi()
+    {
+        const char *e = getenv("GEOSRAD_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+static RoctxApi &roctx_api() { static RoctxApi a; return a; }
+// kernel-group id (geosrad_kernel_name) -> the reference timers it stands for (up to three, outermost first)
+static const char *const ROCTX_NAMES[14][3] = {
+    {"---RRTMG_RUN", "k_validate_pwv", nullptr}, {"---RRTMG_RUN", "setcoef", nullptr}, {"---RRTMG_CLDSGEN", "overlap", nullptr},
+    {"---RRTMG_CLDSGEN", "---RRTMG_CLDPRMC", nullptr}, {"---RRTMG_RUN", "taumol+rtrnmc", nullptr}, {"---RRTMG_RUN", "reduce", nullptr},
+    {"---RRTMG_PART", nullptr, nullptr}, {"---RRTMG_SETCOEF", nullptr, nullptr}, {"---RRTMG_TAUMOL", "---RRTMG_REFTRA", "---RRTMG_VRTQDR"},
+    {"---RRTMG_PART", "reduce", nullptr}, {"---IRRAD_RUN", "prep", nullptr}, {"---IRRAD_RUN", "bands", nullptr}, {"---SORAD_RUN", "prep", nullptr},
+    {"---SORAD_RUN", "passes", nullptr}};
+
 static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr",
                                        "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr", "cldf", "ciwp", "clwp", "rei", "rel",
                                        "plev", "tsfc", "emis", "tauaer"};
@@ -222,14 +253,22 @@ struct geosrad_ctx {
         else (void)hipEventCreate(&e);
         return e;
     }
+    int roctx_depth = 0;
     void span_begin(int kid, hipStream_t st)
     {
+        if (roctx_api().push && kid >= 0 && kid < 14) {
+            for (int k = 0; k < 3; k++) if (ROCTX_NAMES[kid][k]) { roctx_api().push(ROCTX_NAMES[kid][k]); roctx_depth++; }
+        }
         if (!profiling) return;
         Span s{kid, getev(), getev()};
         (void)hipEventRecord(s.a, st);
         spans.push_back(s);
     }
-    void span_end(hipStream_t st) { if (profiling && !spans.empty()) (void)hipEventRecord(spans.back().b, st); }
+    void span_end(hipStream_t st)
+    {
+        if (profiling && !spans.empty()) (void)hipEventRecord(spans.back().b, st);
+        for (; roctx_depth > 0; roctx_depth--) roctx_api().pop();
+    }
     void prof_collect()
     {
         for (auto &s : spans) {

@@ -50,7 +50,7 @@ module rrtmg_sw_rad
    use iso_c_binding
    use geosrad_c
 #ifdef GEOSRAD_WITH_MAPL
-   use MAPL, only : MAPL_MetaComp
+   use MAPL, only : MAPL_MetaComp, MAPL_TimerOn, MAPL_TimerOff
 #endif
    implicit none
 contains
@@ -111,6 +111,13 @@ contains
       end if
       if (present(bndscl)) pb = c_loc(bndscl)
       if (present(indsolvar)) pi = c_loc(indsolvar)
+      ! The reference's timers (rrtmg_sw_rad.F90:1181-1200 registers ---RRTMG_PART, _CLDSGEN, _CLDPRMC, _SETCOEF, _TAUMOL, _REFTRA, _VRTQDR):
+      ! the whole call is one asynchronous pipeline here, so on the host it is charged to ---RRTMG_PART (the timer that brackets the
+      ! reference's partition loop); the stages carry the reference's names as roctx ranges on the GPU timeline (GEOSRAD_ROCTX=1,
+      ! rocprofv3 --marker-trace)
+#ifdef GEOSRAD_WITH_MAPL
+      call MAPL_TimerOn(MAPL, "---RRTMG_PART")
+#endif
       st = geosrad_rrtmg_sw(geosrad_ctx_handle(), int(rpart,c_int), int(ncol,c_int), int(nlay,c_int), real(scon,c_double), &
          real(adjes,c_double), c_loc(coszen), int(isolvar,c_int), c_loc(play), c_loc(plev), c_loc(tlay), &
          c_loc(h2ovmr), c_loc(o3vmr), c_loc(co2vmr), c_loc(ch4vmr), c_loc(o2vmr), int(iceflgsw,c_int), int(liqflgsw,c_int), &
@@ -121,6 +128,9 @@ contains
          c_loc(nirr), c_loc(nirf), c_loc(parr), c_loc(parf), c_loc(uvrr), c_loc(uvrf), c_loc(fswband), &
          c_loc(cotdtp), c_loc(cotdhp), c_loc(cotdmp), c_loc(cotdlp), c_loc(cotntp), c_loc(cotnhp), c_loc(cotnmp), c_loc(cotnlp), &
          merge(1_c_int, 0_c_int, do_drfband), pdr, pdf, pb, pi)
+#ifdef GEOSRAD_WITH_MAPL
+      call MAPL_TimerOff(MAPL, "---RRTMG_PART")
+#endif
       clearCounts = cc
       if (do_drfband .and. st == 0) then
          drband(1:ncol,1:nbndsw) = zdr; dfband(1:ncol,1:nbndsw) = zdf
