@@ -310,6 +310,10 @@ int SFX(oracle_irrad)(int m, int np, const REAL *ple, const REAL *ta, const REAL
             /* the reference `return`s here (irrad.F90:478), i.e. stops after the first column when trace is false; GEOS always
              * passes trace = .true. (GEOS_IrradGridComp.F90:1487) -- band 10 is simply skipped here */
             if (ibn == 10 && !trace) break;
+            {   /* test hook: ORACLE_CHOU_BAND=n keeps band n only (per-band comparison with the tables of the technical memoranda) */
+                const char *only = getenv("ORACLE_CHOU_BAND");
+                if (only && atoi(only) != ibn) continue;
+            }
             const int h2otable = ibn == 1 || ibn == 2 || ibn == 8, conbnd = ibn >= 2 && ibn <= 7, co2bnd = ibn == 3, oznbnd = ibn == 5,
                       n2obnd = ibn == 6 || ibn == 7, ch4bnd = n2obnd, combnd = ibn == 4 || ibn == 5, f11bnd = combnd,
                       f12bnd = ibn == 4 || ibn == 6, f22bnd = f12bnd, b10bnd = ibn == 10, do_aerosol = na > 0;

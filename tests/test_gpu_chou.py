@@ -180,3 +180,46 @@ def test_irrad_gpu_isothermal_equilibrium(gpu_ctx, rk):
     fu = np.asarray(o["flxu"], dtype=np.float64)
     assert (fu.max(axis=0) - fu.min(axis=0)).max() <= (1e-9 if rk == 8 else 2e-3), (fu.max(axis=0) - fu.min(axis=0)).max()
     np.testing.assert_allclose(-fu[0], 5.670374e-8 * T0 ** 4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_gpu_chou_schemes_match_techmemo_tables(gpu_ctx, rk, tmp_path):
+    """The kernels themselves against the numbers the reference repository publishes for irrad / sorad (tests/golden/chou_techmemo.py;
+    CPU counterpart with the per-band breakdown: tests/test_oracle_chou.py::test_irrad_matches_techmemo_tables, ::test_sorad_...):
+    IrradDoc94 section 7.9-7.10 sample atmosphere -> clear-sky fluxes within 1.2 % of IrradDoc03 Table 14 with the shipped (CKD 2.3)
+    coefficients, and the 76-level net flux profile of the memorandum's sample output within 3 W m-2 once the context is given the
+    memoranda's continuum coefficients (a table blob with Roberts et al.'s xke, none below 540 cm-1); SolarDoc Table 9's stratus case
+    within the memorandum's own parameterization-against-detailed spread."""
+    import os
+    from tests.golden import chou_techmemo as M
+    from geosradiation_gridcomp_amd import _lib, tableblob
+    ctx = gpu_ctx[rk]
+    ch = M.irrad_inputs(m=3)
+    o = ctx.irrad(3, 75, ch["ple"], ch["ta"], ch["wa"], ch["oa"], ch["tb"], ch["co2"], False, ch["n2o"], ch["ch4"], ch["cfc11"], ch["cfc12"],
+                  ch["cfc22"], ch["cwc"], ch["fcld"], ch["ict"], ch["icb"], ch["reff"], ch["ns"], ch["fs"], ch["tg"], ch["eg"], ch["tv"], ch["ev"],
+                  ch["rv"], ch["na"], ch["nb"], ch["taua"], ch["ssaa"], ch["asya"])
+    sfc, top = float(o["flcd"][-1, 0]), float(-o["flcu"][0, 0])
+    assert abs(sfc / M.MLS_SFC_DOWN["param_2003"] - 1) <= 0.012 and abs(top / M.MLS_TOA_UP["param_2003"] - 1) <= 0.012, (sfc, top)
+    kind = "r8" if rk == 8 else "r4"
+    rb, t = tableblob.read_blob(os.path.join(_lib.DATA, f"chou_lw_{kind}.grtb"))
+    t = dict(t); t["xke"] = M.XKE_1994.astype(t["xke"].dtype)
+    blob = tmp_path / "chou_lw_memo.grtb"
+    tableblob.write_blob(str(blob), rb, t)
+    try:
+        ctx.irrad_ini(str(blob))
+        o = ctx.irrad(3, 75, ch["ple"], ch["ta"], ch["wa"], ch["oa"], ch["tb"], ch["co2"], False, ch["n2o"], ch["ch4"], ch["cfc11"], ch["cfc12"],
+                      ch["cfc22"], ch["cwc"], ch["fcld"], ch["ict"], ch["icb"], ch["reff"], ch["ns"], ch["fs"], ch["tg"], ch["eg"], ch["tv"],
+                      ch["ev"], ch["rv"], ch["na"], ch["nb"], ch["taua"], ch["ssaa"], ch["asya"])
+    finally:
+        ctx.irrad_ini()
+    net = (o["flcu"].astype(np.float64) + o["flcd"])[:, 1]
+    assert np.abs(net - M.FLC_1994).max() <= 3.0, np.abs(net - M.FLC_1994).max()
+    assert abs(float(o["flcd"][-1, 0]) - M.MLS_SFC_DOWN["param_1994"]) <= 2.7 and abs(float(-o["flcu"][0, 0]) - M.MLS_TOA_UP["param_1994"]) <= 1.8
+    _, ts = tableblob.read_blob(os.path.join(_lib.DATA, "chou_sw_r8.grtb"))
+    hk_uv, hk_ir = np.asarray(ts["hk_uv_old"], dtype=np.float64), np.ascontiguousarray(np.asarray(ts["hk_ir_old"], dtype=np.float64).T)
+    ins = M.SW_S0 * M.SW_COSZ
+    s = ctx.sorad_columns(M.sorad_inputs(hk_uv, hk_ir, cloud=True, m=3))
+    toa, sfc = float(s["flx"][0, 2]) * ins, float(s["flx"][-1, 2]) * ins
+    for got, key in ((toa, "toa"), (sfc, "sfc"), (toa - sfc, "atm")):
+        assert abs(got - M.SW_STRATUS[key][0]) <= 8.5, (key, got, M.SW_STRATUS[key])
+    assert abs(toa / M.SW_STRATUS["toa"][0] - 1) <= 0.01
