@@ -213,11 +213,20 @@ __host__ __device__ constexpr int ch_planes_max()
     for (int ibn = 1; ibn <= 10; ibn++) m = ch_planes(ibn) > m ? ch_planes(ibn) : m;
     return m;
 }
-// LDS bytes of k_chou_bands for np layers
-template <typename R> constexpr size_t chou_bands_lds_bytes(int np)
+// columns per wavefront of k_chou_bands and lanes per column (see chou_band_body).  1: the whole wavefront walks one column's rows.
+// 2 (two half-wavefronts of 32 lanes, each with LDS arrays of its own) cuts loop 2000 from 82 to 61.5 lock-step walks per column but
+// doubles the LDS of a wavefront, i.e. halves the wavefronts per CU - and the kernel lives on those (latency of the LDS read-modify-
+// writes and table gathers of a step): 42.7 against 32.1 ms per 100 000 columns (profiles/r03_chou_rows.md), so 1 stays
+#ifndef CH_CPW
+#define CH_CPW 1
+#endif
+constexpr int CH_LPC = 64 / CH_CPW;
+// LDS bytes of one column of k_chou_bands for np layers (16-byte multiple), and of a block (CH_CPW columns)
+template <typename R> constexpr size_t ch_lds_bytes_col(int np)
 {
-    return (size_t)((ch_planes_max() + 3) * (np + 1) + 12 * (np + 2)) * sizeof(R) + (size_t)(np + 1) * sizeof(int);
+    return (((size_t)((ch_planes_max() + 3) * (np + 1) + 12 * (np + 2)) * sizeof(R) + (size_t)(np + 1) * sizeof(int)) + 15) & ~(size_t)15;
 }
+template <typename R> constexpr size_t chou_bands_lds_bytes(int np) { return CH_CPW * ch_lds_bytes_col<R>(np); }
 
 // running transmittance state of one lane (one k1)
 template <typename R> struct ChState {
@@ -225,20 +234,29 @@ template <typename R> struct ChState {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// k_chou_bands: one wave per (column, band); blockIdx.x = column, blockIdx.y = band - 1.  Dynamic LDS.
+// k_chou_bands: one wavefront per (CH_CPW columns, band); blockIdx.x = column group, blockIdx.y = band - 1.  Dynamic LDS.
 // The band is a template parameter of the body: which absorbers a band has, where their exponentials sit and how many running
 // products a lane carries are then compile-time facts (dead branches and their registers disappear).
 // ---------------------------------------------------------------------------------------------------
 template <typename R, int IBN>
 GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned char *ch_smem)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    // CH_CPW columns per wavefront, CH_LPC = 64 / CH_CPW lanes each: loop 2000 walks one row k1 per lane in lock-step, rows of 73 .. 1
+    // steps at 72 layers; with 64 lanes per column the second pass (rows 64 .. 72) and the idle tails leave 49 % of the lane-steps
+    // unused (82 steps per column), with 32 lanes per column the passes of two columns are 73 + 41 + 9 = 123 steps (61.5 per column).
+    // Each half-wavefront owns its own LDS arrays; the lanes of a half never touch the other half's.
+    const int half = (int)threadIdx.x / CH_LPC, lane = (int)threadIdx.x % CH_LPC;
+    const int icol = (int)blockIdx.x * CH_CPW + half;
+    const bool valid = icol < A.m;                            // (odd column count: the last wavefront's second half computes along on
+    const int i = valid ? icol : A.m - 1;                     //  the last column and writes nothing)
+    const unsigned long long hmask = CH_LPC == 64 ? ~0ull : (((1ull << CH_LPC) - 1ull) << (half * CH_LPC));
     constexpr int ibn = IBN;
     const int np = A.np, K1 = np + 1, K2 = np + 2, ld = A.ld;
     constexpr ChBand B = ch_band(IBN);
     const bool trace = A.trace != 0, do_aer = A.na > 0;
 
     // ---- LDS carve-up ----------------------------------------------------------------------------------
+    ch_smem += (size_t)half * ch_lds_bytes_col<R>(np);
     R *sp = reinterpret_cast<R *>(ch_smem);
     auto take = [&](int n) { R *q = sp; sp += n; return q; };
     constexpr bool TAB = B.h2otable || B.co2bnd || B.oznbnd;
@@ -259,7 +277,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     const R *rec = A.rec + (size_t)i * CF_NFIELD * K1;
 
     // ---- P0: per-layer quantities of this band (lanes = layers) -------------------------------------------------
-    for (int k = lane; k <= np; k += 64) {
+    for (int k = lane; k <= np; k += CH_LPC) {
         const R pa = rec[CF_PA * K1 + k], dt = rec[CF_DT * K1 + k], dh2o = rec[CF_DH2O * K1 + k], dcont = rec[CF_DCONT * K1 + k],
                 dco2 = rec[CF_DCO2 * K1 + k], do3 = rec[CF_DO3 * K1 + k];
         if constexpr (TAB) { s_pa[k] = pa; s_dt[k] = dt; }
@@ -366,7 +384,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             const R tau2 = (wp * rec[CF_CWC2 * K1 + k]) * (awb[0] + (awb[1] + (awb[2] + awb[3] * r2) * r2) * r2);
             const R tau3 = (R)0.00307 * (wp * rec[CF_CWC3 * K1 + k]);
             const R tau4 = rs <= 0 ? (R)0 : (wp * rec[CF_CWC4 * K1 + k]) * (aib[0] + aib[1] / gr_pow<R>(rs, aib[2]));
-            A.taudiag[((size_t)(ibn - 1) * np + (k - 1)) * ld + i] = tau1 + tau2 + tau3 + tau4;
+            if (valid) A.taudiag[((size_t)(ibn - 1) * np + (k - 1)) * ld + i] = tau1 + tau2 + tau3 + tau4;
             R tauc = tau1 + tau2 + tau3 + tau4;
             const R fc = rec[CF_FCLD * K1 + k];
             if (tauc > (R)0.02 && fc > (R)0.01) {
@@ -397,7 +415,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                         ss = ss / ta_;
                         const R ff = (R).5 + ((R).3739 + ((R)0.0076 + (R)0.1185 * as) * as) * as;
                         ta_ = ta_ * ((R)1. - ss * ff);
-                        A.asya[j] = as; A.ssaa[j] = ss; A.taua[j] = ta_;
+                        if (valid) { A.asya[j] = as; A.ssaa[j] = ss; A.taua[j] = ta_; }
                     }
                     tae = gr_exp<R>((R)-1.66 * ta_);
                 }
@@ -448,7 +466,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     }
     if (lane == 0) { blayer[0] = blayer[1]; blayer[np + 1] = bs; }
     __syncthreads();
-    for (int k = lane; k <= np + 1; k += 64) {      // (:594-606)
+    for (int k = lane; k <= np + 1; k += CH_LPC) {      // (:594-606)
         R v;
         if (k >= 2 && k <= np) {
             const R dpk = rec[CF_DPPA * K1 + k] * (R)0.01, dpm = rec[CF_DPPA * K1 + k - 1] * (R)0.01;      // hPa like the reference
@@ -463,22 +481,22 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     int ncld0 = 0, ncld1 = 0, ncld2 = 0;
     {
         bool anyc = false;
-        for (int k = lane; k <= np; k += 64) anyc |= enn[k] > 0;
-        if (__any(anyc)) {
+        for (int k = lane; k <= np; k += CH_LPC) anyc |= enn[k] > 0;
+        if ((__ballot(anyc) & hmask) != 0) {
             const int ict = A.ict, icb = A.icb;
-            for (int k = lane; k <= np; k += 64) {
+            for (int k = lane; k <= np; k += CH_LPC) {
                 const int g0 = k < ict ? 0 : (k < icb ? ict : icb), g1 = k < ict ? ict - 1 : (k < icb ? icb - 1 : np);
                 const R e = enn[k];
                 int rank = 0;
                 for (int j = g0; j <= g1; j++) { const R ej = enn[j]; rank += (ej < e || (ej == e && j < k)) ? 1 : 0; }
                 icx[g0 + rank] = k;
             }
-            for (int k0 = 0; k0 <= np; k0 += 64) {
+            for (int k0 = 0; k0 <= np; k0 += CH_LPC) {
                 const int k = k0 + lane;
                 const bool pos = k <= np && enn[k] > 0;
-                ncld0 += __popcll(__ballot(pos && k < ict));
-                ncld1 += __popcll(__ballot(pos && k >= ict && k < icb));
-                ncld2 += __popcll(__ballot(pos && k >= icb));
+                ncld0 += __popcll(__ballot(pos && k < ict) & hmask);
+                ncld1 += __popcll(__ballot(pos && k >= ict && k < icb) & hmask);
+                ncld2 += __popcll(__ballot(pos && k >= icb) & hmask);
             }
         }
     }
@@ -571,7 +589,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     };
 
     // ---- P3: loop 1500 (:802-935): upward / downward emission of every single layer (lanes = layers) ------------------
-    for (int km = lane; km <= np; km += 64) {
+    for (int km = lane; km <= np; km += CH_LPC) {
         ChState<R> S; reset_state(S);
         R trant = 1;
         layer_tran(km, false, S, trant);
@@ -587,14 +605,14 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
         ad[km] = dn; au[km] = up;
     }
     if (lane == 0) { bu[np + 1] = bs; au[np + 1] = bs; cu[np + 1] = bs; du[np + 1] = bs; }
-    for (int k = lane; k < 4 * K2; k += 64) fdn[k] = 0;
+    for (int k = lane; k < 4 * K2; k += CH_LPC) fdn[k] = 0;
     __syncthreads();
     R *part = A.part + ((size_t)i * CH_NB + (ibn - 1)) * CH_NKIND * K2;
 
     // ---- P4: loop 2000 (:948-1290): lanes = k1, lock-step walk over k2 --------------------------------------------------
     R *flxd = fdn, *flcd = fdn + K2, *flad = fdn + 2 * K2, *flxad = fdn + 3 * K2;
     const int ict = A.ict, icb = A.icb;
-    for (int k1b = 0; k1b <= np; k1b += 64) {
+    for (int k1b = 0; k1b <= np; k1b += CH_LPC) {
         const int k1 = k1b + lane;
         const bool act = k1 <= np;
         ChState<R> S; reset_state(S);
@@ -653,7 +671,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             // (no s_waitcnt / s_barrier: the next step's loads overlap this step's stores)
             __builtin_amdgcn_wave_barrier();
         }
-        if (act) {      // parked where P5's loop index k == k1 of this same lane picks them up again
+        if (act && valid) {      // parked where P5's loop index k == k1 of this same lane picks them up again
             part[0 * K2 + k1] = axu; part[1 * K2 + k1] = acu; part[2 * K2 + k1] = aau; part[3 * K2 + k1] = axau;
             part[4 * K2 + k1] = trant * fclr; part[5 * K2 + k1] = taant * fclr; part[6 * K2 + k1] = trant; part[7 * K2 + k1] = taant;
             part[8 * K2 + k1] = k1 > 0 ? -dbs * (trant * fclr) : (R)0;
@@ -664,7 +682,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     // ---- P5: surface emission and reflection (:1292-1315), band partials to HBM ------------------------------------------
     const bool sfc = !B.b10bnd;
     const R fxd_s = flxd[np + 1], fcd_s = flcd[np + 1], fad_s = flad[np + 1], fxad_s = flxad[np + 1];
-    for (int k = lane; k <= np + 1; k += 64) {
+    for (int k = lane; k <= np + 1; k += CH_LPC) {
         R xu = 0, cu_ = 0, au_ = 0, xau = 0, df = 0, t0 = 1, t1 = 1, t2 = 1, t3 = 1;      // level np+1: nothing below it
         if (k <= np) {
             xu = part[0 * K2 + k]; cu_ = part[1 * K2 + k]; au_ = part[2 * K2 + k]; xau = part[3 * K2 + k];
@@ -679,6 +697,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                 xau = xau - fxad_s * t1 * rflxs;
             }
         }
+        if (!valid) continue;
         part[0 * K2 + k] = xu; part[1 * K2 + k] = cu_; part[2 * K2 + k] = au_; part[3 * K2 + k] = xau;
         part[4 * K2 + k] = flxd[k]; part[5 * K2 + k] = flcd[k]; part[6 * K2 + k] = flad[k]; part[7 * K2 + k] = flxad[k];
         part[8 * K2 + k] = df;

@@ -2052,7 +2052,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             hipLaunchKernelGGL(k_chou_prep<R>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, A);
             span_end(st);
             span_begin(11, st);
-            hipLaunchKernelGGL(k_chou_bands<R>, dim3((unsigned)nc, nband), dim3(64), lds, st, A, (const ChouDev<R> *)d_C);
+            hipLaunchKernelGGL(k_chou_bands<R>, dim3((unsigned)((nc + CH_CPW - 1) / CH_CPW), nband), dim3(64), lds, st, A, (const ChouDev<R> *)d_C);
             span_end(st);
             ChouOut<R> O{};
             auto Q = [&](int k) { return (R *)out[k] + c0; };
