@@ -557,7 +557,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     SwDev<R> h_S{};
     SwDev<R> *d_S = nullptr;
     bool have_sw = false;
-    char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0;
+    char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0, ws_sw_planes = 0;
     // Chou-Suarez SW tables + workspace
     char *d_tab_so = nullptr; size_t tab_so_bytes = 0;
     SoradDev<R> h_O{};
@@ -1657,7 +1657,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     }
 
     struct WsSw { R *sc; uint32_t *scidx; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *alpha, *rcorr, *taucmc, *ssacmc, *asmcmc, *cotsum, *cell, *part, *bsfc, *cot; };
-    size_t ws_layout_sw(int nc, int nlay, WsSw *w, char *base) const
+    size_t ws_layout_sw(int nc, int nlay, WsSw *w, char *base, int planes) const
     {
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return base ? base + o : (char *)nullptr; };
@@ -1675,22 +1675,28 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(NG_SW * cl * sizeof(R)); if (w) w->ssacmc = (R *)p;
         p = take(NG_SW * cl * sizeof(R)); if (w) w->asmcmc = (R *)p;
         p = take((size_t)3 * NG_SW * nc * sizeof(R)); if (w) w->cotsum = (R *)p;
-        p = take((size_t)14 * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
+        // parked planes of the band sweeps: k_sw_reform fp32 5 (gas optical depth + 2 x 2 upward reflectances), fp64 15 (no gas optical
+        // depth, 2 x 5 layer properties instead); k_sw_bands 14
+        // (the stage-dump instantiation is always k_sw_bands: sw_planes(true))
+        const size_t nplanes = (size_t)planes;
+        p = take(nplanes * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
         p = take((size_t)4 * SWR_SLOTS_MAX * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;      // per band (14) or per quad (32 slots)
         p = take((size_t)3 * SWR_SLOTS_MAX * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
         p = take((size_t)8 * 6 * nc * sizeof(R)); if (w) w->cot = (R *)p;
         return off;
     }
-    int ensure_ws_sw(int nc, int nlay)
+    int sw_planes(bool dbg) const { return (sw_path == 2 && !dbg) ? (sizeof(R) == 4 ? 5 : 15) : 14; }
+    int ensure_ws_sw(int nc, int nlay, int planes)
     {
-        if (d_ws_sw && nc <= ws_sw_ncol && nlay == ws_sw_nlay) return GEOSRAD_OK;
+        if (d_ws_sw && nc <= ws_sw_ncol && nlay == ws_sw_nlay && planes <= ws_sw_planes) return GEOSRAD_OK;
+        if (planes < ws_sw_planes) planes = ws_sw_planes;
         const int want = (d_ws_sw && nlay == ws_sw_nlay && nc < ws_sw_ncol) ? ws_sw_ncol : nc;
         if (d_ws_sw) { HIPCHK(hipFree(d_ws_sw)); d_ws_sw = nullptr; ws_sw_bytes = 0; }
-        const size_t need = ws_layout_sw(want, nlay, nullptr, nullptr);
+        const size_t need = ws_layout_sw(want, nlay, nullptr, nullptr, planes);
         hipError_t e = hipMalloc((void **)&d_ws_sw, need);
         if (e != hipSuccess) return fail(GEOSRAD_ENOMEM, "hipMalloc of the SW workspace failed (" + std::to_string(need >> 20) +
                                                          " MiB); lower it with geosrad_set_chunk()");
-        ws_sw_bytes = need; ws_sw_ncol = want; ws_sw_nlay = nlay;
+        ws_sw_bytes = need; ws_sw_ncol = want; ws_sw_nlay = nlay; ws_sw_planes = planes;
         return GEOSRAD_OK;
     }
 
@@ -1737,10 +1743,11 @@ template <typename R> struct Ctx : geosrad_ctx {
                       do_drfband, bndscl, indsolvar, dbg, nullptr);
     }
 
-    // RRTMG_SW band sweeps: fp32 re-forms the cell optics in its second sweep (k_sw_reform, 12 parked bytes per cell); in fp64 the second
-    // two-stream (IEEE divisions, double-precision exp / sqrt) costs more than the 32 parked bytes it would save (32.5 against 29.4 ms per
-    // 97 200 columns), so the fp64 instantiation keeps the first mapping (k_sw_bands); GEOSRAD_SW_PATH=bands selects it for fp32 too
-    bool sw_reform_on() const { return sw_path == 2 && sizeof(R) == 4; }
+    // RRTMG_SW band sweeps: k_sw_reform (lane = (column, unit of g-points); fp32 re-forms the cell optics in its second sweep and parks 12
+    // bytes per cell; in fp64 the second two-stream - IEEE divisions, double-precision exp / sqrt - costs more than the parked bytes it
+    // would save, 32.5 against 29.4 ms per 97 200 columns, so that instantiation parks the layer properties too);
+    // GEOSRAD_SW_PATH=bands selects the first mapping, k_sw_bands
+    bool sw_reform_on() const { return sw_path == 2; }
 
     // sw_na_out (SwOutIx order, all of SO_UFLX .. SO_COT0 + 7 non-null) requests an additional pass without the aerosol terms
     int sw_run(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
@@ -1766,13 +1773,13 @@ template <typename R> struct Ctx : geosrad_ctx {
         const long cap = (long)(0xFFFFFFFFull / ((unsigned long long)nlay * 12ull * sizeof(R))) & ~255L;
         int nc_max = ncol < chunk ? ncol : chunk;
         if ((long)nc_max > cap) nc_max = (int)cap;
-        rc = ensure_ws_sw(nc_max, nlay);
+        rc = ensure_ws_sw(nc_max, nlay, sw_planes(dbg != nullptr));
         if (rc) return rc;
 
         for (int c0 = 0; c0 < ncol; c0 += nc_max) {
             const int nc = (ncol - c0) < nc_max ? (ncol - c0) : nc_max;
             WsSw w;
-            ws_layout_sw(nc, nlay, &w, d_ws_sw);
+            ws_layout_sw(nc, nlay, &w, d_ws_sw, ws_sw_planes);
             SwArgs<R> A{};
             A.ncol = nc; A.ld = ncol; A.nlay = nlay; A.iceflg = iceflg; A.liqflg = liqflg; A.doy = dyofyr; A.cloudLM = cloudLM;
             A.cloudMH = cloudMH; A.iaer = iaer; A.normFlx = normFlx; A.do_drfband = do_drfband;

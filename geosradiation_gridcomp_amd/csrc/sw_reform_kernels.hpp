@@ -1,4 +1,4 @@
-// sw_reform_kernels.hpp -- RRTMG_SW band sweeps, lane = (column, band) like k_sw_bands (sw_kernels.hpp), with the second sweep
+// sw_reform_kernels.hpp -- RRTMG_SW band sweeps, lane = (column, unit of a band's g-points), with (fp32) the second sweep
 // RE-FORMING every cell's optics and layer properties instead of reading them back:
 //   sweep A (surface -> TOA): k-distribution, delta scaling, reftra_sw, upward adding (vrtqdr_sw :1453-1505); parks per cell the gas
 //     optical depth and the two upward reflectances at the cell's upper boundary - 12 bytes (fp32) instead of k_sw_bands' 28;
@@ -45,6 +45,10 @@ template <typename R, typename B, bool CLD, int GO, int NGU, int SLOT>
 GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV, int col, int nclear)
 {
     constexpr int NG = NGU, NGB = B::NG, IBM = B::JB - 15, G0 = B::G0;        // NG: g-points of this lane; NGB: of the band (strides)
+    // fp32 re-forms a cell's optics in the second sweep; in fp64 the second two-stream (IEEE divisions, double-precision exp / sqrt) costs
+    // more than the traffic it saves, so there the five layer properties are parked as well (planes 5 .. 9; the total sky's in cloudy
+    // cells: 10 .. 14) and read back - the unit mapping (small state, no spills, two wavefronts per SIMD instead of one) is what fp64 gains
+    constexpr bool REFORM = sizeof(R) == 4;
     constexpr int W = NG >= 4 ? 4 : 2;
     constexpr int NQ = (NG + W - 1) / W;
     constexpr int S = pad4(NGB);
@@ -191,7 +195,8 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                 const uint32_t ct4 = CT4(lay, g);
                 SwCell<R> c;
                 sw_cell_clear<R>(tg[j], tr[j], ta, om, as, prmu0, rmu0, c);
-                PST(0, ct4, tg[j]);
+                if constexpr (REFORM) PST(0, ct4, tg[j]);
+                else { PST(5, ct4, c.ref); PST(6, ct4, c.refd); PST(7, ct4, c.tra); PST(8, ct4, c.trad); PST(9, ct4, c.dbt); }
                 {   // upward adding (:1453-1505): reflectances of everything below the cell's upper boundary
                     const R zrj = f_rcp<R>((R)1. - prupd[g] * c.refd);
                     const R pu = c.ref + (c.trad * ((c.tra - c.dbt) * prupd[g] + c.dbt * prup[g])) * zrj;
@@ -207,7 +212,10 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                     if (ccol && !divg) { prupT[g] = prup[g]; prupdT[g] = prupd[g]; }
                     if (divg) {
                         SwCell<R> t = c;
-                        if (cellcld) sw_cell_cloud<R>(c, tcv[j], ocv[j], gcv[j], prmu0, rmu0, t);
+                        if (cellcld) {
+                            sw_cell_cloud<R>(c, tcv[j], ocv[j], gcv[j], prmu0, rmu0, t);
+                            if constexpr (!REFORM) { PST(10, ct4, t.ref); PST(11, ct4, t.refd); PST(12, ct4, t.tra); PST(13, ct4, t.trad); PST(14, ct4, t.dbt); }
+                        }
                         const R zrj = f_rcp<R>((R)1. - prupdT[g] * t.refd);
                         const R pu = t.ref + (t.trad * ((t.tra - t.dbt) * prupdT[g] + t.dbt * prupT[g])) * zrj;
                         const R pd = t.refd + t.trad * t.trad * prupdT[g] * zrj;
@@ -256,15 +264,18 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
     }
     // a group's parked values (gas optical depth; the clear sky's upward reflectances at the lower boundary) are requested one group
     // ahead of their use, a layer's Rayleigh / aerosol terms one layer ahead
-    struct Park { R tg[W], pu[W], pd[W]; };
+    struct Park { R tg[W], pu[W], pd[W], lp[REFORM ? 1 : 5][W]; };
     auto request = [&](int lay, int q, Park &b) {
         const int lu = lay > 0 ? lay - 1 : 0;      // (surface layer: a harmless repeat; replaced by the albedo on use)
 #pragma unroll
         for (int j = 0; j < W; j++) {
             const int g = q * W + j;
             b.tg[j] = 0; b.pu[j] = 0; b.pd[j] = 0;
+            if constexpr (!REFORM) { for (int k = 0; k < 5; k++) b.lp[k][j] = 0; }
             if (g >= NG) continue;
-            b.tg[j] = PLD(0, CT4(lay, g)); b.pu[j] = PLD(1, CT4(lu, g)); b.pd[j] = PLD(2, CT4(lu, g));
+            if constexpr (REFORM) b.tg[j] = PLD(0, CT4(lay, g));
+            else { for (int k = 0; k < 5; k++) b.lp[k][j] = PLD(5 + k, CT4(lay, g)); }
+            b.pu[j] = PLD(1, CT4(lu, g)); b.pd[j] = PLD(2, CT4(lu, g));
         }
     };
     struct Lay { R colmol, ta, om, as; uint32_t idx; R ca, cb2; };
@@ -323,7 +334,10 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                 if (wlc) {
 #pragma unroll
                     for (int j = 0; j < W; j++)
-                        if (q * W + j < NG) { tcv[j] = ldg(tcb, MC4(lay, q * W + j)); ocv[j] = ldg(ocb, MC4(lay, q * W + j)); gcv[j] = ldg(gcb, MC4(lay, q * W + j)); }
+                        if (q * W + j < NG) {
+                            tcv[j] = ldg(tcb, MC4(lay, q * W + j));
+                            if constexpr (REFORM) { ocv[j] = ldg(ocb, MC4(lay, q * W + j)); gcv[j] = ldg(gcb, MC4(lay, q * W + j)); }
+                        }
                 }
                 if (__ballot(anydv) != 0) {
 #pragma unroll
@@ -337,11 +351,25 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
             }
             // Rayleigh optical depth of the group (taur = colmol * rayl)
             R tr[W];
-            if (SwrRaylPerG<B>::value || q == 0) sw_rayl<R, B, W>(T, lower, cl.colmol, js, fs, GO + q * W, tr);
-            if constexpr (!SwrRaylPerG<B>::value) {
-                if (q == 0) tr0 = tr[0];
+            if constexpr (REFORM) {
+                if (SwrRaylPerG<B>::value || q == 0) sw_rayl<R, B, W>(T, lower, cl.colmol, js, fs, GO + q * W, tr);
+                if constexpr (!SwrRaylPerG<B>::value) {
+                    if (q == 0) tr0 = tr[0];
 #pragma unroll
-                for (int j = 0; j < W; j++) tr[j] = tr0;
+                    for (int j = 0; j < W; j++) tr[j] = tr0;
+                }
+            }
+            // fp64: the total sky's parked layer properties of the group's cloudy cells, behind one wave-uniform test
+            R tp[REFORM ? 1 : 5][W];
+            if constexpr (!REFORM && CLD) {
+                bool anycm = false;
+#pragma unroll
+                for (int j = 0; j < W; j++) anycm = anycm || (ccol && laycld && tcv[j] > 0);
+                if (__ballot(anycm) != 0) {
+#pragma unroll
+                    for (int j = 0; j < W; j++)
+                        if (q * W + j < NG) { for (int k = 0; k < 5; k++) tp[k][j] = PLD(10 + k, CT4(lay, q * W + j)); }
+                }
             }
 #pragma unroll
             for (int j = 0; j < W; j++) {
@@ -349,7 +377,8 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                 if (g >= NG) continue;
                 const R zi = zinc[g] * prmu0;
                 SwCell<R> c;
-                sw_cell_clear<R>(cur.tg[j], tr[j], cl.ta, cl.om, cl.as, prmu0, rmu0, c);
+                if constexpr (REFORM) sw_cell_clear<R>(cur.tg[j], tr[j], cl.ta, cl.om, cl.as, prmu0, rmu0, c);
+                else { c.tau = 0; c.om = 0; c.g = 0; c.ref = cur.lp[0][j]; c.refd = cur.lp[1][j]; c.tra = cur.lp[2][j]; c.trad = cur.lp[3][j]; c.dbt = cur.lp[4][j]; }
                 // downward adding recurrences (:1530-1572): values at the lower boundary of this layer
                 {
                     R zt, pr;
@@ -376,7 +405,8 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                     if (divg) {
                         dmask |= 1u << g;
                         SwCell<R> t = c;
-                        if (cm) sw_cell_cloud<R>(c, tcv[j], ocv[j], gcv[j], prmu0, rmu0, t);
+                        if constexpr (REFORM) { if (cm) sw_cell_cloud<R>(c, tcv[j], ocv[j], gcv[j], prmu0, rmu0, t); }
+                        else { if (cm) { t.ref = tp[0][j]; t.refd = tp[1][j]; t.tra = tp[2][j]; t.trad = tp[3][j]; t.dbt = tp[4][j]; } }
                         R zt, pr;
                         if (jk == 0) { zt = t.tra; pr = t.refd; }
                         else {
