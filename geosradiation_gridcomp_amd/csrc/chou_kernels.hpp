@@ -249,7 +249,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     const int icol = (int)blockIdx.x * CH_CPW + half;
     const bool valid = icol < A.m;                            // (odd column count: the last wavefront's second half computes along on
     const int i = valid ? icol : A.m - 1;                     //  the last column and writes nothing)
-    const unsigned long long hmask = CH_LPC == 64 ? ~0ull : (((1ull << CH_LPC) - 1ull) << (half * CH_LPC));
+    const unsigned long long hmask = CH_LPC == 64 ? ~0ull : (((1ull << (CH_LPC & 63)) - 1ull) << (half * CH_LPC));
     constexpr int ibn = IBN;
     const int np = A.np, K1 = np + 1, K2 = np + 2, ld = A.ld;
     constexpr ChBand B = ch_band(IBN);

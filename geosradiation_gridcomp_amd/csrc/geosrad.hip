@@ -939,7 +939,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.so[0] = 1; M.so[1] = 2; M.so[2] = 3; M.so[3] = 4;        // seed_order=[1,2,3,4] (rrtmg_lw_rad.F90:546)
             M.cwp_tiny = (R)1.e-20;                                       // rrtmg_lw_rad.F90:544
             M.play = A.play; M.cldf = A.cldf; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
-            M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
+            M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear; M.cftop = w.colcloudy;
             M.taucmc = A.taucmc; M.laycloudy = A.laycloudy; M.clearCounts = A.clearCounts; M.err = d_err;
             {
                 McPlan MP; int nseg = 0;
@@ -1813,7 +1813,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             M.so[0] = 4; M.so[1] = 3; M.so[2] = 2; M.so[3] = 1;        // seed_order=[4,3,2,1] (SW/rrtmg_sw_rad.F90:1401)
             M.cwp_tiny = (R)1.e-20;
             M.play = A.play; M.cldf = A.cld; M.ciwp = A.ciwp; M.clwp = A.clwp; M.rei = A.rei; M.rel = A.rel;
-            M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear;
+            M.alpha = A.alpha; M.rcorr = A.rcorr; M.perm = w.perm; M.nclear = w.nclear; M.cftop = w.colcloudy;
             M.taucmc = A.taucmc; M.ssacmc = A.ssacmc; M.asmcmc = A.asmcmc; M.laycloudy = A.laycloudy; M.cotsum = A.cotsum; M.clearCounts = A.clearCounts; M.err = d_err + 1;
             {
                 McPlan MP; int nseg = 0;

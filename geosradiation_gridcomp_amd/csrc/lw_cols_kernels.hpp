@@ -284,7 +284,7 @@ GR_DEV void lwc_band(const LwArgs<R> &A, const LwOut<R> &O, const LwDev<R> &T, R
                         }
                         R odepth = secdiff * (tau[j] + ta);
                         if (odepth < 0) odepth = 0;
-                        const R tblind = odepth / (bpade + odepth);
+                        const R tblind = lw_pade<R>(odepth, bpade);
                         itg[j] = (int)(tblint * tblind + (R)0.5);
                         eg[j] = lut_at(itg[j]);
                     }
@@ -309,7 +309,7 @@ GR_DEV void lwc_band(const LwArgs<R> &A, const LwOut<R> &O, const LwDev<R> &T, R
                             if (tc > 0) {
                                 // cloud added to the DISCRETISED gas optical depth (:264-268)
                                 const R odtot = ldg(T.tau_tbl, (uint32_t)itg[j] * (uint32_t)sizeof(R)) + secdiff * tc;
-                                const R tb2 = odtot / (bpade + odtot);
+                                const R tb2 = lw_pade<R>(odtot, bpade);
                                 const int ittot = (int)(tblint * tb2 + (R)0.5);
                                 const R2 e2 = lut_at(ittot);
                                 *LWC_CELL(bcur, 0, gl, S.lay, S.c) = (R)1. - e2.x;

@@ -81,7 +81,7 @@ template <typename R> struct LwArgs {
     R *sc;                       // [SC_NFIELD][nlay][ncol]
     uint32_t *scidx;             // [nlay][ncol]
     R *pwvcm;                    // [ncol]
-    uint8_t *colcloudy;          // [ncol]  any cldf > 0 in the column
+    uint8_t *colcloudy;          // [ncol]  1 + the highest layer with cldf > 0 (0: none)
     int32_t *perm;               // [ncol]  compacted position -> column of the batch: clear columns first, then cloudy (stable)
     int32_t *nclear;             // [1]     number of clear columns of the batch
     uint8_t *laycloudy;          // [nlay][ncol]  optically cloudy for ANY g-point (cldprmc's `cloudy`)

@@ -82,8 +82,9 @@ template <> GR_DEV void stg_nt<double2>(double2 *base, uint32_t byteoff, double2
 // k_validate_pwv: one thread per column.
 //   - the reference's input assertions (LW/rrtmg_lw_rad.F90:209-318) -> error bits
 //   - pwvcm (LW/rrtmg_lw_setcoef.F90:206-272), same summation order (bottom-up)
-//   - colcloudy = any(cldf > 0): lets later kernels skip McICA work for clear columns without
-//     changing results (all masks false, clearCounts = ngpt)
+//   - colcloudy = 1 + the highest layer with cldf > 0 (0: none; nlay <= mxlay = 203 fits a byte): lets later kernels skip McICA
+//     work for clear columns, and the generator stop above a wave's highest cloud, without changing results (all
+//     masks false, clearCounts = ngpt)
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R> *__restrict__ T)
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
     const R *chk[17] = {A.play, A.tlay, A.h2o, A.o3, A.co2, A.ch4, A.n2o, A.o2, A.cfc11, A.cfc12, A.cfc22, A.ccl4,
                         A.cldf, A.ciwp, A.clwp, A.rei, A.rel};
     R amttl = 0, wvttl = 0;
-    bool cloudy = false;
+    int cftop = 0;
     R pprev = A.plev[col];
     if (pprev < 0 || A.tlev[col] < 0) err |= 1u << 17;
     for (int lay = 0; lay < nlay; lay++) {
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
         const R btemp = h2o * coldry;
         amttl = amttl + coldry + btemp;
         wvttl = wvttl + btemp;
-        if (A.cldf[i] > 0) cloudy = true;
+        if (A.cldf[i] > 0) cftop = lay + 1;
         // pressure ordering (LW/rrtmg_lw_setcoef.F90:443-453): lower-atmosphere layer above an upper one
         pprev = pup;
     }
@@ -125,7 +126,8 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
         if (A.emis[(size_t)ib * ld + col] < 0) err |= 1u << 19;
     const R wvsh = (amw * wvttl) / (amd * amttl);
     A.pwvcm[col] = wvsh * ((R)1.e3 * A.plev[col]) / ((R)1.e2 * grav);
-    A.colcloudy[col] = cloudy ? 1 : 0;
+    const bool cloudy = cftop > 0;
+    A.colcloudy[col] = (uint8_t)cftop;
     // clear column: all sub-columns clear in every super-layer (cloud_subcol_gen.F90:649-659);
     // cloudy column: k_mcica's (column, band) threads add their counts
     for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = cloudy ? 0 : NG_LW;
@@ -148,6 +150,10 @@ __global__ void __launch_bounds__(256) k_validate_pwv(LwArgs<R> A, const LwDev<R
 // by perm[position].  256-column blocks are then homogeneous (at most one mixed block), so clear blocks run the
 // cheaper clear-sky instantiation whatever the spatial distribution of the cloudy columns, and no wave
 // carries idle cloudy-only work for its clear lanes.  Columns are independent: the permutation does not touch results.
+// (Ordering the cloudy columns by cloud top as well, so that the per-wave decisions of the cloudy instantiations - the generator's
+// walk up to the wave's highest cloud, the band kernels' cloud path per layer - see similar neighbours, was measured both batch-wide
+// and inside 256-column blocks: k_mcica gains 0.45 ms batch-wide, but every array read in the caller's column order then costs
+// more cache lines per wave and k_sw_reform loses 0.2-0.25 ms; the step does not move - profiles/r03_mcica_cloudtop.md.)
 // ---------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(1024) k_partition(int ncol, const uint8_t *__restrict__ colcloudy, int32_t *__restrict__ perm,
                                                     int32_t *__restrict__ nclear)
@@ -1023,6 +1029,15 @@ template <typename R> constexpr size_t lw_bands_lds_bytes() { return LwLutInLds<
 __host__ __device__ constexpr int lw_nfraca(int ib) { constexpr int n[17] = {0, 1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9}; return n[ib]; }
 __host__ __device__ constexpr int lw_nfracb(int ib) { constexpr int n[17] = {0, 1, 1, 5, 5, 5, 0, 1, 1, 1, 1, 1, 0, 1, 1, 0, 1}; return n[ib]; }
 
+// Pade variable of an optical depth, od / (bpade + od) (LW/rrtmg_lw_rtrnmc.F90:264-268): the index into the transmittance table.
+// fp32: the hardware reciprocal (1 ulp) instead of the correctly rounded quotient's ten dependent instructions; a quotient within
+// ~1e-7 of a rounding boundary of the 10 000-entry table then lands in the neighbouring entry, which evaluation-order differences
+// between two fp32 builds of the reference do as well (in-run parity against the fp32 oracle: 1.8e-3 W m-2 with, 2.7e-3 without)
+template <typename R> GR_DEV R lw_pade(R od, R bpade) { return od / (bpade + od); }
+#ifndef LW_EXACT_DIV
+template <> GR_DEV float lw_pade<float>(float od, float bpade) { return od * __builtin_amdgcn_rcpf(bpade + od); }
+#endif
+
 template <typename R, typename BAND, bool CLD, bool DBG>
 GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclear, const typename Vec2<R>::T *luts)
 {
@@ -1150,7 +1165,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 }
                 R odepth = secdiff * (tau[j] + ta);
                 if (odepth < 0) odepth = 0;
-                const R tblind = odepth / (bpade + odepth);
+                const R tblind = lw_pade<R>(odepth, bpade);
                 itg[j] = (int)(tblint * tblind + (R)0.5);
                 eg[j] = lut_at(itg[j]);
             }
@@ -1190,7 +1205,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                         cldcell = true;
                         // cloud added to the DISCRETISED gas tau (:264-268)
                         const R odtot = ldg(T.tau_tbl, (uint32_t)itgas * (uint32_t)sizeof(R)) + secdiff * tc;
-                        const R tb2 = odtot / (bpade + odtot);
+                        const R tb2 = lw_pade<R>(odtot, bpade);
                         const int ittot = (int)(tblint * tb2 + (R)0.5);
                         itp = ittot;
                         const R2 e2 = lut_at(ittot);
@@ -1267,7 +1282,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                 }
                 R odepth = secdiff * (tau[j] + ta);
                 if (odepth < 0) odepth = 0;
-                const R tblind = odepth / (bpade + odepth);
+                const R tblind = lw_pade<R>(odepth, bpade);
                 itg[j] = (int)(tblint * tblind + (R)0.5);
                 eg[j] = lut_at(itg[j]);
                 anyc = anyc || tcv[j] > 0;
@@ -1291,7 +1306,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     // cloud added to the DISCRETISED gas tau (:264-268); evaluated for the whole wave, kept for the cloudy cells
                     const bool cld = tcv[j] > 0;
                     const R odtot = ttb[j] + secdiff * tcv[j];
-                    const R tb2 = odtot / (bpade + odtot);
+                    const R tb2 = lw_pade<R>(odtot, bpade);
                     const int ittot = (int)(tblint * tb2 + (R)0.5);
                     itp = cld ? ittot : itg[j];
                     const R2 e2 = lut_at(itp);

@@ -339,6 +339,7 @@ template <typename R> struct McArgs {
     const R *play, *cldf, *ciwp, *clwp, *rei, *rel;
     const R *alpha, *rcorr;            // [nlay][ncol]
     const int32_t *perm, *nclear;      // k_partition's compaction (null: identity, all columns)
+    const uint8_t *cftop;              // [ncol] original order: 1 + the highest layer with cloud fraction (null: walk every layer)
     // MODE 0
     R *taucmc; uint8_t *laycloudy; int32_t *clearCounts; uint32_t *err;
     // MODE 1
@@ -396,7 +397,20 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
     uint32_t any_all = 0, any_hi = 0, any_mid = 0, any_lo = 0;      // bit s: sub-column s has a cloudy cell (in the super-layer)
     uint32_t err = 0;
 
-    for (int il = 0; il < nlay; il++) {
+    // The walk ends above the highest layer in which a column of the wave has cloud fraction: the reference walks on to the top
+    // (the streams are consumed for every layer), but a layer without cloud fraction is clear in every sub-column whatever is drawn,
+    // nothing above reads the streams again, and nothing is written for such a layer.  In RRTMG's ordering (surface first) that is
+    // the whole stratosphere.
+    int lend = nlay;
+    if (PLANES && M.cftop) {
+        const int t = (int)M.cftop[pc];
+        int m = 0;                         // maximum over the wave's active lanes, bit by bit (ballots only see active lanes)
+#pragma unroll
+        for (int b = 7; b >= 0; b--)
+            if (__ballot(t >= (m | (1 << b))) != 0) m |= 1 << b;
+        lend = m < nlay ? m : nlay;
+    }
+    for (int il = 0; il < lend; il++) {
         const size_t w = (size_t)il * n + col, a = (size_t)il * ld + pc;
         const R al = il > 0 ? M.alpha[w] : (R)0;
         const R rc = (inhomo && il > 0) ? M.rcorr[w] : (R)0;
@@ -555,7 +569,7 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
     const int col0 = (int)(fb / nsub), nst = ncw * nlay;
     R *const cwi = tile + 64 * rs, *const cwl = cwi + nst, *const cfs = cwl + nst, *const als = cfs + nst, *const rcs = als + nst;
     int *const colflag = reinterpret_cast<int *>(rcs + nst);
-    if (lane < ncw) colflag[lane] = 0;
+    for (int i = lane; i < ncw; i += 64) colflag[i] = 0;
     __builtin_amdgcn_wave_barrier();
     {
         int c = 0, l = lane;
@@ -565,7 +579,7 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
             const size_t a = (size_t)l * ld + cc, w = (size_t)l * n + cc;
             const R v0 = M.ciwp[a], v1 = M.clwp[a], v2 = M.cldf[a], v3 = M.alpha[w], v4 = inhomo ? M.rcorr[w] : (R)0;
             cwi[i] = v0; cwl[i] = v1; cfs[i] = v2; als[i] = v3; rcs[i] = v4;
-            if (v2 > 0) colflag[c] = 1;              // every writer writes 1
+            if (v2 > 0) atomicMax(&colflag[c], l + 1);   // 1 + the column's highest layer with cloud fraction (0: none)
             l += 64;
             while (l >= nlay) { l -= nlay; c++; }
         }
@@ -578,9 +592,19 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
     const long f = active ? f0 + lane : ntot - 1;
     const int col = (int)(f / nsub), isub = (int)(f - (long)col * nsub);
     const int cofs = (col - col0) * nlay;
-    const bool colcloudy = active && colflag[col - col0] != 0;
+    const int cftop = active ? colflag[col - col0] : 0;
+    const bool colcloudy = cftop != 0;
     const bool wave_cloudy = __ballot(colcloudy) != 0;
     if (wave_cloudy) {
+        // the walk ends above the wave's highest layer with cloud fraction (k_mcica): the cells above are clear whatever is drawn
+        int wtop = 0;
+#pragma unroll
+        for (int b = 15; b >= 0; b--)
+            if (__ballot(cftop >= (wtop | (1 << b))) != 0) wtop |= 1 << b;
+        constexpr int MC_G = 4;
+        int nl = (wtop + MC_G - 1) & ~(MC_G - 1);
+        nl = nl < nlay ? nl : nlay;
+        for (int il = nl; il < nlay; il++) tile[lane * rs + il] = (R)-1;
         Kiss k1 = kiss_seed<R>(M.play, ld, nlay, col, surface_at_one, M.so);
         if (isub > 0) {       // n = 0 must stay the identity (a raw seed may be a non-canonical MWC residue)
             KissJump J = jsubs[isub];
@@ -592,13 +616,12 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
         // layers in groups of MC_G: the group's draws (integer work only), then the previous group's scaling factors are combined
         // and stored, then this group's table values are requested - a request has a whole group's arithmetic to arrive in;
         // the layer inputs of the next group are requested a group ahead as well
-        constexpr int MC_G = 4;
         ZcwReq<R> pq[MC_G];
         bool pcl[MC_G];
 #pragma unroll
         for (int k = 0; k < MC_G; k++) { pcl[k] = false; pq[k].v0 = pq[k].v1 = pq[k].v2 = pq[k].v3 = pq[k].r1 = pq[k].r2 = 0; }
         bool ppend = false;
-        for (int g0 = 0; g0 < nlay + MC_G; g0 += MC_G) {      // one extra trip stores the last group
+        for (int g0 = 0; g0 < nl + MC_G; g0 += MC_G) {        // one extra trip stores the last group
             R al[MC_G], rc[MC_G], cf[MC_G];
 #pragma unroll
             for (int k = 0; k < MC_G; k++) {
@@ -612,7 +635,7 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
             for (int k = 0; k < MC_G; k++) {
                 const int il = g0 + k;
                 cl[k] = false; c3[k] = 0; sg[k] = 1;
-                if (il >= nlay) continue;
+                if (il >= nl) continue;
                 const R thr = nf_sub((R)1., cf[k]);
                 sg[k] = cf[k] > (R)0.99 ? (R)0.5 : (cf[k] > (R)0.9 ? (R)0.71 : (R)1.0);
                 // cloud presence with exponential overlap (:406-414)
@@ -634,7 +657,7 @@ __global__ void __launch_bounds__(64) k_mcica_sa(McArgs<R> M, const KissJump *__
 #pragma unroll
             for (int k = 0; k < MC_G; k++) {
                 const int il = g0 - MC_G + k;
-                if (il < 0 || il >= nlay) continue;
+                if (il < 0 || il >= nl) continue;
                 const R z = ppend ? zcw_combine<R>(pq[k]) : (R)1;
                 tile[lane * rs + il] = pcl[k] ? z : (R)-1;
             }

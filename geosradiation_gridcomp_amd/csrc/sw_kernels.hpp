@@ -60,7 +60,7 @@ template <typename R> struct SwArgs {
     const R *tauaer, *ssaaer, *asmaer, *coszen, *asdir, *asdif, *aldir, *aldif;
     // workspace
     R *sc; uint32_t *scidx;              // setcoef record [SW_NFIELD][nlay][ncol] + packed indices
-    uint8_t *colcloudy;                  // [ncol] any cld > 0, original column order
+    uint8_t *colcloudy;                  // [ncol] 1 + highest layer with cld > 0 (0: none), original column order
     int32_t *perm, *nclear;              // k_partition: compacted position -> column; number of clear columns
     R *alpha, *rcorr;
     R *taucmc, *ssacmc, *asmcmc;         // McICA cloud optics, band-major planes [band][lay][g][col]
@@ -90,18 +90,19 @@ __global__ void __launch_bounds__(256) k_sw_validate(SwArgs<R> A)
     const int ld = A.ld, nlay = A.nlay;
     uint32_t err = 0;
     const R *chk[12] = {A.play, A.tlay, A.h2o, A.o3, A.co2, A.ch4, A.o2, A.cld, A.ciwp, A.clwp, A.rei, A.rel};
-    bool cloudy = false;
+    int cftop = 0;
     for (int lay = 0; lay < nlay; lay++) {
         const size_t i = (size_t)lay * ld + col;
 #pragma unroll
         for (int k = 0; k < 12; k++)
             if (chk[k][i] < 0) err |= 1u << k;
         if (A.plev[i] < 0) err |= 1u << SWERR_PLEV;
-        if (A.cld[i] > 0) cloudy = true;
+        if (A.cld[i] > 0) cftop = lay + 1;
     }
     if (A.plev[(size_t)nlay * ld + col] < 0) err |= 1u << SWERR_PLEV;
     if (A.asdir[col] < 0 || A.aldir[col] < 0 || A.asdif[col] < 0 || A.aldif[col] < 0) err |= 1u << SWERR_ALB;
-    A.colcloudy[col] = cloudy ? 1 : 0;
+    const bool cloudy = cftop > 0;
+    A.colcloudy[col] = (uint8_t)cftop;       // 1 + the highest layer with cloud fraction (lw_kernels.hpp k_validate_pwv)
     for (int k = 0; k < 4; k++) A.clearCounts[(size_t)k * ld + col] = cloudy ? 0 : NG_SW;   // rrtmg_sw_rad.F90:1520-1523
     if (err) atomicOr(A.err, err);
 }

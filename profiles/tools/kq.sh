@@ -11,7 +11,7 @@ f=glob.glob("gpurun_out/ks_$TAG/**/x_kernel_stats.csv", recursive=True)[0]
 out=[]
 for r in csv.DictReader(open(f)):
     n=r["Name"]
-    if "k_sw_bands" in n or "k_sw_reform" in n or "k_sw_reduce" in n or "k_lw_bands" in n or "k_swr" in n:
+    if "k_sw_bands" in n or "k_sw_reform" in n or "k_sw_reduce" in n or "k_lw_bands" in n or "k_swr" in n or "k_mcica" in n:
         short=n.split("geosrad::")[1].split("(")[0]
         out.append("%s=%.3f" % (short, float(r["AverageNs"])/1e6))
 print("$TAG", " ".join(sorted(out)))

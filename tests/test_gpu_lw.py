@@ -125,6 +125,41 @@ def test_against_oracle_on_fresh_columns(gpu_ctx, rk):
     ctx.set_inhomogeneity(0); clib.set_inhomogeneity(0, kind)
 
 
+def test_generator_stops_at_the_waves_highest_cloud(gpu_ctx):
+    """k_mcica ends its walk above the highest layer in which a column of the wave has cloud fraction (the reference consumes the streams
+    up to the top; nothing there can become cloudy).  Cloud tops from the lowest to the very top layer inside one 64-column wave, a wave
+    whose only cloud is the top layer, one with cloud in the lowest layer only: clearCounts and fluxes of RRTMG_LW and RRTMG_SW against
+    the oracle in fp64 (which walks every layer)."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    n, nlay = 192, 72
+    inp = synth.make_columns(n, nlay, start=777, aerosol=True, cloudy_frac=1.0)
+    cldf, clwp, ciwp = inp["cldf"].copy(), inp["clwp"].copy(), inp["ciwp"].copy()
+    cldf[:, 64:] = 0; clwp[:, 64:] = 0; ciwp[:, 64:] = 0
+    for c in range(0, 64, 3):                         # wave 0: the synthetic decks + a thin cloud anywhere up to the top layer
+        l = (c * 71) // 63
+        cldf[l, c] = 0.4; ciwp[l, c] = 6.0
+    cldf[nlay - 1, 64 + 17] = 0.7; ciwp[nlay - 1, 64 + 17] = 3.0          # wave 1: one column, top layer only
+    cldf[0, 128 + 5] = 0.5; clwp[0, 128 + 5] = 40.0                       # wave 2: one column, lowest layer only
+    inp.update(cldf=cldf, clwp=clwp, ciwp=ciwp)
+    ctx = gpu_ctx[8]
+    ctx.set_inhomogeneity(1); clib.set_inhomogeneity(1, "r8")
+    try:
+        o = ctx.rrtmg_lw_columns(inp); r = clib.rrtmg_lw(inp, "r8")
+        q = ctx.rrtmg_sw_columns(inp, iaer=10, normFlx=1); qr = clib.rrtmg_sw(inp, prec="r8", iaer=10, normFlx=1)
+    finally:
+        ctx.set_inhomogeneity(0); clib.set_inhomogeneity(0, "r8")
+    assert r["rc"] == 0 and qr["rc"] == 0
+    np.testing.assert_array_equal(o["clearCounts"], r["clearCounts"])
+    np.testing.assert_array_equal(q["clearCounts"], qr["clearCounts"])
+    assert (o["clearCounts"][0, 64 + 17] < 140) and (o["clearCounts"][0, 128 + 5] < 140)
+    for k in FLUX:
+        if "dTs" not in k:
+            assert np.abs(o[k] - r[k]).max() <= TOL_FLUX[8], k
+    for k in ("swuflx", "swdflx", "swuflxc", "swdflxc"):
+        assert np.abs(q[k] - qr[k]).max() <= 1e-9, k
+
+
 def test_chunking_is_invisible(gpu_ctx):
     from geosradiation_gridcomp_amd import synth
     ctx = gpu_ctx[4]
