@@ -456,6 +456,20 @@ class Context:
             ci(int(lcldmh)), ci(normflx), None if bs is None else _p(bs), None if ins is None else _p(ins),
             self._ptr_array(G.SWD_OUT, ptr)))
 
+    def sw_driver_chou_dev(self, stream, ncol, lm, ptr, consts, lcldmh, lcldlm, hk_uv, hk_ir, do_drfband=False):
+        """Chou-Suarez branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:4484-4572, SHRTWAVE :6597-6672):
+        `ptr` holds device pointers of gridcomp.SWC_IN (TAUA / SSAA / ASYA may be missing: no aerosols) and gridcomp.SWC_OUT;
+        consts in the order of gridcomp.SWC_CONST; hk_uv (5) and hk_ir (memory order of the Fortran (3,10), as for sorad_dev) host arrays
+        (HK_UV_TEMP, HK_IR_TEMP)."""
+        from . import gridcomp as G
+        ci = ctypes.c_int
+        cs = (ctypes.c_double * len(G.SWC_CONST))(*consts)
+        hu = np.ascontiguousarray(hk_uv, dtype=self.dtype)
+        hi = np.ascontiguousarray(hk_ir, dtype=self.dtype)
+        self._chk(self.L.geosrad_sw_driver_chou_dev(self.h, ctypes.c_void_p(stream), ci(ncol), ci(lm), self._ptr_array(G.SWC_IN, ptr), cs,
+                                                    ci(int(lcldmh)), ci(int(lcldlm)), _p(hu), _p(hi), ci(1 if do_drfband else 0),
+                                                    self._ptr_array(G.SWC_OUT, ptr)))
+
     def lw_chou_post_dev(self, stream, ncol, lm, ptr):
         """after irrad in the Chou-Suarez branch of LW_Driver (GEOS_IrradGridComp.F90:2101-2108, :3601-3616): gridcomp.LWC_IN / LWC_OUT"""
         from . import gridcomp as G

@@ -492,6 +492,8 @@ struct geosrad_ctx {
                               int liqflg, double sc, double dist, int isolvar, int dyofyr, int include_aerosols, int lcldlm,
                               int lcldmh, int normflx, const void *bndsolvar, const void *indsolvar, void *const *out) = 0;
     virtual int lw_chou_post_dev(hipStream_t st, int ncol, int lm, const void *const *in, void *const *out) = 0;
+    virtual int sw_driver_chou_dev(hipStream_t st, int ncol, int lm, const void *const *in, const double *consts, int lcldmh, int lcldlm,
+                                   const void *hk_uv, const void *hk_ir, int do_drfband, void *const *out) = 0;
     virtual int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
                                   const void *const *in, void *const *out) = 0;
     virtual int lw_update_rats_dev(hipStream_t st, int ncol, int lm, int nrats, const void *const *in, void *const *out) = 0;
@@ -564,6 +566,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     SoradDev<R> *d_O = nullptr;
     bool have_sorad = false;
     char *d_ws_so = nullptr; size_t ws_so_bytes = 0;
+    char *d_ws_swc = nullptr; size_t ws_swc_bytes = 0;      // sw_driver_chou_dev: the arrays SORADCORE prepares for sorad
     // Chou-Suarez LW tables + workspace
     char *d_tab_ch = nullptr; size_t tab_ch_bytes = 0;
     ChouDev<R> h_C{};
@@ -597,6 +600,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (d_tab_so) (void)hipFree(d_tab_so);
         if (d_O) (void)hipFree(d_O);
         if (d_ws_so) (void)hipFree(d_ws_so);
+        if (d_ws_swc) (void)hipFree(d_ws_swc);
         if (d_C) (void)hipFree(d_C);
         if (d_ws_ch) (void)hipFree(d_ws_ch);
         for (char *q : d_ws_drvs) if (q) (void)hipFree(q);
@@ -1226,6 +1230,50 @@ template <typename R> struct Ctx : geosrad_ctx {
         hipLaunchKernelGGL((k_lwd_chou_post<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, P);
         HIPCHK(hipGetLastError());
         return GEOSRAD_OK;
+    }
+
+    // Chou-Suarez branch of SORADCORE: k_swc_prep + sorad_dev.  The prepared arrays live in a buffer of their own (sorad_dev's scratch is
+    // sized per chunk, these per call).
+    int sw_driver_chou_dev(hipStream_t st, int ncol, int lm, const void *const *in, const double *consts, int lcldmh, int lcldlm,
+                           const void *hk_uv, const void *hk_ir, int do_drfband, void *const *out) override
+    {
+        HIPCHK(hipSetDevice(device));
+        if (ncol <= 0 || lm < 4) return fail(GEOSRAD_EINVAL, "bad ncol/lm");
+        if (!consts) return fail(GEOSRAD_EINVAL, "consts null");
+        const bool aer = in[GEOSRAD_SWC_TAUA] != nullptr;
+        if (aer != (in[GEOSRAD_SWC_SSAA] != nullptr) || aer != (in[GEOSRAD_SWC_ASYA] != nullptr))
+            return fail(GEOSRAD_EINVAL, "TAUA / SSAA / ASYA: all three or none");
+        for (int k = 0; k < GEOSRAD_SWC_NIN; k++)
+            if (!in[k] && !(k >= GEOSRAD_SWC_TAUA && k <= GEOSRAD_SWC_ASYA)) return fail(GEOSRAD_EINVAL, "null input field");
+        const size_t cell = (size_t)ncol * sizeof(R);
+        const size_t o_plh = 0, o_o3 = o_plh + al((size_t)(lm + 1) * cell), o_qq = o_o3 + al((size_t)lm * cell), o_rr = o_qq + al((size_t)4 * lm * cell),
+                     o_zero = o_rr + al((size_t)4 * lm * cell), need = o_zero + (aer ? 0 : al((size_t)8 * lm * cell));
+        if (need > ws_swc_bytes) {
+            if (d_ws_swc) { HIPCHK(hipFree(d_ws_swc)); d_ws_swc = nullptr; ws_swc_bytes = 0; }
+            if (hipMalloc((void **)&d_ws_swc, need) != hipSuccess) return fail(GEOSRAD_ENOMEM, "SORADCORE (Chou-Suarez) workspace");
+            ws_swc_bytes = need;
+        }
+        SwcPrep<R> P{};
+        P.ncol = ncol; P.lm = lm;
+        P.ple = (const R *)in[GEOSRAD_SWC_PLE]; P.ox = (const R *)in[GEOSRAD_SWC_OX];
+        for (int s = 0; s < 4; s++) { P.q[s] = (const R *)in[GEOSRAD_SWC_QI + s]; P.r[s] = (const R *)in[GEOSRAD_SWC_RI + s]; }
+        P.o3fac = (R)consts[GEOSRAD_SWC_C_O3MW] / (R)consts[GEOSRAD_SWC_C_AIRMW]; P.undef = (R)consts[GEOSRAD_SWC_C_UNDEF];
+        P.plhpa = (R *)(d_ws_swc + o_plh); P.o3 = (R *)(d_ws_swc + o_o3); P.qq3 = (R *)(d_ws_swc + o_qq); P.rr3 = (R *)(d_ws_swc + o_rr);
+        hipLaunchKernelGGL((k_swc_prep<R>), dim3((unsigned)((ncol + 255) / 256), lm + 1), dim3(256), 0, st, P);
+        HIPCHK(hipGetLastError());
+        const void *zero = d_ws_swc + o_zero;          // TAUA = SSAA = ASYA = 0 (SOL:4543-4546): one block serves the three
+        if (!aer) HIPCHK(hipMemsetAsync(d_ws_swc + o_zero, 0, (size_t)8 * lm * cell, st));
+        const void *si[SI_NIN];
+        si[SI_COSZ] = in[GEOSRAD_SWC_ZT]; si[SI_PL] = P.plhpa; si[SI_TA] = in[GEOSRAD_SWC_T]; si[SI_WA] = in[GEOSRAD_SWC_Q]; si[SI_OA] = P.o3;
+        si[SI_CWC] = P.qq3; si[SI_FCLD] = in[GEOSRAD_SWC_CL]; si[SI_REFF] = P.rr3;
+        si[SI_TAUA] = aer ? in[GEOSRAD_SWC_TAUA] : zero; si[SI_SSAA] = aer ? in[GEOSRAD_SWC_SSAA] : zero; si[SI_ASYA] = aer ? in[GEOSRAD_SWC_ASYA] : zero;
+        si[SI_RSUVBM] = in[GEOSRAD_SWC_ALBVR]; si[SI_RSUVDF] = in[GEOSRAD_SWC_ALBVF]; si[SI_RSIRBM] = in[GEOSRAD_SWC_ALBNR]; si[SI_RSIRDF] = in[GEOSRAD_SWC_ALBNF];
+        void *so[SOO_NOUT];
+        so[SOO_FLX] = out[GEOSRAD_SWC_FSW]; so[SOO_FLC] = out[GEOSRAD_SWC_FSC]; so[SOO_FLXU] = out[GEOSRAD_SWC_FSWU]; so[SOO_FLCU] = out[GEOSRAD_SWC_FSCU];
+        so[SOO_FDIRIR] = out[GEOSRAD_SWC_NIRR]; so[SOO_FDIFIR] = out[GEOSRAD_SWC_NIRF]; so[SOO_FDIRPAR] = out[GEOSRAD_SWC_PARR];
+        so[SOO_FDIFPAR] = out[GEOSRAD_SWC_PARF]; so[SOO_FDIRUV] = out[GEOSRAD_SWC_UVRR]; so[SOO_FDIFUV] = out[GEOSRAD_SWC_UVRF];
+        so[SOO_SFCBAND] = out[GEOSRAD_SWC_FSWBAND]; so[SOO_DRBAND] = out[GEOSRAD_SWC_DRBAND]; so[SOO_DFBAND] = out[GEOSRAD_SWC_DFBAND];
+        return sorad_dev(st, ncol, lm, 8, si, consts[GEOSRAD_SWC_C_CO2], lcldmh, lcldlm, hk_uv, hk_ir, so, do_drfband);
     }
 
     int lw_update_flx_dev(hipStream_t st, int ncol, int lm, int rrtmg, int lev_mid_high, int lev_low_mid, double undef,
@@ -2475,6 +2523,8 @@ struct MultiCtx final : geosrad_ctx {
     int sw_driver_dev(hipStream_t, int, int, int, const void *const *, const double *, int, int, double, double, int, int, int, int, int, int,
                       const void *, const void *, void *const *) override { return nodev("geosrad_sw_driver_rrtmg_dev"); }
     int lw_chou_post_dev(hipStream_t, int, int, const void *const *, void *const *) override { return nodev("geosrad_lw_chou_post_dev"); }
+    int sw_driver_chou_dev(hipStream_t, int, int, const void *const *, const double *, int, int, const void *, const void *, int,
+                           void *const *) override { return nodev("geosrad_sw_driver_chou_dev"); }
     int lw_update_flx_dev(hipStream_t, int, int, int, int, int, double, const void *const *, void *const *) override { return nodev("geosrad_lw_update_flx_dev"); }
     int lw_update_rats_dev(hipStream_t, int, int, int, const void *const *, void *const *) override { return nodev("geosrad_lw_update_rats_dev"); }
     int lw_update_bands_dev(hipStream_t, int, const int32_t *, const double *, const double *, double, const void *, const void *, const void *,
@@ -2878,6 +2928,13 @@ int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *c, void *stream, int ncol, int lm, 
     if (!c || !in || !consts || !out) return GEOSRAD_EINVAL;
     return c->sw_driver_dev((hipStream_t)stream, ncol, lm, nb_aer, in, consts, iceflgsw, liqflgsw, sc, dist, isolvar, dyofyr,
                             include_aerosols, lcldlm, lcldmh, normflx, bndsolvar, indsolvar, out);
+}
+
+int geosrad_sw_driver_chou_dev(geosrad_ctx *c, void *stream, int ncol, int lm, const void *const *in, const double *consts, int lcldmh,
+                               int lcldlm, const void *hk_uv, const void *hk_ir, int do_drfband, void *const *out)
+{
+    if (!c || !in || !out) return GEOSRAD_EINVAL;
+    return c->sw_driver_chou_dev((hipStream_t)stream, ncol, lm, in, consts, lcldmh, lcldlm, hk_uv, hk_ir, do_drfband, out);
 }
 
 int geosrad_lw_chou_post_dev(geosrad_ctx *c, void *stream, int ncol, int lm, const void *const *in, void *const *out)

@@ -307,6 +307,47 @@ template <typename R> __global__ void __launch_bounds__(256) k_lwd_chou_post(Lwc
     }
 }
 
+// Chou-Suarez branch of SORADCORE (SOL:4484-4528): `sorad` takes the packed GEOS fields in their own layout and ordering; what the
+// driver prepares for it: interface pressures in hPa, ozone as a non-negative MASS fraction from the odd-oxygen prognostic (above 1 hPa
+// scaled by exp(-1.5 (log10 p - 2)^2), p the mid-layer pressure in Pa), the four condensate species and their effective radii in
+// microns as (ncol, LM, 4) arrays with MAPL_UNDEF radii replaced by 36 / 14 / 50 / 50 microns.  (The reference overwrites the undefined
+// radii in its packed import buffer, which it discards afterwards; here the imports stay untouched.)  The relative humidity it also
+// forms (:4489) is not an argument of SHRTWAVE.
+template <typename R> struct SwcPrep {
+    int ncol, lm;
+    const R *ple, *ox, *q[4], *r[4];      // q / r: ice, liquid, rain, snow
+    R o3fac, undef;                       // MAPL_O3MW / MAPL_AIRMW
+    R *plhpa, *o3, *qq3, *rr3;            // (ncol, LM+1), (ncol, LM), (ncol, LM, 4) x 2
+};
+template <typename R> __global__ void __launch_bounds__(256) k_swc_prep(SwcPrep<R> P)
+{
+#pragma clang fp contract(off)      // the statements below are the reference's, operation by operation
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= P.ncol) return;
+    const int k = blockIdx.y;                                      // 0 .. LM
+    const size_t o = (size_t)k * P.ncol + ij;
+    const R pe = P.ple[o];
+    P.plhpa[o] = pe * (R)0.01;                                     // SOL:4490
+    if (k == P.lm) return;
+    const R pl = (R)0.5 * (pe + P.ple[o + P.ncol]);                // SOL:4488
+    R o3 = P.ox[o];                                                // SOL:4523-4533
+    if (pl < (R)100.) {
+        const R x = gr_log10<R>(pl) - (R)2.;
+        o3 = o3 * gr_exp<R>((R)-1.5 * (x * x));
+    }
+    o3 = o3 * P.o3fac;
+    P.o3[o] = o3 > (R)0. ? o3 : (R)0.;
+    const R dflt[4] = {(R)36.e-6, (R)14.e-6, (R)50.e-6, (R)50.e-6};   // SOL:4508-4511
+    const size_t sp = (size_t)P.lm * P.ncol;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        P.qq3[s * sp + o] = P.q[s][o];                             // SOL:4502-4505
+        R r = P.r[s][o];
+        if (r == P.undef) r = dflt[s];
+        P.rr3[s * sp + o] = r * (R)1.e6;                           // SOL:4512-4515
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Update_Flx (IRR:3796-3999)
 // ---------------------------------------------------------------------------------------------------------------------------

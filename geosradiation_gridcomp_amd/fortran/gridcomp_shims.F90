@@ -8,7 +8,7 @@ module geosrad_gridcomp
    use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
    implicit none
    private
-   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_update_surface, sw_driver_rrtmg, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
+   public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_update_surface, sw_driver_rrtmg, sw_driver_chou, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
    public :: lit_index, lit_pack, lit_unpack
    public :: dev_alloc, dev_free, dev_put, dev_get, dev_sync
 
@@ -37,6 +37,13 @@ module geosrad_gridcomp
       LWC_FLAD_INT = 7, LWC_FLXAD_INT = 8, LWC_DFDTS = 9, LWC_TS = 10, LWC_NIN = 10
    integer, parameter, public :: LWC_SFCEM_INT = 1, LWC_FLX_INT = 2, LWC_FLXA_INT = 3, LWC_FLC_INT = 4, LWC_FLA_INT = 5, LWC_DFDTSC = 6, &
       LWC_DFDTSNA = 7, LWC_DFDTSCNA = 8, LWC_TS_INT = 9, LWC_NOUT = 9
+   ! ---- GEOSRAD_SWC_* ----
+   integer, parameter, public :: SWC_PLE = 1, SWC_T = 2, SWC_Q = 3, SWC_OX = 4, SWC_CL = 5, SWC_QI = 6, SWC_QL = 7, SWC_QR = 8, SWC_QS = 9, &
+      SWC_RI = 10, SWC_RL = 11, SWC_RR = 12, SWC_RS = 13, SWC_TAUA = 14, SWC_SSAA = 15, SWC_ASYA = 16, SWC_ZT = 17, SWC_ALBVR = 18, &
+      SWC_ALBVF = 19, SWC_ALBNR = 20, SWC_ALBNF = 21, SWC_NIN = 21
+   integer, parameter, public :: SWC_C_CO2 = 1, SWC_C_O3MW = 2, SWC_C_AIRMW = 3, SWC_C_UNDEF = 4, SWC_NCONST = 4
+   integer, parameter, public :: SWC_FSW = 1, SWC_FSC = 2, SWC_FSWU = 3, SWC_FSCU = 4, SWC_NIRR = 5, SWC_NIRF = 6, SWC_PARR = 7, &
+      SWC_PARF = 8, SWC_UVRR = 9, SWC_UVRF = 10, SWC_FSWBAND = 11, SWC_DRBAND = 12, SWC_DFBAND = 13, SWC_NOUT = 13
    ! ---- GEOSRAD_SWD_* ----
    integer, parameter, public :: SWD_PLE = 1, SWD_PL = 2, SWD_T = 3, SWD_Q = 4, SWD_O3 = 5, SWD_CH4 = 6, SWD_CL = 7, SWD_TS = 8, &
       SWD_QQ_ICE = 9, SWD_QQ_LIQ = 10, SWD_RR_ICE = 11, SWD_RR_LIQ = 12, SWD_TAUA = 13, SWD_SSAA = 14, SWD_ASYA = 15, SWD_ZT = 16, &
@@ -119,6 +126,15 @@ module geosrad_gridcomp
          real(c_double), value :: sc, dist
          type(c_ptr), intent(in) :: fin(*), fout(*)
          real(c_double), intent(in) :: consts(*)
+      end function
+      integer(c_int) function geosrad_sw_driver_chou_dev(ctx, stream, ncol, lm, fin, consts, lcldmh, lcldlm, hk_uv, hk_ir, do_drfband, fout) &
+            bind(C, name='geosrad_sw_driver_chou_dev')
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: ctx, stream
+         integer(c_int), value :: ncol, lm, lcldmh, lcldlm, do_drfband
+         type(c_ptr), intent(in) :: fin(*), fout(*)
+         real(c_double), intent(in) :: consts(*)
+         real, intent(in) :: hk_uv(*), hk_ir(*)
       end function
       integer(c_int) function geosrad_lw_chou_post_dev(ctx, stream, ncol, lm, fin, fout) bind(C, name='geosrad_lw_chou_post_dev')
          import :: c_int, c_ptr
@@ -311,6 +327,19 @@ contains
       rc = geosrad_sw_driver_rrtmg_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), int(nb_aer,c_int), fin, consts, &
             int(iceflgsw,c_int), int(liqflgsw,c_int), real(sc,c_double), real(dist,c_double), int(isolvar,c_int), int(dyofyr,c_int), &
             merge(1_c_int, 0_c_int, include_aerosols), int(lcldlm,c_int), int(lcldmh,c_int), 1_c_int, c_null_ptr, c_null_ptr, fout)
+   end subroutine
+
+   ! Chou-Suarez branch of SORADCORE (GEOS_SolarGridComp.F90:4484-4572 and the SHRTWAVE cover :6597-6672) on the packed daytime columns;
+   ! hk_uv_temp / hk_ir_temp: the GridComp's band weights (:2997-3028)
+   subroutine sw_driver_chou(ncol, lm, fin, consts, lcldmh, lcldlm, hk_uv_temp, hk_ir_temp, do_drfband, fout, rc)
+      integer, intent(in) :: ncol, lm, lcldmh, lcldlm
+      type(c_ptr), intent(in) :: fin(SWC_NIN), fout(SWC_NOUT)
+      real(c_double), intent(in) :: consts(SWC_NCONST)
+      real, intent(in) :: hk_uv_temp(5), hk_ir_temp(3,10)
+      logical, intent(in) :: do_drfband
+      integer, intent(out) :: rc
+      rc = geosrad_sw_driver_chou_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), fin, consts, int(lcldmh,c_int), &
+            int(lcldlm,c_int), hk_uv_temp, hk_ir_temp, merge(1_c_int, 0_c_int, do_drfband), fout)
    end subroutine
 
    ! after `call IRRAD` in the Chou-Suarez branch of LW_Driver (GEOS_IrradGridComp.F90:2101-2108, :3601-3616)

@@ -30,6 +30,12 @@ SWD_CONST = ["CO2", "O2", "AIRMW", "H2OMW", "O3MW", "RGAS", "GRAV", "UNDEF"]
 SWD_OUT = ["FSW", "FSC", "FSWU", "FSCU", "NIRR", "NIRF", "PARR", "PARF", "UVRR", "UVRF", "FSWBAND", "CLDTS", "CLDHS", "CLDMS", "CLDLS",
            "COTTP", "COTHP", "COTMP", "COTLP", "FSWNA", "FSCNA", "FSWUNA", "FSCUNA", "FSWBANDNA"]
 
+# Chou-Suarez branch of SORADCORE (SOL:4484-4572, SHRTWAVE :6597-6672): GEOSRAD_SWC_*
+SWC_IN = ["PLE", "T", "Q", "OX", "CL", "QI", "QL", "QR", "QS", "RI", "RL", "RR", "RS", "TAUA", "SSAA", "ASYA", "ZT", "ALBVR", "ALBVF",
+          "ALBNR", "ALBNF"]
+SWC_CONST = ["CO2", "O3MW", "AIRMW", "UNDEF"]
+SWC_OUT = ["FSW", "FSC", "FSWU", "FSCU", "NIRR", "NIRF", "PARR", "PARF", "UVRR", "UVRF", "FSWBAND", "DRBAND", "DFBAND"]
+
 LWU_IN = ["TSINST", "TS_INT", "SFCEM_INT", "FCLD", "FLX_INT", "FLXA_INT", "FLC_INT", "FLA_INT", "FLXU_INT", "FLXAU_INT", "FLCU_INT",
           "FLAU_INT", "FLXD_INT", "FLXAD_INT", "FLCD_INT", "FLAD_INT", "DFDTS", "DFDTSNA", "DFDTSC", "DFDTSCNA"]
 LWU_IN_NA = ["FLXA_INT", "FLA_INT", "FLXAU_INT", "FLAU_INT", "FLXAD_INT", "FLAD_INT", "DFDTSNA", "DFDTSCNA"]
@@ -54,6 +60,12 @@ MAPL = {"AIRMW": 28.965, "H2OMW": 18.015, "O3MW": 47.9982, "RUNIV": 8314.47, "GR
 MAPL["RGAS"] = MAPL["RUNIV"] / MAPL["AIRMW"]
 # trace-gas scalars of the Irrad / Solar resource files (IRR:1594-1597)
 GAS = {"CO2_FIXED": 4.0e-4, "CO2": 4.0e-4, "O2": 0.2090029, "CCL4": 0.1105000e-09}
+
+
+def swc_consts(co2=None, **over):
+    d = dict(CO2=GAS["CO2"] if co2 is None else co2, O3MW=MAPL["O3MW"], AIRMW=MAPL["AIRMW"], UNDEF=MAPL["UNDEF"])
+    d.update(over)
+    return [d[k] for k in SWC_CONST]
 
 
 def lwd_consts(**over):

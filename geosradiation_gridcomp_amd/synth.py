@@ -239,6 +239,31 @@ def chou_sw_inputs(inp, aerosol=False):
     return out
 
 
+def geos_chou_sw_fields(inp, aerosol=True, undef_every=7):
+    """GEOS-side fields (gridcomp.SWC_IN; model ordering, SI units, [k][ij]) that lead the Chou-Suarez branch of SORADCORE
+    (GEOS_SolarGridComp.F90:4484-4553) back to `chou_sw_inputs(inp)`: odd oxygen as a VOLUME mixing ratio, effective radii in metres with
+    every `undef_every`-th cell MAPL_UNDEF (the GridComp then substitutes 36 / 14 / 50 / 50 microns).  float64 numpy; plus the
+    scalars sorad needs."""
+    from . import gridcomp as G
+    cs = chou_sw_inputs(inp, aerosol=aerosol)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    f = {"PLE": f64(cs["pl"]) * 100.0, "T": f64(cs["ta"]), "Q": f64(cs["wa"]), "OX": f64(cs["oa"]) * (G.MAPL["AIRMW"] / G.MAPL["O3MW"]),
+         "CL": f64(cs["fcld"]), "ZT": f64(cs["cosz"]), "ALBVR": f64(cs["rsuvbm"]), "ALBVF": f64(cs["rsuvdf"]), "ALBNR": f64(cs["rsirbm"]),
+         "ALBNF": f64(cs["rsirdf"])}
+    for s, (q, r) in enumerate((("QI", "RI"), ("QL", "RL"), ("QR", "RR"), ("QS", "RS"))):
+        f[q] = f64(cs["cwc"][s])
+        rr = f64(cs["reff"][s]) * 1.0e-6
+        if undef_every:
+            flat = rr.reshape(-1)
+            flat[s::undef_every] = G.MAPL["UNDEF"]
+        f[r] = rr
+    if aerosol:
+        f["TAUA"] = f64(cs["taua"]); f["SSAA"] = f64(cs["ssaa"]); f["ASYA"] = f64(cs["asya"])
+    f["LCLDMH"] = int(cs["ict"]); f["LCLDLM"] = int(cs["icb"]); f["CO2"] = float(cs["co2"])
+    f["HK_UV"] = cs["hk_uv"]; f["HK_IR"] = cs["hk_ir"]
+    return f
+
+
 def geos_lw_fields(inp):
     """GEOS-side (model ordering, 1 = top, SI units) fields of gridcomp.LWD_IN that lead LW_Driver's prep
     (GEOS_IrradGridComp.F90:3243-3371) back to (nearly) the RRTMG-side columns `inp` of make_columns; plus the model-ordering

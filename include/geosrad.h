@@ -362,6 +362,24 @@ int geosrad_sw_driver_rrtmg_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm
                                 int include_aerosols, int lcldlm, int lcldmh, int normflx, const void *bndsolvar,
                                 const void *indsolvar, void *const *out);
 
+/* geosrad_sw_driver_chou_dev: the Chou-Suarez branch of SORADCORE on the packed daytime columns (GEOS_SolarGridComp.F90:4484-4553
+ * prep: interface pressures in hPa, odd oxygen -> non-negative ozone mass fraction, the species arrays QQ3 / RR3 with MAPL_UNDEF radii
+ * replaced, zero aerosol arrays when there are none; :4558-4572 `call shrtwave` = SHRTWAVE :6597-6672 = `call SORAD`).  Fields in the
+ * GEOS layout and MODEL ordering (what sorad expects).  The RADSW_BINARY_CLOUDS option (:4480-4481) is the caller's `where`.
+ * taua / ssaa / asya (ncol,LM,8) in sorad's (tau, tau*ssa, tau*ssa*g) form, or all three NULL (num_aero_vars == 0).  hk_uv (5),
+ * hk_ir (3,10): HOST pointers, the GridComp's HK_UV_TEMP / HK_IR_TEMP (:2997-3028).  lcldmh / lcldlm: sorad's ict / icb.
+ * Outputs as SHRTWAVE's: FSW, FSC, FSWU, FSCU (ncol,LM+1), the six surface components (ncol), FSWBAND (ncol,8); DRBAND / DFBAND
+ * (ncol,8) are written when do_drfband != 0 (SOLAR_TO_OBIO .and. include_aerosols), else may be NULL.  Fractions of the TOA insolation. */
+enum { GEOSRAD_SWC_PLE /*(ncol,LM+1) Pa*/, GEOSRAD_SWC_T, GEOSRAD_SWC_Q, GEOSRAD_SWC_OX, GEOSRAD_SWC_CL, GEOSRAD_SWC_QI, GEOSRAD_SWC_QL,
+       GEOSRAD_SWC_QR, GEOSRAD_SWC_QS, GEOSRAD_SWC_RI /*m, MAPL_UNDEF allowed*/, GEOSRAD_SWC_RL, GEOSRAD_SWC_RR, GEOSRAD_SWC_RS,
+       GEOSRAD_SWC_TAUA /*(ncol,LM,8) nullable*/, GEOSRAD_SWC_SSAA, GEOSRAD_SWC_ASYA, GEOSRAD_SWC_ZT /*cos zenith*/, GEOSRAD_SWC_ALBVR,
+       GEOSRAD_SWC_ALBVF, GEOSRAD_SWC_ALBNR, GEOSRAD_SWC_ALBNF, GEOSRAD_SWC_NIN };
+enum { GEOSRAD_SWC_C_CO2, GEOSRAD_SWC_C_O3MW, GEOSRAD_SWC_C_AIRMW, GEOSRAD_SWC_C_UNDEF, GEOSRAD_SWC_NCONST };
+enum { GEOSRAD_SWC_FSW, GEOSRAD_SWC_FSC, GEOSRAD_SWC_FSWU, GEOSRAD_SWC_FSCU, GEOSRAD_SWC_NIRR, GEOSRAD_SWC_NIRF, GEOSRAD_SWC_PARR,
+       GEOSRAD_SWC_PARF, GEOSRAD_SWC_UVRR, GEOSRAD_SWC_UVRF, GEOSRAD_SWC_FSWBAND, GEOSRAD_SWC_DRBAND, GEOSRAD_SWC_DFBAND, GEOSRAD_SWC_NOUT };
+int geosrad_sw_driver_chou_dev(geosrad_ctx *ctx, void *stream, int ncol, int lm, const void *const *in, const double *consts,
+                               int lcldmh, int lcldlm, const void *hk_uv, const void *hk_ir, int do_drfband, void *const *out);
+
 /* geosrad_lw_update_flx_dev: Update_Flx (GEOS_IrradGridComp.F90:3796-3999), the per-model-step linearisation of the LW fluxes in
  * the surface temperature.  rrtmg != 0: the no-aerosol flavours are `undef` and their internals may be NULL (IRR:3927-3990).
  * lev_mid_high / lev_low_mid: the model levels found from PREF (IRR:3811-3829). */

@@ -387,6 +387,20 @@ def swd_prep(f, consts, iceflg=3, liqflg=1, prec="f32"):
     return out, {"TAUA": ins[12], "SSAA": ins[13], "ASYA": ins[14]}
 
 
+def swc_prep(f, consts, prec="f32"):
+    """Chou-Suarez branch of SORADCORE, prep (SOL:4484-4528).  `f`: GEOS fields PLE OX QI QL QR QS RI RL RR RS, [k][ij];
+    consts = (O3MW, AIRMW, UNDEF).  Returns PLhPa (LM+1,ncol), O3 (LM,ncol), QQ3 (4,LM,ncol), RR3 (4,LM,ncol)."""
+    L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)
+    lm, ncol = f["OX"].shape
+    ins = [_c(f[k], dt) for k in ("PLE", "OX", "QI", "QL", "QR", "QS", "RI", "RL", "RR", "RS")]
+    out = dict(PLhPa=np.zeros((lm + 1, ncol), dtype=dt), O3=np.zeros((lm, ncol), dtype=dt), QQ3=np.zeros((4, lm, ncol), dtype=dt),
+               RR3=np.zeros((4, lm, ncol), dtype=dt))
+    cs = (ctypes.c_double * 3)(*consts)
+    getattr(L, f"oracle_swc_prep_{sfx}")(ctypes.c_int(ncol), ctypes.c_int(lm), _parr(ins), cs,
+                                         _parr([out[k] for k in ("PLhPa", "O3", "QQ3", "RR3")]))
+    return out
+
+
 def swd_post(flux, clearCounts, cot8, aerosols, undef, prec="f32"):
     """SOL:6395-6450.  flux: swuflx swdflx swuflxc swdflxc; cot8: cotdtp cotdhp cotdmp cotdlp cotntp cotnhp cotnmp cotnlp"""
     L = lib(); sfx = _sfx(prec); dt = dtype_of(sfx)

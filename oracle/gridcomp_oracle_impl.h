@@ -3,7 +3,8 @@
  * Plain-C restatement of the GridComp data path either side of the RRTMG solvers:
  *   GEOSirrad_GridComp/GEOS_IrradGridComp.F90  (IRR)  LW_Driver RRTMG branch :3188-3372, :3487-3533, :3560-3565, :3601-3615;
  *                                                     Update_Flx :3796-3999
- *   GEOSsolar_GridComp/GEOS_SolarGridComp.F90  (SOL)  SORADCORE RRTMG branch :6113-6219, :6395-6450; UPDATE_EXPORT :7540-7579
+ *   GEOSsolar_GridComp/GEOS_SolarGridComp.F90  (SOL)  SORADCORE RRTMG branch :6113-6219, :6395-6450; Chou-Suarez branch :4484-4528;
+ *                                                     UPDATE_EXPORT :7540-7579
  *   GEOS_RadiationGridComp.F90                 (RAD)  :798-819
  * PARITY UNPINNED: these routines live in the ESMF/MAPL GridComps, which cannot be built in this image (ESMF, MAPL absent; writing
  * stand-ins for them is not allowed), and the reference holds no test vectors for them.  The statements below follow the
@@ -257,6 +258,37 @@ void SFX(oracle_swd_prep)(int ncol, int lm, int nb, REAL *const *in, const doubl
         for (size_t i = 0; i < (size_t)ncol * lm; i++)
             if (neg[a][i] < 0) neg[a][i] = 0;
     free(dpr); free(tlev);
+}
+
+/* SORADCORE Chou-Suarez branch prep (SOL:4484-4528).  in[] = PLE OX QI QL QR QS RI RL RR RS (GEOS layout, model ordering);
+ * consts = {O3MW, AIRMW, UNDEF}; rr[] = PLhPa (ncol,LM+1), O3 (ncol,LM), QQ3 (ncol,LM,4), RR3 (ncol,LM,4).  The imports are not modified
+ * (the reference overwrites undefined radii in its packed buffer, which it then discards). */
+void SFX(oracle_swc_prep)(int ncol, int lm, const REAL *const *in, const double *consts, REAL *const *rr)
+{
+    const REAL *ple = in[0], *ox = in[1];
+    const REAL o3fac = (REAL)consts[0] / (REAL)consts[1], undef = (REAL)consts[2];
+    const REAL dflt[4] = {(REAL)36.e-6, (REAL)14.e-6, (REAL)50.e-6, (REAL)50.e-6};      /* SOL:4508-4511 */
+    REAL *plhpa = rr[0], *o3 = rr[1], *qq3 = rr[2], *rr3 = rr[3];
+    const size_t sp = (size_t)lm * ncol;
+    for (int ij = 0; ij < ncol; ij++) {
+        for (int k = 0; k <= lm; k++) G2(plhpa, k) = G2(ple, k) * (REAL)0.01;            /* SOL:4490 */
+        for (int k = 0; k < lm; k++) {
+            const REAL pl = (REAL)0.5 * (G2(ple, k) + G2(ple, k + 1));                    /* SOL:4488 */
+            REAL o = G2(ox, k);                                                           /* SOL:4523-4533 */
+            if (pl < (REAL)100.) {
+                const REAL x = LOG10(pl) - (REAL)2.;
+                o = o * EXP((REAL)-1.5 * (x * x));
+            }
+            o = o * o3fac;
+            G2(o3, k) = o > 0 ? o : 0;
+            for (int s = 0; s < 4; s++) {
+                G2(qq3 + s * sp, k) = G2(in[2 + s], k);                                  /* SOL:4502-4505 */
+                REAL r = G2(in[6 + s], k);
+                if (r == undef) r = dflt[s];
+                G2(rr3 + s * sp, k) = r * (REAL)1.e6;                                    /* SOL:4512-4515 */
+            }
+        }
+    }
 }
 
 /* SOL:6395-6450.  flux[] = swuflx swdflx swuflxc swdflxc; cot8[] = cotd t h m l, cotn t h m l; out[] = fsw fsc fswu fscu, cldts..cldls,

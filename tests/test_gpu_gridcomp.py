@@ -573,3 +573,68 @@ def test_lit_column_compaction_roundtrip_and_sw_on_packed_columns(gpu_ctx, rk):
         keep = torch.full((nlev, n), 123.0, dtype=tdt, device="cuda")
         ctx.lit_unpack_dev(st, nlit, n, nlev, pos.data_ptr(), src.data_ptr(), keep.data_ptr())     # no DEFAULT: dark columns untouched
         assert (keep.cpu().numpy().reshape(full[k].shape)[..., ~day] == 123.0).all()
+
+
+@pytest.mark.parametrize("rk", [4, 8])
+@pytest.mark.parametrize("aer", [True, False])
+def test_chou_branch_of_soradcore(gpu_ctx, rk, aer):
+    """geosrad_sw_driver_chou_dev on GEOS fields (model ordering, Pa, odd oxygen as volume mixing ratio, radii in metres with MAPL_UNDEF
+    cells, top layers above 1 hPa) = the oracle's statement of SORADCORE's preparation (SOL:4484-4528) followed by the oracle's sorad;
+    with no aerosol arrays the driver supplies the zeroes (SOL:4543-4546).  Also: the driver = geosrad_sorad_dev on the oracle-prepared
+    arrays (fp64: bitwise wherever the prepared ozone is)."""
+    import torch
+    from oracle import clib
+    ctx = gpu_ctx[rk]; prec = PREC[rk]; dt = np.float32 if rk == 4 else np.float64
+    inp = synth.make_columns(300, 72, start=8080, cloudy_frac=0.6, aerosol=True)
+    f = synth.geos_chou_sw_fields(inp, aerosol=aer)
+    assert (f["PLE"][:3] < 100.0).all()                       # the odd-oxygen scaling above 1 hPa is exercised
+    lm, m = f["T"].shape
+    consts = G.swc_consts(co2=f["CO2"])
+    t, ptr = _dev({k: f[k] for k in G.SWC_IN if k in f}, dt)
+    shapes = {k: (lm + 1, m) for k in ("FSW", "FSC", "FSWU", "FSCU")}
+    shapes.update({k: (m,) for k in ("NIRR", "NIRF", "PARR", "PARF", "UVRR", "UVRF")})
+    shapes.update({k: (8, m) for k in ("FSWBAND", "DRBAND", "DFBAND")})
+    tout, pout = _zeros(shapes, dt)
+    ptr.update(pout)
+    st = _stream()
+    ctx.sw_driver_chou_dev(st, m, lm, ptr, consts, f["LCLDMH"], f["LCLDLM"], f["HK_UV"], f["HK_IR"], do_drfband=True)
+    ctx.check(st)
+    g = {k: v.cpu().numpy() for k, v in tout.items()}
+    # the oracle's way
+    fr = {k: np.asarray(v, dtype=dt) for k, v in f.items() if isinstance(v, np.ndarray)}       # what the device was given
+    pr = clib.swc_prep(fr, (G.MAPL["O3MW"], G.MAPL["AIRMW"], G.MAPL["UNDEF"]), prec)
+    z = np.zeros((8, lm, m), dtype=dt)
+    cs = dict(cosz=fr["ZT"], pl=pr["PLhPa"], ta=fr["T"], wa=fr["Q"], oa=pr["O3"], cwc=pr["QQ3"], fcld=fr["CL"], reff=pr["RR3"],
+              hk_uv=f["HK_UV"], hk_ir=f["HK_IR"], taua=fr["TAUA"] if aer else z, ssaa=fr["SSAA"] if aer else z, asya=fr["ASYA"] if aer else z,
+              rsuvbm=fr["ALBVR"], rsuvdf=fr["ALBVF"], rsirbm=fr["ALBNR"], rsirdf=fr["ALBNF"], co2=f["CO2"], ict=f["LCLDMH"], icb=f["LCLDLM"])
+    o = clib.sorad(cs, prec, do_drfband=True)
+    assert o["rc"] == 0
+    names = dict(FSW="flx", FSC="flc", FSWU="flxu", FSCU="flcu", NIRR="fdirir", NIRF="fdifir", PARR="fdirpar", PARF="fdifpar", UVRR="fdiruv",
+                 UVRF="fdifuv", FSWBAND="flx_sfc_band", DRBAND="drband", DFBAND="dfband")
+    tol = 1e-9 if rk == 8 else 2e-5
+    for k, ok in names.items():
+        assert np.isfinite(g[k]).all(), k
+        assert np.abs(g[k].astype(np.float64) - o[ok].astype(np.float64)).max() <= tol, k
+    assert (g["FSW"][0] > 0.3).all() and (g["FSWU"][0] > 0).all()
+    # the same solver on the oracle-prepared arrays
+    sd, sp = _dev({k: v for k, v in cs.items() if isinstance(v, np.ndarray) and k not in ("hk_uv", "hk_ir")}, dt)
+    so, sop = _zeros({"flx": (lm + 1, m), "flc": (lm + 1, m), "flxu": (lm + 1, m), "flcu": (lm + 1, m), "fdiruv": (m,), "fdifuv": (m,),
+                      "fdirpar": (m,), "fdifpar": (m,), "fdirir": (m,), "fdifir": (m,), "flx_sfc_band": (8, m), "drband": (8, m),
+                      "dfband": (8, m)}, dt)
+    sp.update(sop)
+    ctx.sorad_dev(st, m, lm, 8, sp, f["CO2"], f["LCLDMH"], f["LCLDLM"], f["HK_UV"], f["HK_IR"], do_drfband=True)
+    torch.cuda.synchronize()
+    for k, ok in names.items():
+        a, b = g[k], so[ok].cpu().numpy()
+        if rk == 8:
+            assert np.abs(a - b).max() <= 1e-13, k
+        else:
+            assert np.abs(a.astype(np.float64) - b).max() <= 2e-6, k
+    # argument errors
+    bad = dict(ptr); bad.pop("OX")
+    with pytest.raises(GeosradError):
+        ctx.sw_driver_chou_dev(st, m, lm, bad, consts, f["LCLDMH"], f["LCLDLM"], f["HK_UV"], f["HK_IR"])
+    if aer:
+        bad = dict(ptr); bad.pop("SSAA")
+        with pytest.raises(GeosradError):
+            ctx.sw_driver_chou_dev(st, m, lm, bad, consts, f["LCLDMH"], f["LCLDLM"], f["HK_UV"], f["HK_IR"])

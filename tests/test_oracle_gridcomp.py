@@ -172,3 +172,36 @@ def test_sw_prep_post_update_and_tendencies(cols):
     np.testing.assert_allclose(t["ALW"], rt["SFCEM"] - rt["DSFDTS"] * rt["TRD"], rtol=1e-15)
     np.testing.assert_array_equal(t["BLW"], rt["DSFDTS"])
     np.testing.assert_allclose(t["RADSRF"], rt["FSW"][lm] + rt["FLW"][lm], rtol=1e-15)
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-6), ("f64", 1e-13)])
+def test_chou_sw_prep_against_numpy(cols, prec, tol):
+    """Chou-Suarez branch of SORADCORE, what it prepares for `sorad` (GEOS_SolarGridComp.F90:4484-4528), against numpy statements of the
+    same lines (the 72-layer grid has its top layers above 1 hPa, where odd oxygen is scaled, :4527-4529)."""
+    f = synth.geos_chou_sw_fields(cols, aerosol=False)
+    undef = G.MAPL["UNDEF"]
+    o = clib.swc_prep(f, (G.MAPL["O3MW"], G.MAPL["AIRMW"], undef), prec)
+    np.testing.assert_allclose(o["PLhPa"], f["PLE"] * 0.01, rtol=tol)
+    pl = 0.5 * (f["PLE"][:-1] + f["PLE"][1:])
+    o3 = f["OX"].copy()
+    hi = pl < 100.0
+    assert hi[:2].all() and not hi[-40:].any()
+    o3[hi] *= np.exp(-1.5 * (np.log10(pl[hi]) - 2.0) ** 2)
+    o3 = np.maximum(o3 * (G.MAPL["O3MW"] / G.MAPL["AIRMW"]), 0.0)
+    np.testing.assert_allclose(o["O3"], o3, rtol=max(tol, 5e-7) * 4, atol=1e-30)
+    dflt = (36.0, 14.0, 50.0, 50.0)
+    n_undef = 0
+    for s, (q, r) in enumerate((("QI", "RI"), ("QL", "RL"), ("QR", "RR"), ("QS", "RS"))):
+        np.testing.assert_allclose(o["QQ3"][s], f[q], rtol=tol, atol=1e-30)
+        und = f[r] == undef
+        n_undef += und.sum()
+        np.testing.assert_allclose(o["RR3"][s], np.where(und, dflt[s], f[r] * 1.0e6), rtol=max(tol, 2e-7))
+    assert n_undef > 100
+    # and the prepared arrays are sorad's inputs again (the radii where they were defined)
+    cs = synth.chou_sw_inputs(cols, aerosol=False)
+    f2 = synth.geos_chou_sw_fields(cols, aerosol=False, undef_every=0)
+    o2 = clib.swc_prep(f2, (G.MAPL["O3MW"], G.MAPL["AIRMW"], undef), prec)
+    np.testing.assert_allclose(o2["PLhPa"], cs["pl"], rtol=3e-7)
+    np.testing.assert_allclose(o2["O3"][~hi], cs["oa"][~hi], rtol=3e-6, atol=1e-30)
+    np.testing.assert_allclose(o2["RR3"], cs["reff"], rtol=3e-6)
+    np.testing.assert_array_equal(o2["QQ3"].astype(np.float32), cs["cwc"])
