@@ -900,7 +900,9 @@ def main():
 
     # RRTMG_LW and RRTMG_SW are independent (two sibling GridComps in GEOS): enqueued on two HIP streams their kernels share the
     # GPU - the latency-bound LW band kernel and the HBM-bound SW one complement each other, and no launch has an idle tail
-    prio = os.environ.get("GEOSRAD_BENCH_PRIO", "")             # experiment: "sw" / "lw" puts that solver on a high-priority stream
+    # the latency-bound solver (RRTMG_LW: ~1.5-1.9 wavefronts per SIMD resident, two thirds of their cycles waiting) goes on a
+    # high-priority stream: its blocks are placed first and RRTMG_SW's fill what is left (19.06 -> 18.90 ms; GEOSRAD_BENCH_PRIO=none | sw | lw)
+    prio = os.environ.get("GEOSRAD_BENCH_PRIO", "lw")
     side = torch.cuda.Stream(priority=-1 if prio == "sw" else 0) if (not a.no_overlap and do_lw and do_sw) else None
     sw_stream = side.cuda_stream if side is not None else stream
     lw_side = torch.cuda.Stream(priority=-1) if (side is not None and prio == "lw") else None

@@ -1111,9 +1111,11 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     const R reflect = (R)1. - semis;
 
     // radiances per g-point: downward during the first sweep, converted in place to upward at the surface
-    R rad[NG], radc[NG], dlu[NG], dclu[NG];   // radc/dclu are dead (eliminated) when CLD == false
+    // (the surface step is taken at the start of the upward sweep, where the Planck fractions of layer 0 are evaluated anyway: the
+    // derivative radiances dlu / dclu then only live there, not across the downward sweep)
+    R rad[NG], radc[NG];                      // radc is dead (eliminated) when CLD == false
 #pragma unroll
-    for (int g = 0; g < NG; g++) { rad[g] = 0; dlu[g] = 0; radc[g] = 0; dclu[g] = 0; }
+    for (int g = 0; g < NG; g++) { rad[g] = 0; radc[g] = 0; }
     bool diverge = false;
     int ltop = -1;   // highest optically cloudy layer: where the clear/total streams part (:297-307)
     R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
@@ -1229,20 +1231,6 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     }
                     dcsum = dcsum + sumfac * radc[g];
                 }
-                if (lay == 0) {
-                    // surface: emission + reflection turn the downward radiance into the upward one (:319-333)
-                    const R rad0 = pf[j] * plankbnd;
-                    rad[g] = rad0 + reflect * rad[g];
-                    dlu[g] = pf[j] * dplankbnd;
-                    usum = usum + sumfac * rad[g];
-                    dusum = dusum + sumfac * dlu[g];
-                    if (CLD) {
-                        radc[g] = rad0 + reflect * radc[g];
-                        dclu[g] = dlu[g];
-                        ucsum = ucsum + sumfac * radc[g];
-                        ducsum = ducsum + sumfac * dclu[g];
-                    }
-                }
             }
             __builtin_amdgcn_sched_barrier(0);   // keep one g-group's table rows in flight at a time
         }
@@ -1323,20 +1311,6 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     if (wdv) stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)(itg[j]));
                     dcsum = dcsum + sumfac * radc[g];
                 }
-                if (lay == 0) {
-                    // surface: emission + reflection turn the downward radiance into the upward one (:319-333)
-                    const R rad0 = pf[j] * plankbnd;
-                    rad[g] = rad0 + reflect * rad[g];
-                    dlu[g] = pf[j] * dplankbnd;
-                    usum = usum + sumfac * rad[g];
-                    dusum = dusum + sumfac * dlu[g];
-                    if (CLD) {
-                        radc[g] = rad0 + reflect * radc[g];
-                        dclu[g] = dlu[g];
-                        ucsum = ucsum + sumfac * radc[g];
-                        ducsum = ducsum + sumfac * dclu[g];
-                    }
-                }
             }
             __builtin_amdgcn_sched_barrier(0);   // keep one g-group's table rows in flight at a time
         }
@@ -1353,9 +1327,6 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     // TOA downward flux is zero (level nlay); written so the reduce kernel can sum unconditionally
     PART(0, nlay, 0);
     if (CLD && ccol) PART(1, nlay, 0);
-    PART(2, 0, usum);
-    if (CLD && ccol) PART(3, 0, ucsum);
-    if (dudTs) { PART(4, 0, dusum); if (CLD && ccol) PART(5, 0, ducsum); }
 
     // ---- upward sweep, surface -> top (:336-379) -----------------------------------------------------
     // highest layer in which a column of this wave keeps a gas-only pair of its own (wave-uniform; no memory access): above it the
@@ -1365,8 +1336,12 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
         for (int l = nlay - 1; l >= 0; l--)
             if (__ballot(ccol && diverge && ltop == l) != 0) { wtop = l; break; }
     }
+    R dlu[NG], dclu[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) { dlu[g] = 0; dclu[g] = 0; }
 #pragma nounroll
     for (int lay = 0; lay < nlay; lay++) {
+        R u0 = 0, uc0 = 0, du0 = 0, duc0 = 0;       // level 0 (surface) sums, formed in the first trip
         usum = 0; ucsum = 0; dusum = 0; ducsum = 0;
         PK sv[NG], sg[NG];
 #pragma unroll
@@ -1396,6 +1371,20 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
             for (int j = 0; j < W; j++) {
                 const int g = q * W + j;
                 if (g >= NG) continue;
+                if (lay == 0) {
+                    // surface: emission + reflection turn the downward radiance into the upward one (:319-333)
+                    const R rad0 = pf[j] * plankbnd;
+                    rad[g] = rad0 + reflect * rad[g];
+                    dlu[g] = pf[j] * dplankbnd;
+                    u0 = u0 + sumfac * rad[g];
+                    du0 = du0 + sumfac * dlu[g];
+                    if (CLD) {
+                        radc[g] = rad0 + reflect * radc[g];
+                        dclu[g] = dlu[g];
+                        uc0 = uc0 + sumfac * radc[g];
+                        duc0 = duc0 + sumfac * dclu[g];
+                    }
+                }
                 const R2 e1 = lut_at((int)sv[g]);
                 const R a1 = (R)1. - e1.x, b1 = pf[j] * (blay + e1.y * dplankup);
                 rad[g] = rad[g] + (b1 - rad[g]) * a1;
@@ -1412,6 +1401,11 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     ducsum = ducsum + sumfac * dclu[g];
                 }
             }
+        }
+        if (lay == 0) {
+            PART(2, 0, u0);
+            if (CLD && ccol) PART(3, 0, uc0);
+            if (dudTs) { PART(4, 0, du0); if (CLD && ccol) PART(5, 0, duc0); }
         }
         PART(2, lay + 1, usum);
         if (CLD && ccol) PART(3, lay + 1, ucsum);
