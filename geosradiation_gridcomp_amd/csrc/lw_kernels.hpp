@@ -1121,15 +1121,34 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
     R usum = 0, ucsum = 0, dusum = 0, ducsum = 0;
 
     // parked cells of the g-group processed last, waiting to be written (see phase 2 below)
-    constexpr bool DEFER = !CLD;       // the cloudy instantiation has no registers to spare for it
+    constexpr bool DEFER = !CLD;       // (the cloudy body defers its stores the same way, in its own branch)
     PK pend1[W], pend2[W];
     uint32_t poff[W];
     int npend = 0;
     uint32_t pmask2 = 0;
     // ---- downward sweep, top layer -> surface ------------------------------------------------------
     R plk_up = planck_at<R>(T.totplnk, IB, ldg(A.tlev + (size_t)nlay * ld, cba));   // level above the current layer
+    // the layer's cloud flag is read one layer ahead: it decides (by ballot) whether the layer's McICA optical depths are requested,
+    // and behind a load of its own that request would start a memory round trip late
+    int lc_next = CLD ? (int)ldg(A.laycloudy, (uint32_t)(nlay - 1) * (uint32_t)n + ucol) : 0;
 #pragma nounroll
     for (int lay = nlay - 1; lay >= 0; lay--) {
+        const int lc_cur = lc_next;
+        if (CLD && lay > 0) lc_next = (int)ldg(A.laycloudy, (uint32_t)(lay - 1) * (uint32_t)n + ucol);
+        const bool laycld0 = CLD && ccol && lc_cur != 0;
+        const bool wlc0 = CLD && __ballot(laycld0) != 0;
+        // McICA optical depths of ALL the layer's g-points, requested with the layer record: one HBM round trip per cloudy layer instead
+        // of one per g-group
+        R tcall[CLD ? NG : 1];
+        if (CLD) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) tcall[g] = 0;
+            if (wlc0) {
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+                    tcall[g] = ldg(taucmc_b, (((uint32_t)lay * (uint32_t)NG + (uint32_t)g) * (uint32_t)n + ucol) * (uint32_t)sizeof(R));
+            }
+        }
         Layer<R> L;
         load_layer<R>(A, lay, col, pc, L);
         // the layer's aerosol and temperatures are requested, and the Planck look-ups they lead to made, BEFORE the band's prep: behind
@@ -1143,7 +1162,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
         plk_up = plk_dn;
         bool laycld = false;
         if (CLD) {
-            laycld = ccol && ldg(A.laycloudy, (uint32_t)lay * (uint32_t)n + ucol) != 0;
+            laycld = laycld0;
             if (laycld && !diverge) { diverge = true; ltop = lay; }   // (:297-299) before this layer's clear-sky update
         }
         const uint32_t cell0 = ((uint32_t)lay * (uint32_t)NG) * (uint32_t)n + ucol;   // g = 0 cell of this layer; + g*n
@@ -1248,7 +1267,7 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
             if (wlc) {
 #pragma unroll
                 for (int j = 0; j < W; j++)
-                    if (q * W + j < NG) tcv[j] = ldg(taucmc_b, (cell0 + (uint32_t)(q * W + j) * (uint32_t)n) * (uint32_t)sizeof(R));
+                    if (q * W + j < NG) tcv[j] = tcall[q * W + j];
 #pragma unroll
                 for (int j = 0; j < W; j++) tcv[j] = laycld ? tcv[j] : (R)0;
             }
@@ -1280,6 +1299,18 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
 #pragma unroll
                 for (int j = 0; j < W; j++) ttb[j] = ldg(T.tau_tbl, (uint32_t)itg[j] * (uint32_t)sizeof(R));
             }
+            // the PREVIOUS group's parked cells are written only now, behind this group's loads (see the cloud-free body)
+            __builtin_amdgcn_sched_barrier(0);
+            if (npend) {
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    if (j < npend) {
+                        stg_nt(s1_b, poff[j] * (uint32_t)sizeof(PK), pend1[j]);
+                        if ((pmask2 >> j) & 1u) stg_nt(s2_b, poff[j] * (uint32_t)sizeof(PK), pend2[j]);
+                    }
+            }
+            npend = 0; pmask2 = 0;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < W; j++) {
                 const int g = q * W + j;
@@ -1303,12 +1334,12 @@ GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclea
                     atot = cld ? ac : agas; bbutot = cld ? bbut : bbugas; bbd = cld ? bbdtot : bbdgas;
                 }
                 rad[g] = rad[g] + (bbd - rad[g]) * atot;
-                stg_nt(s1_b, scell * (uint32_t)sizeof(PK), (PK)(itp));
+                pend1[j] = (PK)(itp); poff[j] = scell; npend = j + 1;
                 dsum = dsum + sumfac * rad[g];
                 if (CLD) {
                     const R rc = radc[g] + (bbdgas - radc[g]) * agas;
                     radc[g] = diverge ? rc : rad[g];
-                    if (wdv) stg_nt(s2_b, scell * (uint32_t)sizeof(PK), (PK)(itg[j]));
+                    if (wdv) { pend2[j] = (PK)(itg[j]); pmask2 |= 1u << j; }
                     dcsum = dcsum + sumfac * radc[g];
                 }
             }

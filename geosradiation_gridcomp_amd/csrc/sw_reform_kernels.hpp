@@ -147,8 +147,11 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
     int lowc[NG];            // lowest cloudy layer of sub-column g: the parked total-sky planes hold values from there upwards
 #pragma unroll
     for (int g = 0; g < NG; g++) { prup[g] = albp; prupd[g] = albd; prupT[g] = albp; prupdT[g] = albd; lowc[g] = 0x7fffffff; }
+    int lcA = CLD ? (int)ldg(A.laycloudy, ucol) : 0;       // the layer's cloud flag, read one layer ahead (it gates the layer's McICA requests)
 #pragma nounroll
     for (int lay = 0; lay < nlay; lay++) {
+        const int lcA_cur = lcA;
+        if (CLD && lay + 1 < nlay) lcA = (int)ldg(A.laycloudy, (uint32_t)(lay + 1) * (uint32_t)n + ucol);
         SwLayer<R> L;
         sw_load_layer<R>(A, lay, col, L);
         R ta = 0, om = 1, as = 0;
@@ -156,7 +159,7 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
             const uint32_t ab = ((uint32_t)lay * (uint32_t)ld + (uint32_t)pc) * (uint32_t)sizeof(R);
             ta = ldg(A.tauaer + aerb, ab); om = ldg(A.ssaaer + aerb, ab); as = ldg(A.asmaer + aerb, ab);
         }
-        const bool laycld = CLD && ccol && ldg(A.laycloudy, (uint32_t)lay * (uint32_t)n + ucol) != 0;
+        const bool laycld = CLD && ccol && lcA_cur != 0;
         const bool wlc = CLD && __ballot(laycld) != 0;      // some column of the wave has cloud in this layer (wave-uniform)
         SwPrep<R> P;
         sw_prep<R, B>(T, L, P);
@@ -169,7 +172,12 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
             if (wlc) {
 #pragma unroll
                 for (int j = 0; j < W; j++)
-                    if (q * W + j < NG) tcv[j] = ldg(tcb, MC4(lay, q * W + j));
+                    if (q * W + j < NG) {
+                        // (single-scattering albedo and asymmetry with the optical depth: behind a test of the optical depths they were a
+                        // second memory round trip per group)
+                        tcv[j] = ldg(tcb, MC4(lay, q * W + j));
+                        ocv[j] = ldg(ocb, MC4(lay, q * W + j)); gcv[j] = ldg(gcb, MC4(lay, q * W + j));
+                    }
             }
             R tg[W], tr[W];
             sw_eval<R, B, W>(T, L, P, GO + q * W, tg, tr);
@@ -179,14 +187,8 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                 for (int j = 0; j < W; j++) tr[j] = tr0;
             }
             if (wlc) {
-                bool anyc = false;
 #pragma unroll
-                for (int j = 0; j < W; j++) { tcv[j] = laycld ? tcv[j] : (R)0; anyc = anyc || tcv[j] > 0; }
-                if (__ballot(anyc) != 0) {
-#pragma unroll
-                    for (int j = 0; j < W; j++)
-                        if (q * W + j < NG) { ocv[j] = ldg(ocb, MC4(lay, q * W + j)); gcv[j] = ldg(gcb, MC4(lay, q * W + j)); }
-                }
+                for (int j = 0; j < W; j++) tcv[j] = laycld ? tcv[j] : (R)0;
             }
 #pragma unroll
             for (int j = 0; j < W; j++) {
@@ -297,12 +299,15 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
     request_layer(nlay - 1, nl);
     request(nlay - 1, 0, nx);
     R sdir = 0, sfd = 0, sfu = 0;
+    int lcB = CLD ? (int)ldg(A.laycloudy, (uint32_t)(nlay - 1) * (uint32_t)n + ucol) : 0;
 #pragma nounroll
     for (int lay = nlay - 1; lay >= 0; lay--) {      // cross layer `lay`; its lower boundary is API level `lay`
+        const int lcB_cur = lcB;
+        if (CLD && lay > 0) lcB = (int)ldg(A.laycloudy, (uint32_t)(lay - 1) * (uint32_t)n + ucol);
         const int jk = nlay - 1 - lay;
         const Lay cl = nl;
         request_layer(lay > 0 ? lay - 1 : 0, nl);
-        const bool laycld = CLD && ccol && ldg(A.laycloudy, (uint32_t)lay * (uint32_t)n + ucol) != 0;
+        const bool laycld = CLD && ccol && lcB_cur != 0;
         const bool wlc = CLD && __ballot(laycld) != 0;
         bool lower = true; int js = 1; R fs = 0;
         if constexpr (B::JB == 24) {
