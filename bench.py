@@ -428,6 +428,71 @@ def committed_counters(ckey, kname):
     return None, None
 
 
+def under_profiler():
+    """True when this process was started by rocprofv3 (its tool library is preloaded and has initialised the GPU already: no child
+    process may be started from here)"""
+    return any(k.startswith(("ROCPROF", "ROCTRACER", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+
+
+PMC_GROUPS = {"k_sw_bands": ("k_sw_reform", "k_sw_bands"), "k_lw_bands": ("k_lw_bands",), "k_mcica": ("k_mcica",), "k_chou_bands": ("k_chou_bands",),
+              "k_sorad_pass": ("k_sorad_pass",)}
+
+
+def live_counters(a, argv):
+    """The dominant kernels' PMC figures of THIS build on THIS box, collected the way MI355X_MICROARCH.md prescribes: rocprofv3 --pmc around a
+    short one-stream run of the same workload, one counter group per run (FETCH_SIZE | WRITE_SIZE | the issue counters), the program directly
+    behind `--`.  Runs as child processes BEFORE this process touches the GPU.  Returns {kernel group: {...}} per step, or None (no profiler,
+    a failed pass): bench.py then quotes the figures committed under profiles/ and says so in traffic_source."""
+    import csv, glob, shutil, subprocess, tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    steps, warm = 2, 1
+    keep = [x for x in argv if x in ("--no-aerosol",)]
+    child = [sys.executable, os.path.join(here, "bench.py"), "--no-pmc", "--no-cpu", "--no-parity", "--no-f64", "--no-overlap", "--steps", str(steps),
+             "--warmup", str(warm), "--scheme", a.scheme, "--ncol", str(a.ncol), "--nlay", str(a.nlay), "--cloudy", str(a.cloudy),
+             "--real", str(a.real), "--lit", str(a.lit)] + keep
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    sums = {}
+    tmp = tempfile.mkdtemp(prefix="geosrad_pmc_", dir="/tmp")
+    try:
+        for i, grp in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"])):
+            d = os.path.join(tmp, "p%d" % i)
+            r = subprocess.run([prof, "--pmc"] + grp + ["-d", d, "-o", "x", "--output-format", "csv", "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        kn = row["Kernel_Name"]
+                        for g, pats in PMC_GROUPS.items():
+                            if any(("geosrad::" + p_ + "<") in kn or ("geosrad::" + p_ + "(") in kn for p_ in pats):
+                                e = sums.setdefault(g, {})
+                                e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nstep = steps + warm
+    out = {}
+    for g, c in sums.items():
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        e = {"traffic_bytes": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / nstep}     # KB; gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md)
+        if c.get("GRBM_GUI_ACTIVE"):
+            e["valu_insts"] = c["SQ_INSTS_VALU"] / nstep
+            e["valu_util"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 3)
+            e["wait_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") else None
+            e["resident_waves_per_simd"] = round(4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 2)
+        out[g] = e
+    return out or None
+
+
 def roofline_note(kname, two_streams):
     """what a `launch` of the dominant kernel is and why its fraction of the HBM peak on the compulsory bytes is what it is"""
     if kname in ("k_lw_bands", "k_sw_bands"):
@@ -751,6 +816,9 @@ def main():
     ap.add_argument("--coherent", type=int, default=1, help="repeat every K-th profile K times (gather-divergence sensitivity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-f64", action="store_true", help="lwsw / lw / sw at --real 4: skip the real_kind 8 leg (3 + 5 steps after the timed region)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not collect the dominant kernels' PMC counters in child rocprofv3 runs before the timed run (roofline.traffic, roofline_compute "
+                         "then quote the figures committed under profiles/)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity figures (256 columns of the timed batch against the oracle) and the f64 leg")
     ap.add_argument("--host-api", action="store_true",
                     help="lwsw / lw / sw: also time the drop-in host-pointer entry points (geosrad_rrtmg_lw / _sw: pinned staging, chunk-pipelined "
@@ -781,6 +849,10 @@ def main():
     if a.ranks_per_gpu:
         return bench_ranks_per_gpu(a)
 
+    live = None
+    if rank == 0 and a.gpus == 1 and world == 1 and not a.no_pmc and a.scheme in ("lwsw", "lw", "sw", "chou", "irrad", "sorad") \
+            and not under_profiler():
+        live = live_counters(a, sys.argv[1:])          # child processes, before this one touches the GPU
     cpu = None
     if a.lit < 1.0:
         a.no_cpu = True           # the CPU leg times LW and SW on the same columns: not the --lit workload
@@ -1040,16 +1112,23 @@ def main():
             ckey = "lwsw_97200_72_0.6_aer_f32"
         elif a.scheme in ("chou", "irrad", "sorad") and default_paths and (ncol, nlay, a.cloudy, aerosol, a.real) == (100_000, 72, 0.6, True, 4):
             ckey = "chou_100000_72_0.6_aer_f32"
-        if ckey is not None:
+        t = None
+        if live is not None and kname in live:
+            t, traffic_source = dict(live[kname]), "measured in this run: rocprofv3 --pmc child runs of 3 one-stream steps of the same workload"
+            t["lane_ops_per_column"] = round(t["valu_insts"] * 64.0 / ncol_k) if "valu_insts" in t else None
+        elif ckey is not None:
             t, traffic_source = committed_counters(ckey, kname)
+        if True:
             if t is not None:
                 traffic = t["traffic_bytes"] / launches_per_step
                 if "valu_util" in t:
                     # the fused path is ~170 FLOP per compulsory byte, so the vector-ALU side is the second roofline
                     compute = {"kernel": kname, "valu_util": t["valu_util"], "lane_ops_per_column": t.get("lane_ops_per_column"),
                                "valu_insts_per_step": t.get("valu_insts"), "wait_frac": t.get("wait_frac"), "source": traffic_source,
-                               "note": "valu_util = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES-normalised wave issue capacity of the kernel's launches "
-                                       "(profiles/tools/valu.py); lane_ops_per_column = SQ_INSTS_VALU x 64 lanes / columns"}
+                               "resident_waves_per_simd": t.get("resident_waves_per_simd"),
+                               "note": "valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): share of the kernel's SIMD-cycles "
+                                       "with a vector instruction in the pipe; lane_ops_per_column = SQ_INSTS_VALU x 64 lanes / columns; wait_frac = "
+                                       "SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
                    "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
                    "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # profiles/tools/ab.sh TAG LIB [bench args...]: one bench line into gpurun_out/TAG.json, kernel times printed
 TAG=$1; LIB=$2; shift; shift
-GEOSRAD_LIB=$LIB python bench.py --no-cpu --steps 10 "$@" > gpurun_out/$TAG.json 2> gpurun_out/$TAG.err
+GEOSRAD_LIB=$LIB python bench.py --no-pmc --no-cpu --steps 10 "$@" > gpurun_out/$TAG.json 2> gpurun_out/$TAG.err
 python - <<PY
 import json
 try:

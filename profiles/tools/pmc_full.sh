@@ -14,7 +14,7 @@ i=0
 [ -n "$LIB" ] && [ "$LIB" != "-" ] && export GEOSRAD_LIB=$LIB
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $P -d gpurun_out/pmc_${TAG}_$i -o x --output-format csv -- python3 bench.py --no-cpu --no-parity --no-overlap --steps 2 --warmup 1 "$@" > gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 gpurun_out/pmc_${TAG}_$i.log; }
+  timeout -k 10 200 rocprofv3 --pmc $P -d gpurun_out/pmc_${TAG}_$i -o x --output-format csv -- python3 bench.py --no-pmc --no-cpu --no-parity --no-overlap --steps 2 --warmup 1 "$@" > gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 gpurun_out/pmc_${TAG}_$i.log; }
 done
 python3 profiles/tools/pmc_sum.py gpurun_out/pmc_${TAG}_1 gpurun_out/pmc_${TAG}_2 gpurun_out/pmc_${TAG}_3 gpurun_out/pmc_${TAG}_4 gpurun_out/pmc_${TAG}_5 > gpurun_out/pmc_${TAG}.txt
 grep -A26 "k_lw_bands\|k_sw_bands\|k_sw_reform" gpurun_out/pmc_${TAG}.txt | head -150

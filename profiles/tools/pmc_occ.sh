@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R
 [ -n "$LIB" ] && [ "$LIB" != "-" ] && export GEOSRAD_LIB=$LIB
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAIT_ANY -d gpurun_out/occ_$TAG -o x --output-format csv -- python3 bench.py --no-cpu --no-parity --no-f64 --no-overlap --steps 2 --warmup 1 "$@" > gpurun_out/occ_$TAG.log 2>&1 || { echo "failed"; tail -3 gpurun_out/occ_$TAG.log; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAIT_ANY -d gpurun_out/occ_$TAG -o x --output-format csv -- python3 bench.py --no-pmc --no-cpu --no-parity --no-f64 --no-overlap --steps 2 --warmup 1 "$@" > gpurun_out/occ_$TAG.log 2>&1 || { echo "failed"; tail -3 gpurun_out/occ_$TAG.log; exit 1; }
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

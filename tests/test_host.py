@@ -136,3 +136,20 @@ def test_fortran_host_functions_match_reference(tmp_path, kind, ih):
         np.testing.assert_array_equal(adl, ar)
         np.testing.assert_array_equal(rdl, rr)
         assert (z == 1).all() if ih == 0 else z.std() > 0.1
+
+
+def test_bench_does_not_spawn_profiler_children_under_a_profiler(monkeypatch):
+    """bench.py collects the dominant kernels' PMC counters in child rocprofv3 runs BEFORE it touches the GPU; when it is itself started
+    by rocprofv3 (whose tool library has initialised the GPU already) it must not start any child."""
+    import bench
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCTRACER", "ROCP_")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    assert not bench.under_profiler()
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert bench.under_profiler()
+    monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.under_profiler()
+    assert set(bench.PMC_GROUPS) >= {"k_sw_bands", "k_lw_bands", "k_chou_bands", "k_sorad_pass"}
