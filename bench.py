@@ -1103,8 +1103,9 @@ def main():
         per_launch_s = (ms / max(n, 1)) * 1e-3
         ncol_k = ncol_sw if kname == "k_sw_bands" else ncol          # columns the dominant kernel's launches cover
         achieved = abytes * (ncol_k / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
-        # separate rocprofv3 --pmc runs): only quoted for the exact configuration those passes were collected on
+        # HBM bytes per launch of the dominant kernel: measured by this run's own rocprofv3 --pmc child runs (live_counters), else from the
+        # passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc runs) - those only for the exact configuration they
+        # were collected on
         traffic = traffic_source = compute = None
         default_paths = not (os.environ.get("GEOSRAD_LW_PATH") or os.environ.get("GEOSRAD_SORAD_PATH") or os.environ.get("GEOSRAD_LIB"))
         ckey = None
@@ -1118,17 +1119,16 @@ def main():
             t["lane_ops_per_column"] = round(t["valu_insts"] * 64.0 / ncol_k) if "valu_insts" in t else None
         elif ckey is not None:
             t, traffic_source = committed_counters(ckey, kname)
-        if True:
-            if t is not None:
-                traffic = t["traffic_bytes"] / launches_per_step
-                if "valu_util" in t:
-                    # the fused path is ~170 FLOP per compulsory byte, so the vector-ALU side is the second roofline
-                    compute = {"kernel": kname, "valu_util": t["valu_util"], "lane_ops_per_column": t.get("lane_ops_per_column"),
-                               "valu_insts_per_step": t.get("valu_insts"), "wait_frac": t.get("wait_frac"), "source": traffic_source,
-                               "resident_waves_per_simd": t.get("resident_waves_per_simd"),
-                               "note": "valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): share of the kernel's SIMD-cycles "
-                                       "with a vector instruction in the pipe; lane_ops_per_column = SQ_INSTS_VALU x 64 lanes / columns; wait_frac = "
-                                       "SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+        if t is not None:
+            traffic = t["traffic_bytes"] / launches_per_step
+            if "valu_util" in t:
+                # the fused path is ~170 FLOP per compulsory byte, so the vector-ALU side is the second roofline
+                compute = {"kernel": kname, "valu_util": t["valu_util"], "lane_ops_per_column": t.get("lane_ops_per_column"),
+                           "valu_insts_per_step": t.get("valu_insts"), "wait_frac": t.get("wait_frac"), "source": traffic_source,
+                           "resident_waves_per_simd": t.get("resident_waves_per_simd"),
+                           "note": "valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): share of the kernel's SIMD-cycles "
+                                   "with a vector instruction in the pipe; lane_ops_per_column = SQ_INSTS_VALU x 64 lanes / columns; wait_frac = "
+                                   "SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
         schemes = {"lwsw": "RRTMG_LW (140 g-points) + RRTMG_SW (112 g-points)", "lw": "RRTMG_LW (140 g-points)",
                    "sw": "RRTMG_SW (112 g-points)", "chou": "Chou-Suarez irrad (10 bands) + sorad (8 bands, 35 spectral passes)",
                    "irrad": "Chou-Suarez irrad (10 bands, trace gases on)", "sorad": "Chou-Suarez sorad (8 bands, 35 spectral passes)"}[a.scheme]
