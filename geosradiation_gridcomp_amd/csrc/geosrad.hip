@@ -969,7 +969,8 @@ template <typename R> struct Ctx : geosrad_ctx {
             } else if (A.dbg_taug) {
                 hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             } else {
-                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(band_grid(nc, NB_LW)), blk, lds, st, A, h_T);
+                // (both instantiations band-major, heaviest band first: see band_block in lw_kernels.hpp)
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             }
             span_end(st);
@@ -1001,7 +1002,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 B.part = rat_part;
                 span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, B, d_T); span_end(st);
                 span_begin(4, st);
-                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(band_grid(nc, NB_LW)), blk, lds, st, B, h_T);
+                hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
                 span_end(st);
                 LwOut<R> OR{};

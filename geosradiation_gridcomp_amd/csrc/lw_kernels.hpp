@@ -1465,7 +1465,10 @@ __host__ __device__ constexpr int lw_band_ng(int ib)
 // (column block, band) = (blockIdx.x, blockIdx.y) grid ran all column blocks of a band before the next band's).
 // A launch with gridDim.y == nb keeps the (column block, band) = (blockIdx.x, blockIdx.y) order: all column blocks of a band before the
 // next band, heaviest bands first - every resident block then runs the same band body on the same tables, which the cloudy RRTMG_LW
-// instantiation (the largest code) needs more than it needs the inputs from L2 (measured: 6.7 against 7.7 ms).
+// instantiation (the largest code) needs more than it needs the inputs from L2 (measured: 6.7 against 7.7 ms).  Round 3: the cloud-free
+// RRTMG_LW instantiation takes this order too - its blocks differ 8x in length (2 to 16 g-points) and with a few thousand of them the
+// one-dimensional order left a quarter of the slots empty in the launch's tail (1.45 of 2 wavefronts per SIMD resident); heaviest band
+// first over ALL column blocks: step 18.97 -> 18.74 ms (two streams), 20.69 -> 20.35 ms (one); 100 000 clear-sky columns unchanged.
 GR_DEV bool band_block(int ncol, int nb, int &bstart, int &bslot)
 {
     if (gridDim.y > 1) { bstart = (int)(blockIdx.x * blockDim.x); bslot = (int)blockIdx.y; return true; }
