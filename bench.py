@@ -461,10 +461,21 @@ def live_counters(a, argv):
     try:
         for i, grp in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"])):
             d = os.path.join(tmp, "p%d" % i)
-            r = subprocess.run([prof, "--pmc"] + grp + ["-d", d, "-o", "x", "--output-format", "csv", "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            # a session of its own, so that a pass that overruns can be ended together with the program it started
+            pr = subprocess.Popen([prof, "--pmc"] + grp + ["-d", d, "-o", "x", "--output-format", "csv", "--"] + child, cwd="/tmp", env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             for f in files:
                 with open(f) as fh:
