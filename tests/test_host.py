@@ -153,3 +153,47 @@ def test_bench_does_not_spawn_profiler_children_under_a_profiler(monkeypatch):
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.under_profiler()
     assert set(bench.PMC_GROUPS) >= {"k_sw_bands", "k_lw_bands", "k_chou_bands", "k_sorad_pass"}
+
+
+def test_bench_counter_passes_are_parsed_as_the_guide_prescribes(tmp_path, monkeypatch):
+    """bench.live_counters: one rocprofv3 --pmc pass per counter group, per-kernel sums over the dispatches of 3 steps, HBM bytes =
+    (FETCH_SIZE x 2 + WRITE_SIZE) KB (the gfx950 correction of MI355X_MICROARCH.md).  A stand-in `rocprofv3` that writes the csv a real
+    pass would leave checks the arithmetic and the kernel grouping without a GPU."""
+    import argparse
+    import stat
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+cs = a[a.index("--pmc") + 1:a.index("-d")]
+d = a[a.index("-d") + 1]
+assert a[a.index("--") + 1].endswith("python") or "python" in a[a.index("--") + 1]
+assert "--no-pmc" in a and "--no-overlap" in a
+os.makedirs(os.path.join(d, "h", "1"), exist_ok=True)
+val = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0, "SQ_INSTS_VALU": 3.0e6, "SQ_ACTIVE_INST_VALU": 2.0e6, "GRBM_GUI_ACTIVE": 8.0e4, "SQ_WAVE_CYCLES": 5.0e6,
+       "SQ_WAIT_ANY": 2.5e6}
+kern = ["void geosrad::k_sw_reform<float, true>(geosrad::SwArgs<float>)", "void geosrad::k_sw_reform<float, false>(geosrad::SwArgs<float>)",
+        "void geosrad::k_lw_bands<float, true, false>(geosrad::LwArgs<float>)", "geosrad::k_partition(int, unsigned char const*, int*, int*)"]
+with open(os.path.join(d, "h", "1", "x_counter_collection.csv"), "w") as f:
+    f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\\n")
+    n = 0
+    for step in range(3):
+        for k in kern:
+            for c in cs:
+                n += 1
+                f.write('%d,"%s",%s,%r\\n' % (n, k, c, val[c]))
+''')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    a = argparse.Namespace(scheme="lwsw", ncol=97200, nlay=72, cloudy=0.6, real=4, lit=1.0)
+    r = bench.live_counters(a, [])
+    assert set(r) == {"k_sw_bands", "k_lw_bands"}                       # k_partition belongs to no group; the two k_sw_reform instantiations to one
+    sw, lw = r["k_sw_bands"], r["k_lw_bands"]
+    assert sw["traffic_bytes"] == pytest.approx(2 * (2 * 1000.0 + 500.0) * 1024.0) and lw["traffic_bytes"] == pytest.approx((2 * 1000.0 + 500.0) * 1024.0)
+    assert sw["valu_insts"] == pytest.approx(2 * 3.0e6)
+    assert lw["valu_util"] == pytest.approx(round(2.0e6 * 4 / (8.0e4 / 8 * 1024), 3)) and lw["wait_frac"] == 0.5
+    assert lw["resident_waves_per_simd"] == pytest.approx(round(4 * 5.0e6 / (8.0e4 / 8 * 1024), 2))
+    # a failing pass -> None (bench.py then quotes the committed figures and says so)
+    fake.write_text("#!/bin/sh\\nexit 3\\n")
+    assert bench.live_counters(a, []) is None
