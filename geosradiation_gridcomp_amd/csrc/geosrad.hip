@@ -626,6 +626,8 @@ template <typename R> struct Ctx : geosrad_ctx {
         if (lw_bands_lds_bytes<R>() > 64 * 1024) {      // the LDS copy of the LW transmittance table (fp32 build)
             const int lds = (int)lw_bands_lds_bytes<R>();
             HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            if constexpr (sizeof(R) == 4)
+                HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, false, false, LW_WIDE_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIPCHK(hipFuncSetAttribute((const void *)k_lw_bands<R, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         }
@@ -971,6 +973,9 @@ template <typename R> struct Ctx : geosrad_ctx {
             } else {
                 // (both instantiations band-major, heaviest band first: see band_block in lw_kernels.hpp)
                 hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
+                if constexpr (sizeof(R) == 4)      // the 768-thread cloud-free blocks: run instead of the 256-thread ones when the batch has many cloud-free columns
+                    hipLaunchKernelGGL((k_lw_bands<R, false, false, LW_WIDE_BLOCK>), dim3((unsigned)((nc + LW_WIDE_BLOCK - 1) / LW_WIDE_BLOCK), NB_LW),
+                                       dim3(LW_WIDE_BLOCK), lds, st, A, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
             }
             span_end(st);
@@ -1003,6 +1008,9 @@ template <typename R> struct Ctx : geosrad_ctx {
                 span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, B, d_T); span_end(st);
                 span_begin(4, st);
                 hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
+                if constexpr (sizeof(R) == 4)
+                    hipLaunchKernelGGL((k_lw_bands<R, false, false, LW_WIDE_BLOCK>), dim3((unsigned)((nc + LW_WIDE_BLOCK - 1) / LW_WIDE_BLOCK), NB_LW),
+                                       dim3(LW_WIDE_BLOCK), lds, st, B, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
                 span_end(st);
                 LwOut<R> OR{};

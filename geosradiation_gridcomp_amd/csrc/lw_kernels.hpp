@@ -1038,14 +1038,14 @@ template <typename R> GR_DEV R lw_pade(R od, R bpade) { return od / (bpade + od)
 template <> GR_DEV float lw_pade<float>(float od, float bpade) { return od * __builtin_amdgcn_rcpf(bpade + od); }
 #endif
 
-template <typename R, typename BAND, bool CLD, bool DBG>
+template <typename R, typename BAND, bool CLD, bool DBG, bool WIDE = true>
 GR_DEV void band_body(const LwArgs<R> &A, const LwDev<R> &Tg, int col, int nclear, const typename Vec2<R>::T *luts)
 {
     constexpr int NG = BAND::NG, IB = BAND::IB, G0 = BAND::G0;
     // g-points per evaluation of the k-distribution: 4 (one 16-byte piece of each table row); 8 in the cloud-free instantiation for the
     // bands whose g-point count is a multiple of 8 (half as many serial table-row round trips per layer, 227 instead of 213 VGPRs:
     // 4.98 -> 4.78 ms per 100 000 clear-sky columns; the cloudy instantiation has no registers for it)
-    constexpr int W = (!CLD && NG % 8 == 0) ? 8 : (NG >= 4 ? 4 : 2);
+    constexpr int W = (!CLD && WIDE && NG % 8 == 0) ? 8 : (NG >= 4 ? 4 : 2);
     constexpr int NQ = (NG + W - 1) / W;
     using R2 = typename Vec2<R>::T;
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
@@ -1488,13 +1488,28 @@ __host__ inline unsigned xcd_grid(int ncol, int bsz, int ny) { const unsigned gx
 // T is passed BY VALUE: table pointers that arrive as kernel arguments are known to be global-address-space
 // and wave-uniform, so a table row fetch is `global_load_dwordx4 v, voff, s[base:base+1]`; behind a
 // pointer-to-struct they degrade to flat loads with a 64-bit per-lane address each.
-template <typename R, bool CLD, bool DBG>
-__global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
+// BLK: threads per block.  The cloud-free fp32 instantiation exists twice: 256 threads with 8 g-points per k-distribution evaluation
+// (181 VGPRs, two blocks = two wavefronts per SIMD on a CU), and 768 threads with 4 (155 VGPRs: one block = THREE wavefronts per
+// SIMD sharing one copy of the transmittance table).  Measured (RRTMG_LW alone, cloud-free batches of 35 000 / 55 000 / 100 000 columns):
+// 1.96 -> 1.78, 3.05 -> 2.71, 5.44 -> 4.93 ms per call with the wide blocks; in the default mixed batch (38 880 cloud-free columns
+// picked out of 97 200: every array read in the caller's column order then touches 2.5x the cache lines, and twelve wavefronts share
+// a CU's L1) 2.01 -> 2.15 ms.  Both are launched; the one the batch does not call for returns at once (6 us): wide blocks for a
+// batch of at least LW_WIDE_FROM cloud-free columns that is at least four fifths cloud-free.
+constexpr int LW_WIDE_BLOCK = 768;
+#ifndef LW_WIDE_FROM
+#define LW_WIDE_FROM 32768
+#endif
+GR_DEV bool lw_wide_blocks(int nclear, int ncol) { return nclear >= LW_WIDE_FROM && 5 * (long)nclear >= 4 * (long)ncol; }
+template <typename R, bool CLD, bool DBG, int BLK = 256>
+__global__ void __launch_bounds__(BLK, BLK == LW_WIDE_BLOCK ? 3 : 1) k_lw_bands(LwArgs<R> A, LwDev<R> T)
 {
     int bstart, bslot;
     if (!band_block(A.ncol, NB_LW, bstart, bslot)) return;
     if (!((A.band_mask >> LW_BAND_ORDER[bslot]) & 1u)) return;      // a RATS pass re-runs the bands its gas appears in
     const int nclear = *A.nclear;
+    if constexpr (!CLD && !DBG && sizeof(R) == 4) {
+        if (lw_wide_blocks(nclear, A.ncol) != (BLK == LW_WIDE_BLOCK)) return;
+    }
     // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
     // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
     const int bend = bstart + (int)blockDim.x < A.ncol ? bstart + (int)blockDim.x : A.ncol;
@@ -1525,22 +1540,22 @@ __global__ void __launch_bounds__(256) k_lw_bands(LwArgs<R> A, LwDev<R> T)
     if (col >= A.ncol) return;
     if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
     switch (LW_BAND_ORDER[bslot]) {
-        case 1: band_body<R, Band1, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 2: band_body<R, Band2, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 3: band_body<R, Band3, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 4: band_body<R, Band4, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 5: band_body<R, Band5, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 6: band_body<R, Band6, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 7: band_body<R, Band7, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 8: band_body<R, Band8, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 9: band_body<R, Band9, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 10: band_body<R, Band10, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 11: band_body<R, Band11, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 12: band_body<R, Band12, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 13: band_body<R, Band13, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 14: band_body<R, Band14, CLD, DBG>(A, T, col, nclear, luts); break;
-        case 15: band_body<R, Band15, CLD, DBG>(A, T, col, nclear, luts); break;
-        default: band_body<R, Band16, CLD, DBG>(A, T, col, nclear, luts); break;
+        case 1: band_body<R, Band1, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 2: band_body<R, Band2, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 3: band_body<R, Band3, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 4: band_body<R, Band4, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 5: band_body<R, Band5, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 6: band_body<R, Band6, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 7: band_body<R, Band7, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 8: band_body<R, Band8, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 9: band_body<R, Band9, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 10: band_body<R, Band10, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 11: band_body<R, Band11, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 12: band_body<R, Band12, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 13: band_body<R, Band13, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 14: band_body<R, Band14, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        case 15: band_body<R, Band15, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
+        default: band_body<R, Band16, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
     }
 }
 
