@@ -913,6 +913,11 @@ def main():
     # ---- inputs resident in HBM -------------------------------------------------------------------------------
     ncol, nlay = a.ncol, a.nlay
     inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
+    if os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"):
+        # experiment (profiles/): the batch's cloud-free columns first - the library's clear | cloudy partition is then the identity and every
+        # array in the caller's column order is read fully coalesced
+        order = np.argsort((inp["cldf"] > 0).any(axis=0), kind="stable")
+        inp = {k: (np.ascontiguousarray(v[..., order]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v) for k, v in inp.items()}
     if a.coherent > 1:
         # sensitivity knob, not a headline configuration: runs of `coherent` identical profiles (neighbouring lanes then gather the
         # same k-distribution rows, as spatially smooth model fields largely do; the default columns are independent draws)
