@@ -5,7 +5,7 @@
 ! GridComp needs to keep its INTERNAL state on the device between the full calculation and the heartbeat updates.
 module geosrad_gridcomp
    use iso_c_binding
-   use geosrad_c, only : geosrad_ctx_handle, geosrad_fail
+   use geosrad_c, only : geosrad_ctx_handle, geosrad_fail, geosrad_data_path, geosrad_load_tables_chou_sw
    implicit none
    private
    public :: lw_driver_rrtmg, lw_driver_rrtmg_rats, lw_update_rats, lw_update_bands, sw_update_surface, sw_driver_rrtmg, sw_driver_chou, lw_chou_post, lw_update_flx, sw_update_export, rad_tendencies
@@ -338,6 +338,17 @@ contains
       real, intent(in) :: hk_uv_temp(5), hk_ir_temp(3,10)
       logical, intent(in) :: do_drfband
       integer, intent(out) :: rc
+      real :: x
+      logical, save :: loaded = .false.
+      if (.not. loaded) then       ! sorad's coefficient tables (the reference keeps them as module data in sorad_constants)
+         if (kind(x) == 4) then
+            rc = geosrad_load_tables_chou_sw(geosrad_ctx_handle(), geosrad_data_path('chou_sw_r4.grtb'))
+         else
+            rc = geosrad_load_tables_chou_sw(geosrad_ctx_handle(), geosrad_data_path('chou_sw_r8.grtb'))
+         end if
+         if (rc /= 0) return
+         loaded = .true.
+      end if
       rc = geosrad_sw_driver_chou_dev(geosrad_ctx_handle(), c_null_ptr, int(ncol,c_int), int(lm,c_int), fin, consts, int(lcldmh,c_int), &
             int(lcldlm,c_int), hk_uv_temp, hk_ir_temp, merge(1_c_int, 0_c_int, do_drfband), fout)
    end subroutine

@@ -269,6 +269,50 @@ def test_fortran_gridcomp_path_on_device_fields(tmp_path, kind, gpu_ctx):
     assert (got["OLR"] > 100).all() and (got["SFCEM"] > got["SFCEM_INT"]).all()      # a warmer surface emits more
 
 
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_chou_branch_of_soradcore_on_device_fields(tmp_path, kind, gpu_ctx):
+    """swchou_driver.F90: `call sw_driver_chou` (module geosrad_gridcomp) on device-resident GEOS fields - the Chou-Suarez branch of SORADCORE,
+    GEOS_SolarGridComp.F90:4484-4572 / SHRTWAVE :6597-6672; same library, same inputs -> the same bits as the Python mirror of the entry point."""
+    import torch
+    from geosradiation_gridcomp_amd import gridcomp as G
+    from geosradiation_gridcomp_amd import synth
+    exe = os.path.join(FDIR, "bin", f"swchou_driver_{kind}")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    ncol, lm = 70, 72
+    inp = synth.make_columns(ncol, lm, start=909, aerosol=True, cloudy_frac=0.6)
+    f = synth.geos_chou_sw_fields(inp, aerosol=True)
+    f32 = {k: np.ascontiguousarray(f[k], dtype=np.float32) for k in G.SWC_IN}
+    # (the file holds float32: MAPL_UNDEF as the float32 the fields carry, so that the real(8) build recognises it too)
+    consts = G.swc_consts(co2=f["CO2"], UNDEF=float(np.float32(G.MAPL["UNDEF"])))
+    hk = np.concatenate([np.asarray(f["HK_UV"], dtype=np.float32).ravel(), np.asarray(f["HK_IR"], dtype=np.float32).ravel()])
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as fh:
+        np.array([ncol, lm, f["LCLDMH"], f["LCLDLM"]], dtype=np.int32).tofile(fh)
+        np.array(consts, dtype=np.float64).tofile(fh)
+        for k in G.SWC_IN:
+            f32[k].tofile(fh)
+        hk.tofile(fh)
+    env = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
+    subprocess.check_call([exe, str(fin), str(fout)], env=env)
+    raw = np.fromfile(fout, dtype=np.float64)
+    n3p = (lm + 1) * ncol
+    got = dict(zip(["FSW", "FSWU", "NIRR", "FSWBAND", "DRBAND"], np.split(raw, np.cumsum([n3p, n3p, ncol, 8 * ncol]))))
+    ctx = gpu_ctx[4 if kind == "r4" else 8]
+    dt = ctx.dtype
+    tdt = torch.float32 if kind == "r4" else torch.float64
+    st = torch.cuda.current_stream().cuda_stream
+    t = {k: torch.from_numpy(v.astype(dt)).cuda() for k, v in f32.items()}
+    for k in G.SWC_OUT:
+        shp = (lm + 1, ncol) if k in ("FSW", "FSC", "FSWU", "FSCU") else ((8, ncol) if k in ("FSWBAND", "DRBAND", "DFBAND") else (ncol,))
+        t[k] = torch.zeros(shp, dtype=tdt, device="cuda")
+    ctx.sw_driver_chou_dev(st, ncol, lm, {k: v.data_ptr() for k, v in t.items()}, consts, f["LCLDMH"], f["LCLDLM"], hk[:5], hk[5:], do_drfband=True)
+    ctx.check(st)
+    for k, v in got.items():
+        np.testing.assert_array_equal(v, t[k].cpu().numpy().astype(np.float64).ravel(), err_msg=k)
+    assert (got["FSW"].reshape(lm + 1, ncol)[0] > 0.3).all() and (got["DRBAND"] >= 0).all()
+
+
 def test_fortran_dropin_rate_at_full_size(tmp_path, capsys, gpu_ctx):
     """The drop-in path as a GEOS maintainer gets it: Fortran callers (lw_driver / sw_driver, default real, host arrays) on a C360 tile's
     per-GPU share, 97 200 columns x 72 layers, cloudy with aerosols, three calls each - the caller-side time of one call includes
