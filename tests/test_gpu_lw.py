@@ -160,6 +160,31 @@ def test_generator_stops_at_the_waves_highest_cloud(gpu_ctx):
         assert np.abs(q[k] - qr[k]).max() <= 1e-9, k
 
 
+def test_wide_cloud_free_blocks_equal_the_narrow_ones(gpu_ctx):
+    """A mostly cloud-free batch (>= 32 768 cloud-free columns, >= 4/5 of the batch) runs the cloud-free instantiation with 768-thread blocks,
+    4 g-points per evaluation (lw_kernels.hpp k_lw_bands<..., 768>); a small batch of the same columns runs the 256-thread, 8-g-point one.
+    The same columns must come out bitwise the same: ragged sizes (not a multiple of 768 or 256), a mixed block at the clear | cloudy
+    boundary, 91 layers."""
+    from geosradiation_gridcomp_amd import synth
+    ctx = gpu_ctx[4]
+    n, nlay = 36_111, 91
+    inp = synth.make_columns(n, nlay, start=123_456, cloudy_frac=0.03, aerosol=True)
+    ncld = int((inp["cldf"] > 0).any(axis=0).sum())
+    assert n - ncld >= 32_768 and 5 * (n - ncld) >= 4 * n and ncld > 500
+    ctx.set_inhomogeneity(1)
+    try:
+        big = ctx.rrtmg_lw_columns(inp, dudTs=True)
+        for lo in (0, 20_000, n - 777):
+            sl = slice(lo, lo + 777)
+            sub = {k: (np.ascontiguousarray(v[..., sl]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == n else v) for k, v in inp.items()}
+            small = ctx.rrtmg_lw_columns(sub, dudTs=True)
+            for k in FLUX + ("clearCounts",):
+                np.testing.assert_array_equal(small[k], big[k][..., sl], err_msg=k)
+    finally:
+        ctx.set_inhomogeneity(0)
+    assert np.isfinite(big["uflx"]).all() and (big["uflx"][nlay] > 50).all()
+
+
 def test_chunking_is_invisible(gpu_ctx):
     from geosradiation_gridcomp_amd import synth
     ctx = gpu_ctx[4]
