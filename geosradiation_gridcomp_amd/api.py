@@ -178,7 +178,8 @@ class Context:
     # ---- RRTMG_SW, host arrays -------------------------------------------------------------------------
     def rrtmg_sw(self, rpart, ncol, nlay, scon, adjes, coszen, isolvar, play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr,
                  iceflgsw, liqflgsw, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer,
-                 asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, do_drfband=False, bndscl=None, indsolvar=None, out=None):
+                 asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, do_drfband=False, bndscl=None, indsolvar=None, out=None,
+                 solcycfrac=None):
         """rrtmg_sw (SW/rrtmg_sw_rad.F90:68).  Returns dict(swuflx,swdflx,swuflxc,swdflxc (nlay+1,ncol); nirr..uvrf,
         cotdtp..cotnlp (ncol); fswband[,drband,dfband] (14,ncol); clearCounts (4,ncol))."""
         dt = self.dtype
@@ -198,6 +199,7 @@ class Context:
             out["clearCounts"] = np.zeros((4, ncol), dtype=np.int32)
         bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
         ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
+        scf = None if solcycfrac is None else np.array([solcycfrac], dtype=dt)
         ci, cd = ctypes.c_int, ctypes.c_double
         rc = self.L.geosrad_rrtmg_sw(
             self.h, ci(rpart), ci(ncol), ci(nlay), cd(scon), cd(adjes), _p(coszen), ci(isolvar), _p(play), _p(plev), _p(tlay),
@@ -205,21 +207,22 @@ class Context:
             _p(tauaer), _p(ssaaer), _p(asmaer), _p(asdir), _p(asdif), _p(aldir), _p(aldif), ci(int(cloudLM)), ci(int(cloudMH)),
             ci(int(normFlx)), _p(out["clearCounts"]), _p(out["swuflx"]), _p(out["swdflx"]), _p(out["swuflxc"]), _p(out["swdflxc"]),
             *[_p(out[k]) for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "fswband")], *[_p(out[k]) for k in _SW_COT],
-            ci(1 if do_drfband else 0), _p(out.get("drband")), _p(out.get("dfband")), _p(bs), _p(ind))
+            ci(1 if do_drfband else 0), _p(out.get("drband")), _p(out.get("dfband")), _p(bs), _p(ind), _p(scf))
         self._chk(rc)
         return out
 
     def rrtmg_sw_columns(self, inp, scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqflg=1, iaer=0, normFlx=0, do_drfband=False,
-                         bndscl=None, indsolvar=None, rpart=4, out=None):
+                         bndscl=None, indsolvar=None, rpart=4, out=None, solcycfrac=None):
         """Convenience: `inp` as produced by synth.make_columns."""
         nlay, ncol = inp["play"].shape
         aer = [inp.get(k) if iaer == 10 else None for k in ("tauaer_sw", "ssaaer_sw", "asmaer_sw")]
         return self.rrtmg_sw(rpart, ncol, nlay, scon, adjes, inp["coszen"], isolvar, inp["play"], inp["plev"], inp["tlay"],
                              *[inp[k] for k in _SW_GAS], iceflg, liqflg, inp["cldf"], inp["ciwp"], inp["clwp"], inp["rei"], inp["rel"],
                              inp["dyofyr"], inp["zm"], inp["alat"], iaer, *aer, inp["asdir"], inp["asdif"], inp["aldir"], inp["aldif"],
-                             inp["cloudLM"], inp["cloudMH"], normFlx, do_drfband=do_drfband, bndscl=bndscl, indsolvar=indsolvar, out=out)
+                             inp["cloudLM"], inp["cloudMH"], normFlx, do_drfband=do_drfband, bndscl=bndscl, indsolvar=indsolvar, out=out,
+                             solcycfrac=solcycfrac)
 
-    def rrtmg_sw_taumol(self, inp, scon=1361.0, isolvar=0, bndscl=None, indsolvar=None):
+    def rrtmg_sw_taumol(self, inp, scon=1361.0, isolvar=0, bndscl=None, indsolvar=None, solcycfrac=None):
         """(taug, taur) numpy (ncol,112,nlay) and ssi (ncol,112) as left by the reference's taumol_sw."""
         dt = self.dtype
         nlay, ncol = inp["play"].shape
@@ -228,9 +231,10 @@ class Context:
         taug = np.zeros((ncol, NGPTSW, nlay), dtype=dt); taur = np.zeros_like(taug); ssi = np.zeros((ncol, NGPTSW), dtype=dt)
         bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
         ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
+        scf = None if solcycfrac is None else np.array([solcycfrac], dtype=dt)
         rc = self.L.geosrad_rrtmg_sw_taumol(self.h, ctypes.c_int(ncol), ctypes.c_int(nlay), ctypes.c_double(scon), ctypes.c_int(isolvar),
                                             _p(a["play"]), _p(a["plev"]), _p(a["tlay"]), *[_p(a[k]) for k in _SW_GAS], _p(bs), _p(ind),
-                                            _p(taug), _p(taur), _p(ssi))
+                                            _p(scf), _p(taug), _p(taur), _p(ssi))
         self._chk(rc)
         return taug, taur, ssi
 
@@ -251,12 +255,13 @@ class Context:
         return o
 
     def rrtmg_sw_dev(self, stream, ncol, nlay, scon, adjes, isolvar, ptr, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx=0,
-                     do_drfband=False, bndscl=None, indsolvar=None, rpart=4):
+                     do_drfband=False, bndscl=None, indsolvar=None, rpart=4, solcycfrac=None):
         """`ptr`: dict name -> device address (int) for every argument array of rrtmg_sw (inputs and outputs)."""
         dt = self.dtype
         v = lambda k: ctypes.c_void_p(ptr[k]) if ptr.get(k) else None
         bs = None if bndscl is None else np.ascontiguousarray(bndscl, dtype=dt)
         ind = None if indsolvar is None else np.ascontiguousarray(indsolvar, dtype=dt)
+        scf = None if solcycfrac is None else np.array([solcycfrac], dtype=dt)
         ci, cd = ctypes.c_int, ctypes.c_double
         rc = self.L.geosrad_rrtmg_sw_dev(
             self.h, ctypes.c_void_p(stream), ci(rpart), ci(ncol), ci(nlay), cd(scon), cd(adjes), v("coszen"), ci(isolvar), v("play"),
@@ -264,7 +269,7 @@ class Context:
             ci(int(dyofyr)), v("zm"), v("alat"), ci(iaer), v("tauaer_sw"), v("ssaaer_sw"), v("asmaer_sw"), v("asdir"), v("asdif"),
             v("aldir"), v("aldif"), ci(int(cloudLM)), ci(int(cloudMH)), ci(int(normFlx)), v("clearCounts_sw"), v("swuflx"), v("swdflx"),
             v("swuflxc"), v("swdflxc"), *[v(k) for k in ("nirr", "nirf", "parr", "parf", "uvrr", "uvrf", "fswband")],
-            *[v(k) for k in _SW_COT], ci(1 if do_drfband else 0), v("drband"), v("dfband"), _p(bs), _p(ind))
+            *[v(k) for k in _SW_COT], ci(1 if do_drfband else 0), v("drband"), v("dfband"), _p(bs), _p(ind), _p(scf))
         self._chk(rc)
 
     # ---- Chou-Suarez LW, host arrays ---------------------------------------------------------------------

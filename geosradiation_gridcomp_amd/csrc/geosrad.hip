@@ -484,7 +484,8 @@ struct geosrad_ctx {
                            void *const *aer, void *const *out) = 0;
     virtual int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg,
                        int liqflg, int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
-                       int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
+                       int do_drfband, const void *bndscl, const void *indsolvar, const void *solcycfrac,
+                       void *const *dbg) = 0;
     virtual int lw_driver_dev(hipStream_t st, int ncol, int lm, int nb, const void *const *in, const double *consts, int iceflg,
                               int liqflg, int doy, int lcldlm, int lcldmh, const int32_t *band_output, void *const *out, int nrats,
                               const int32_t *rat_gas, void *const *rat_out) = 0;
@@ -506,7 +507,8 @@ struct geosrad_ctx {
                                    void *const *out) = 0;
     virtual int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
                         int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out,
-                        int do_drfband, const void *bndscl, const void *indsolvar, void *const *dbg) = 0;
+                        int do_drfband, const void *bndscl, const void *indsolvar, const void *solcycfrac,
+                       void *const *dbg) = 0;
     virtual int lit_index_dev(hipStream_t st, int ncol, const void *zth, int32_t *idx, int32_t *pos, int32_t *nlit_dev, int *nlit_host) = 0;
     virtual int lit_pack_dev(hipStream_t st, int pdim, int udim, int nlev, const int32_t *idx, const int32_t *nlit_dev, const void *unpacked,
                              void *packed) = 0;
@@ -557,6 +559,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     // RRTMG_SW tables
     char *d_tab_sw = nullptr; size_t tab_sw_bytes = 0;
     SwDev<R> h_S{};
+    std::vector<R> avgcyc_mg, avgcyc_sb;          // NRLSSI2 mgavgcyc / sbavgcyc (134 each), host only: isolvar == 1
     SwDev<R> *d_S = nullptr;
     bool have_sw = false;
     char *d_ws_sw = nullptr; size_t ws_sw_bytes = 0; int ws_sw_ncol = 0, ws_sw_nlay = 0, ws_sw_planes = 0;
@@ -1133,6 +1136,8 @@ template <typename R> struct Ctx : geosrad_ctx {
     {
         HIPCHK(hipSetDevice(device));
         if (ncol <= 0 || lm < 4 || nb < 0 || nb > 14) return fail(GEOSRAD_EINVAL, "bad ncol/lm/nb_aer");
+        // SORADCORE asserts the solar-variability options it supports before the call (GEOS_SolarGridComp.F90:6286-6292): no isolvar 1
+        if (isolvar == 1) return fail(GEOSRAD_EINPUT, "SORADCORE: ISOLVAR == 1 is not supported by the GridComp (the solver entry point rrtmg_sw accepts it)");
         for (int k = 0; k < GEOSRAD_SWD_NIN; k++)
             if (!in[k] && k != GEOSRAD_SWD_TAUA && k != GEOSRAD_SWD_SSAA && k != GEOSRAD_SWD_ASYA) return fail(GEOSRAD_EINVAL, "null input array");
         const bool aer = in[GEOSRAD_SWD_TAUA] != nullptr;
@@ -1198,7 +1203,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             nout[SO_FSWBAND] = out[GEOSRAD_SWD_FSWBANDNA] ? out[GEOSRAD_SWD_FSWBANDNA] : (void *)P(o_nband);
         }
         rc = sw_run(st, ncol, lm, sc, dist, isolvar, sin, iceflg, liqflg, dyofyr, 10, lm - lcldlm + 1, lm - lcldmh + 1,
-                    normflx, cc, sout, 0, bndsolvar, indsolvar, nullptr, want_na ? nout : nullptr);
+                    normflx, cc, sout, 0, bndsolvar, indsolvar, nullptr, nullptr, want_na ? nout : nullptr);
         if (rc) return rc;
         SwdPost<R> Q{};
         Q.ncol = ncol; Q.lm = lm; Q.ngpt = NG_SW; Q.aerosols = include_aerosols; Q.undef = (R)consts[GEOSRAD_SWD_C_UNDEF];
@@ -1693,6 +1698,13 @@ template <typename R> struct Ctx : geosrad_ctx {
         T.oneminus = S.scalar("oneminus"); T.grav = S.scalar("grav"); T.avogad = S.scalar("avogad"); T.rrsw_scon = S.scalar("rrsw_scon");
         T.Iint = S.scalar("Iint"); T.Fint = S.scalar("Fint"); T.Sint = S.scalar("Sint");
         T.Mg_avg = S.scalar("Mg_avg"); T.Mg_0 = S.scalar("Mg_0"); T.SB_avg = S.scalar("SB_avg"); T.SB_0 = S.scalar("SB_0");
+        {   // AvgCyc11 of the two indices (isolvar == 1 only; blobs written before round 4 lack them: that option is then refused)
+            avgcyc_mg.clear(); avgcyc_sb.clear();
+            if (B.e.count("mgavgcyc") && B.e.count("sbavgcyc")) {
+                const R *m = S.get("mgavgcyc", 134), *q = S.get("sbavgcyc", 134);
+                if (m && q) { avgcyc_mg.assign(m, m + 134); avgcyc_sb.assign(q, q + 134); }
+            }
+        }
         {
             int32_t icxa[14], ngb[112];
             if (S.ints("icxa", 14, icxa)) for (int b = 1; b <= NB_SW; b++) T.icxa[b] = icxa[b - 1];
@@ -1758,16 +1770,83 @@ template <typename R> struct Ctx : geosrad_ctx {
     }
 
     // solar variability block of the driver (SW/rrtmg_sw_rad.F90:893-1127), scalars only
-    int sw_solar(double scon_d, double adjes_d, int isolvar, const R *bndscl, const R *indsolvar, SwSolar<R> &SV)
+    // NRLSSI2's host routines for isolvar == 1 (SW/NRLSSI2.F90; nsolfrac = 134, intrvl_len = 1 / 132) - false where the reference error-stops
+    static bool nrl_adjust(R solcycfr, const R *indsolvar, R *scl)          // adjust_solcyc_amplitudes (:236-271)
+    {
+        const R fmin = (R)0.0189, fmax = (R)0.3750, dmin2max = fmax - fmin, dmax2min = (R)1. - dmin2max;
+        if (solcycfr >= 0 && solcycfr < fmin) {
+            const R wgt = (solcycfr + (R)1. - fmax) / dmax2min;
+            scl[0] = indsolvar[0] + wgt * ((R)1. - indsolvar[0]); scl[1] = indsolvar[1] + wgt * ((R)1. - indsolvar[1]);
+        } else if (solcycfr >= fmin && solcycfr <= fmax) {
+            const R wgt = (solcycfr - fmin) / dmin2max;
+            scl[0] = (R)1. + wgt * (indsolvar[0] - (R)1.); scl[1] = (R)1. + wgt * (indsolvar[1] - (R)1.);
+        } else if (solcycfr > fmax && solcycfr <= 1) {
+            const R wgt = (solcycfr - fmax) / dmax2min;
+            scl[0] = indsolvar[0] + wgt * ((R)1. - indsolvar[0]); scl[1] = indsolvar[1] + wgt * ((R)1. - indsolvar[1]);
+        } else return false;
+        return true;
+    }
+    bool nrl_interp(R solcycfr, R &Mg, R &SB) const                         // interpolate_indices (:277-332)
+    {
+        const R il = (R)1.0 / (R)132, ilh = (R)0.5 * il;
+        const R *mg = avgcyc_mg.data() - 1, *sb = avgcyc_sb.data() - 1;     // 1-based like the reference
+        if (solcycfr > 0 && solcycfr < 1) {
+            int sfid; R lo, hi;
+            if (solcycfr <= ilh) { sfid = 1; lo = 0; hi = ilh; }
+            else if (solcycfr > ilh && solcycfr < (R)1. - ilh) { sfid = (int)std::floor((solcycfr - ilh) * (R)132) + 2; lo = (R)(sfid - 2) * il + ilh; hi = lo + il; }
+            else { sfid = 133; lo = (R)1. - ilh; hi = 1; }
+            const R f = (solcycfr - lo) / (hi - lo);
+            Mg = mg[sfid] + f * (mg[sfid + 1] - mg[sfid]); SB = sb[sfid] + f * (sb[sfid + 1] - sb[sfid]);
+        } else if (solcycfr == 0) { Mg = mg[1]; SB = sb[1]; }
+        else if (solcycfr == 1) { Mg = mg[134]; SB = sb[134]; }
+        else return false;
+        return true;
+    }
+    void nrl_means(const R *ind_opt, R &mean_f, R &mean_s) const             // initialize_NRLSSI2, isolvar == 1 (:160-232)
+    {
+        const SwDev<R> &T = h_S;
+        const R il = (R)1.0 / (R)132, ilh = (R)0.5 * il;
+        const R *mg = avgcyc_mg.data() - 1, *sb = avgcyc_sb.data() - 1;
+        const R ind[2] = {ind_opt ? ind_opt[0] : (R)1, ind_opt ? ind_opt[1] : (R)1};
+        mean_f = 1; mean_s = 1;
+        const bool s1 = ind[0] != 1, s2 = ind[1] != 1;
+        if (!s1 && !s2) return;
+        const R m1 = ((R)1. + ind[0]) / (R)2., m2 = ((R)1. + ind[1]) / (R)2.;
+        R a1 = 0, a2 = 0, scl[2], fr = ilh;
+        for (int n = 2; n <= 133; n++) {
+            nrl_adjust(fr, ind, scl);
+            if (s1) a1 = a1 + scl[0] * mg[n];
+            if (s2) a2 = a2 + scl[1] * sb[n];
+            fr = fr + il;
+        }
+        if (s1) { a1 = a1 / (R)132; mean_f = (a1 - m1 * T.Mg_0) / (T.Mg_avg - T.Mg_0); }
+        if (s2) { a2 = a2 / (R)132; mean_s = (a2 - m2 * T.SB_0) / (T.SB_avg - T.SB_0); }
+    }
+
+    int sw_solar(double scon_d, double adjes_d, int isolvar, const R *bndscl, const R *indsolvar, const R *solcycfrac, SwSolar<R> &SV)
     {
         const SwDev<R> &T = h_S;
         const R scon = (R)scon_d, adjes = (R)adjes_d;
         R solvar[NB_SW + 1];
         for (int b = 0; b <= NB_SW; b++) { solvar[b] = 1; SV.svar_bnd[b] = 1; SV.adjflux[b] = 1; }
         SV.isolvar = isolvar; SV.svar_f = 1; SV.svar_s = 1; SV.svar_i = 1;
-        if (isolvar == 1)
-            return fail(GEOSRAD_EINPUT, "isolvar == 1 (averaged solar cycle) is not supported: GEOS_SolarGridComp rejects it as well");
-        if (isolvar != -1 && isolvar != 0 && isolvar != 2 && isolvar != 3) return fail(GEOSRAD_EINPUT, "invalid isolvar");
+        if (isolvar != -1 && isolvar != 0 && isolvar != 1 && isolvar != 2 && isolvar != 3) return fail(GEOSRAD_EINPUT, "invalid isolvar");
+        if (isolvar == 1) {
+            // position in AvgCyc11 from solcycfrac, amplitude scaling from indsolvar (rrtmg_sw_rad.F90:906-930, :994-1008, :1060-1079)
+            if (!solcycfrac) return fail(GEOSRAD_EINPUT, "isolvar == 1 requires solcycfrac present!");
+            if (avgcyc_mg.size() != 134 || avgcyc_sb.size() != 134)
+                return fail(GEOSRAD_ETABLE, "isolvar == 1 needs the mgavgcyc / sbavgcyc entries of the RRTMG_SW table blob");
+            if (scon < 0) return fail(GEOSRAD_EINPUT, "scon must be >= 0");
+            const R fr = *solcycfrac;
+            R scl[2] = {1, 1}, Mg_now, SB_now, mean_f, mean_s;
+            if (indsolvar && (indsolvar[0] != 1 || indsolvar[1] != 1))
+                if (!nrl_adjust(fr, indsolvar, scl)) return fail(GEOSRAD_EINPUT, "RRTMG_SW: solcycfr must be in [0,1]");
+            nrl_means(indsolvar, mean_f, mean_s);
+            if (!nrl_interp(fr, Mg_now, SB_now)) return fail(GEOSRAD_EINPUT, "RRTMG_SW: solcycfr must be in [0,1]");
+            SV.svar_f = scl[0] * (Mg_now - T.Mg_0) / (T.Mg_avg - T.Mg_0);
+            SV.svar_s = scl[1] * (SB_now - T.SB_0) / (T.SB_avg - T.SB_0);
+            SV.svar_i = scon == 0 ? (R)1 : (scon - (mean_f * T.Fint + mean_s * T.Sint)) / T.Iint;
+        }
         R ndx0 = T.Mg_avg, ndx1 = T.SB_avg;
         if (isolvar == 2 && indsolvar) { ndx0 = indsolvar[0]; ndx1 = indsolvar[1]; }
         if (scon == 0) {
@@ -1794,10 +1873,10 @@ template <typename R> struct Ctx : geosrad_ctx {
     // ---- RRTMG_SW, device pointers -------------------------------------------------------------------------
     int sw_dev(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
                int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband,
-               const void *bndscl, const void *indsolvar, void *const *dbg) override
+               const void *bndscl, const void *indsolvar, const void *solcycfrac, void *const *dbg) override
     {
         return sw_run(st, ncol, nlay, scon, adjes, isolvar, in, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx, clearCounts, out,
-                      do_drfband, bndscl, indsolvar, dbg, nullptr);
+                      do_drfband, bndscl, indsolvar, solcycfrac, dbg, nullptr);
     }
 
     // RRTMG_SW band sweeps: k_sw_reform (lane = (column, unit of g-points); fp32 re-forms the cell optics in its second sweep and parks 12
@@ -1809,7 +1888,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     // sw_na_out (SwOutIx order, all of SO_UFLX .. SO_COT0 + 7 non-null) requests an additional pass without the aerosol terms
     int sw_run(hipStream_t st, int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg,
                int dyofyr, int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband,
-               const void *bndscl, const void *indsolvar, void *const *dbg, void *const *sw_na_out)
+               const void *bndscl, const void *indsolvar, const void *solcycfrac, void *const *dbg, void *const *sw_na_out)
     {
         HIPCHK(hipSetDevice(device));
         if (!have_sw) return fail(GEOSRAD_EINVAL, "RRTMG_SW tables not set: call geosrad_set_tables_sw first (rrtmg_sw_ini)");
@@ -1823,7 +1902,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         for (int k = 0; k < SO_DRBAND; k++) if (!out[k]) return fail(GEOSRAD_EINVAL, "null output array");
         if (do_drfband && (!out[SO_DRBAND] || !out[SO_DFBAND])) return fail(GEOSRAD_EINVAL, "do_drfband set but drband/dfband null");
         SwSolar<R> SV;
-        int rc = sw_solar(scon, adjes, isolvar, (const R *)bndscl, (const R *)indsolvar, SV);
+        int rc = sw_solar(scon, adjes, isolvar, (const R *)bndscl, (const R *)indsolvar, (const R *)solcycfrac, SV);
         if (rc) return rc;
 
         // one band's [layer][g<=12][column] plane must stay below 4 GiB (32-bit byte offsets)
@@ -1939,7 +2018,7 @@ template <typename R> struct Ctx : geosrad_ctx {
     // ---- RRTMG_SW, host pointers ---------------------------------------------------------------------------
     int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg, int dyofyr,
                 int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband, const void *bndscl,
-                const void *indsolvar, void *const *dbg) override
+                const void *indsolvar, const void *solcycfrac, void *const *dbg) override
     {
         HIPCHK(hipSetDevice(device));
         if (ncol <= 0 || nlay <= 0) return fail(GEOSRAD_EINVAL, "bad ncol/nlay");
@@ -1972,7 +2051,7 @@ template <typename R> struct Ctx : geosrad_ctx {
                 for (int k = 0; k < S_NIN; k++) din[k] = ix_in[k] >= 0 ? dev + arrs[ix_in[k]].off : nullptr;
                 for (int k = 0; k < SO_NOUT; k++) dout[k] = ix_out[k] >= 0 ? dev + arrs[ix_out[k]].off : nullptr;
                 return sw_dev(st, nc, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
-                              (int32_t *)(dev + arrs[ix_cc].off), dout, do_drfband, bndscl, indsolvar, nullptr);
+                              (int32_t *)(dev + arrs[ix_cc].off), dout, do_drfband, bndscl, indsolvar, solcycfrac, nullptr);
             };
             int rc = clear_slot(1);
             if (rc) return rc;
@@ -2012,7 +2091,7 @@ template <typename R> struct Ctx : geosrad_ctx {
         void *ddbg[6] = {d_io + dbgo[0], d_io + dbgo[1], d_io + dbgo[2], nullptr, nullptr, nullptr};
         if (dbg && dbg[3]) for (int k = 3; k < 6; k++) ddbg[k] = d_io + dbgo[k];
         rc = sw_dev(stream, ncol, nlay, scon, adjes, isolvar, din, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
-                    (int32_t *)(d_io + cco), dout, do_drfband, bndscl, indsolvar, dbg ? ddbg : nullptr);
+                    (int32_t *)(d_io + cco), dout, do_drfband, bndscl, indsolvar, solcycfrac, dbg ? ddbg : nullptr);
         if (rc) return rc;
         rc = check(stream, 1);
         if (rc) return rc;
@@ -2482,7 +2561,7 @@ struct MultiCtx final : geosrad_ctx {
     }
     int sw_host(int ncol, int nlay, double scon, double adjes, int isolvar, const void *const *in, int iceflg, int liqflg, int dyofyr,
                 int iaer, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *const *out, int do_drfband, const void *bndscl,
-                const void *indsolvar, void *const *dbg) override
+                const void *indsolvar, const void *solcycfrac, void *const *dbg) override
     {
         if (dbg) return fail(GEOSRAD_EINVAL, "stage dumps need a single-device context");
         const size_t E = (size_t)real_kind;
@@ -2491,7 +2570,7 @@ struct MultiCtx final : geosrad_ctx {
             for (int j = 0; j < S_NIN; j++) i2[j] = off(in[j], (size_t)c0 * E);
             for (int j = 0; j < SO_NOUT; j++) o2[j] = off(out[j], (size_t)c0 * E);
             return k->sw_host(nc, nlay, scon, adjes, isolvar, i2, iceflg, liqflg, dyofyr, iaer, cloudLM, cloudMH, normFlx,
-                              clearCounts ? clearCounts + c0 : nullptr, o2, do_drfband, bndscl, indsolvar, nullptr);
+                              clearCounts ? clearCounts + c0 : nullptr, o2, do_drfband, bndscl, indsolvar, solcycfrac, nullptr);
         });
     }
     int irrad_host(int m, int np, const void *const *in, double co2, int trace, int ict, int icb, int ns, int na, int nb, void *const *aer,
@@ -2526,7 +2605,7 @@ struct MultiCtx final : geosrad_ctx {
     int sorad_dev(hipStream_t, int, int, int, const void *const *, double, int, int, const void *, const void *, void *const *, int) override { return nodev("geosrad_sorad_dev"); }
     int irrad_dev(hipStream_t, int, int, const void *const *, double, int, int, int, int, int, int, void *const *, void *const *) override { return nodev("geosrad_irrad_dev"); }
     int sw_dev(hipStream_t, int, int, double, double, int, const void *const *, int, int, int, int, int, int, int, int32_t *, void *const *, int,
-               const void *, const void *, void *const *) override { return nodev("geosrad_rrtmg_sw_dev"); }
+               const void *, const void *, const void *, void *const *) override { return nodev("geosrad_rrtmg_sw_dev"); }
     int lw_driver_dev(hipStream_t, int, int, int, const void *const *, const double *, int, int, int, int, int, const int32_t *, void *const *, int,
                       const int32_t *, void *const *) override { return nodev("geosrad_lw_driver_rrtmg_dev"); }
     int sw_driver_dev(hipStream_t, int, int, int, const void *const *, const double *, int, int, double, double, int, int, int, int, int, int,
@@ -2700,13 +2779,14 @@ int geosrad_rrtmg_sw(geosrad_ctx *c, int rpart, int ncol, int nlay, double scon,
                      const void *aldir, const void *aldif, int cloudLM, int cloudMH, int normFlx, int32_t *clearCounts, void *swuflx,
                      void *swdflx, void *swuflxc, void *swdflxc, void *nirr, void *nirf, void *parr, void *parf, void *uvrr,
                      void *uvrf, void *fswband, void *cotdtp, void *cotdhp, void *cotdmp, void *cotdlp, void *cotntp, void *cotnhp,
-                     void *cotnmp, void *cotnlp, int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar)
+                     void *cotnmp, void *cotnlp, int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar,
+                     const void *solcycfrac)
 {
     if (!c) return GEOSRAD_EINVAL;
     (void)rpart;
     SW_PACK();
     return c->sw_host(ncol, nlay, scon, adjes, isolvar, in, iceflgsw, liqflgsw, dyofyr, iaer, cloudLM, cloudMH, normFlx, clearCounts, out,
-                      do_drfband, bndscl, indsolvar, nullptr);
+                      do_drfband, bndscl, indsolvar, solcycfrac, nullptr);
 }
 
 int geosrad_rrtmg_sw_dev(geosrad_ctx *c, void *stream, int rpart, int ncol, int nlay, double scon, double adjes, const void *coszen,
@@ -2718,18 +2798,20 @@ int geosrad_rrtmg_sw_dev(geosrad_ctx *c, void *stream, int rpart, int ncol, int 
                          int32_t *clearCounts, void *swuflx, void *swdflx, void *swuflxc, void *swdflxc, void *nirr, void *nirf,
                          void *parr, void *parf, void *uvrr, void *uvrf, void *fswband, void *cotdtp, void *cotdhp, void *cotdmp,
                          void *cotdlp, void *cotntp, void *cotnhp, void *cotnmp, void *cotnlp, int do_drfband, void *drband,
-                         void *dfband, const void *bndscl, const void *indsolvar)
+                         void *dfband, const void *bndscl, const void *indsolvar,
+                     const void *solcycfrac)
 {
     if (!c || !clearCounts) return GEOSRAD_EINVAL;
     (void)rpart;
     SW_PACK();
     return c->sw_dev((hipStream_t)stream, ncol, nlay, scon, adjes, isolvar, in, iceflgsw, liqflgsw, dyofyr, iaer, cloudLM, cloudMH, normFlx,
-                     clearCounts, out, do_drfband, bndscl, indsolvar, nullptr);
+                     clearCounts, out, do_drfband, bndscl, indsolvar, solcycfrac, nullptr);
 }
 
 int geosrad_rrtmg_sw_taumol(geosrad_ctx *c, int ncol, int nlay, double scon, int isolvar, const void *play, const void *plev,
                             const void *tlay, const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr,
-                            const void *o2vmr, const void *bndscl, const void *indsolvar, void *taug, void *taur, void *ssi)
+                            const void *o2vmr, const void *bndscl, const void *indsolvar, const void *solcycfrac, void *taug, void *taur,
+                            void *ssi)
 {
     if (!c || !taug || !taur || !ssi || ncol <= 0 || nlay <= 0) return GEOSRAD_EINVAL;
     // clear-sky run (zero cloud field, overhead sun, black surface); fluxes are discarded
@@ -2752,7 +2834,7 @@ int geosrad_rrtmg_sw_taumol(geosrad_ctx *c, int ncol, int nlay, double scon, int
          *cotnmp = q + 6 * cn, *cotnlp = q + 7 * cn, *drband = nullptr, *dfband = nullptr;
     SW_PACK();
     void *dbg[6] = {taug, taur, ssi, nullptr, nullptr, nullptr};
-    return c->sw_host(ncol, nlay, scon, 1.0, isolvar, in, 3, 1, 1, 0, 1, 2, 0, cc.data(), out, 0, bndscl, indsolvar, dbg);
+    return c->sw_host(ncol, nlay, scon, 1.0, isolvar, in, 3, 1, 1, 0, 1, 2, 0, cc.data(), out, 0, bndscl, indsolvar, solcycfrac, dbg);
 }
 
 int geosrad_rrtmg_sw_cldprmc(geosrad_ctx *c, int ncol, int nlay, const void *play, const void *plev, const void *tlay, const void *h2ovmr,
@@ -2779,7 +2861,7 @@ int geosrad_rrtmg_sw_cldprmc(geosrad_ctx *c, int ncol, int nlay, const void *pla
     q += 8 * cn;
     SW_PACK();
     void *dbg[6] = {q, q + cg, q + 2 * cg, taucmc, ssacmc, asmcmc};
-    return c->sw_host(ncol, nlay, 1361.0, 1.0, 0, in, iceflgsw, liqflgsw, dyofyr, 0, cloudLM, cloudMH, 0, cc.data(), out, 0, nullptr, nullptr, dbg);
+    return c->sw_host(ncol, nlay, 1361.0, 1.0, 0, in, iceflgsw, liqflgsw, dyofyr, 0, cloudLM, cloudMH, 0, cc.data(), out, 0, nullptr, nullptr, nullptr, dbg);
 }
 
 int geosrad_set_tables_chou_lw(geosrad_ctx *c, const void *blob, size_t n) { return c ? c->set_tables_chou_lw(blob, n) : GEOSRAD_EINVAL; }

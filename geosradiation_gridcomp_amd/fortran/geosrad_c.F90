@@ -33,15 +33,16 @@ module geosrad_c
             h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr, iceflgsw, liqflgsw, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, &
             iaer, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, cloudLM, cloudMH, normFlx, clearCounts, &
             swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, &
-            cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, do_drfband, drband, dfband, bndscl, indsolvar) &
-            bind(C, name='geosrad_rrtmg_sw')
+            cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, do_drfband, drband, dfband, bndscl, indsolvar, &
+            solcycfrac) bind(C, name='geosrad_rrtmg_sw')
          import :: c_int, c_ptr, c_double
          type(c_ptr), value :: ctx
          integer(c_int), value :: rpart, ncol, nlay, isolvar, iceflgsw, liqflgsw, dyofyr, iaer, cloudLM, cloudMH, normFlx, do_drfband
          real(c_double), value :: scon, adjes
          type(c_ptr), value :: coszen, play, plev, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, o2vmr, cld, ciwp, clwp, rei, rel, zm, alat, &
             tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, clearCounts, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, &
-            parf, uvrr, uvrf, fswband, cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, drband, dfband, bndscl, indsolvar
+            parf, uvrr, uvrf, fswband, cotdtp, cotdhp, cotdmp, cotdlp, cotntp, cotnhp, cotnmp, cotnlp, drband, dfband, bndscl, indsolvar, &
+            solcycfrac
       end function
       integer(c_int) function geosrad_load_tables_chou_lw(ctx, path) bind(C, name='geosrad_load_tables_chou_lw')
          import :: c_int, c_ptr, c_char

@@ -98,19 +98,20 @@ contains
       ! set, and then as the non-contiguous section ptr2(1:Num2do,:) (GEOS_SolarGridComp.F90:778,4148-4151,6385)
       real, intent(inout), dimension(:,:), pointer :: drband, dfband
       real, intent(in), optional, target :: bndscl(nbndsw), indsolvar(2)
-      real, intent(in), optional :: solcycfrac
+      real, intent(in), optional, target :: solcycfrac
       integer, intent(out), optional :: RC
       integer(c_int), target :: cc(ncol,4)
       integer(c_int) :: st
-      type(c_ptr) :: pb, pi, pdr, pdf
+      type(c_ptr) :: pb, pi, pdr, pdf, pf
       real, allocatable, target :: zdr(:,:), zdf(:,:)       ! contiguous (ncol,nbndsw) images of the pointer targets
-      pb = c_null_ptr; pi = c_null_ptr; pdr = c_null_ptr; pdf = c_null_ptr
+      pb = c_null_ptr; pi = c_null_ptr; pdr = c_null_ptr; pdf = c_null_ptr; pf = c_null_ptr
       if (do_drfband) then                                   ! the pointers are touched only in this case, like the reference
          allocate(zdr(ncol,nbndsw), zdf(ncol,nbndsw))
          pdr = c_loc(zdr); pdf = c_loc(zdf)
       end if
       if (present(bndscl)) pb = c_loc(bndscl)
       if (present(indsolvar)) pi = c_loc(indsolvar)
+      if (present(solcycfrac)) pf = c_loc(solcycfrac)        ! isolvar = 1 (rrtmg_sw_rad.F90:906-930)
       ! The reference's timers (rrtmg_sw_rad.F90:1181-1200 registers ---RRTMG_PART, _CLDSGEN, _CLDPRMC, _SETCOEF, _TAUMOL, _REFTRA, _VRTQDR):
       ! the whole call is one asynchronous pipeline here, so on the host it is charged to ---RRTMG_PART (the timer that brackets the
       ! reference's partition loop); the stages carry the reference's names as roctx ranges on the GPU timeline (GEOSRAD_ROCTX=1,
@@ -127,7 +128,7 @@ contains
          c_loc(swuflx), c_loc(swdflx), c_loc(swuflxc), c_loc(swdflxc), &
          c_loc(nirr), c_loc(nirf), c_loc(parr), c_loc(parf), c_loc(uvrr), c_loc(uvrf), c_loc(fswband), &
          c_loc(cotdtp), c_loc(cotdhp), c_loc(cotdmp), c_loc(cotdlp), c_loc(cotntp), c_loc(cotnhp), c_loc(cotnmp), c_loc(cotnlp), &
-         merge(1_c_int, 0_c_int, do_drfband), pdr, pdf, pb, pi)
+         merge(1_c_int, 0_c_int, do_drfband), pdr, pdf, pb, pi, pf)
 #ifdef GEOSRAD_WITH_MAPL
       call MAPL_TimerOff(MAPL, "---RRTMG_PART")
 #endif

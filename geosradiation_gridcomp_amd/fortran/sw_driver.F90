@@ -19,8 +19,9 @@ program sw_driver
    real, allocatable, dimension(:,:,:) :: tauaer, ssaaer, asmaer
    integer, allocatable :: cc(:,:)
    character(len=512) :: fin, fout
-   character(len=32) :: frep
+   character(len=32) :: frep, ffrac
    integer :: nrep
+   real :: solcycfrac, indsolvar(2)
    integer(8) :: t0, t1, trate
    call get_command_argument(1, fin); call get_command_argument(2, fout)
    open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
@@ -48,10 +49,22 @@ program sw_driver
    if (ih /= 0) call set_inhomogeneity(ih)        ! RAD:Initialize (GEOS_RadiationGridComp.F90:564-565)
    call rrtmg_sw_ini
    mapl_placeholder = 0
+   ! optional fourth argument: the position in the mean solar cycle for isolvar = 1 (the optional arguments INDSOLVAR, SOLCYCFRAC of
+   ! rrtmg_sw_rad.F90:122-124 by keyword)
+   call get_command_argument(4, ffrac)
+   if (len_trim(ffrac) > 0) then
+      read(ffrac, *) solcycfrac
+      indsolvar = (/ 1.15, 0.9 /)
+      call rrtmg_sw(mapl_placeholder, 4, ncol, nlay, real(scon4), 1.0, coszen, isolvar, play, plev, tlay, h2o, o3, co2, ch4, o2, &
+         3, 1, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, &
+         cloudLM, cloudMH, normFlx, cc, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, &
+         c1, c2, c3, c4, c5, c6, c7, c8, .true., drband, dfband, INDSOLVAR=indsolvar, SOLCYCFRAC=solcycfrac, RC=rc)
+   else
    call rrtmg_sw(mapl_placeholder, 4, ncol, nlay, real(scon4), 1.0, coszen, isolvar, play, plev, tlay, h2o, o3, co2, ch4, o2, &
       3, 1, cld, ciwp, clwp, rei, rel, dyofyr, zm, alat, iaer, tauaer, ssaaer, asmaer, asdir, asdif, aldir, aldif, &
       cloudLM, cloudMH, normFlx, cc, swuflx, swdflx, swuflxc, swdflxc, nirr, nirf, parr, parf, uvrr, uvrf, fswband, &
       c1, c2, c3, c4, c5, c6, c7, c8, .true., drband, dfband, RC=rc)
+   end if
    ! optional third argument: repeat the call that many times and report the caller-side time of one call
    call get_command_argument(3, frep)
    if (len_trim(frep) > 0) then

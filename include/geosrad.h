@@ -170,8 +170,11 @@ int geosrad_rrtmg_lw_taumol(geosrad_ctx *ctx, int ncol, int nlay,
  *   swuflx, swdflx, swuflxc, swdflxc (ncol,nlay+1); nirr..uvrf, cot* (ncol); fswband, drband, dfband (ncol,14)
  *   (drband/dfband written only when do_drfband != 0); clearCounts int32 (ncol,4).
  *   scon, adjes: double here, rounded to real_kind like the reference's default-real dummy arguments.
- *   bndscl (14 reals) and indsolvar (2 reals): HOST pointers in both variants, NULL = absent optional argument.
- *   isolvar in {-1, 0, 2, 3}; 1 (solcycfrac) returns GEOSRAD_EINPUT -- GEOS_SolarGridComp.F90:6286-6292 rejects it too.
+ *   bndscl (14 reals), indsolvar (2 reals) and solcycfrac (1 real): HOST pointers in both variants, NULL = absent optional argument.
+ *   isolvar in {-1, 0, 1, 2, 3} (rrtmg_sw_rad.F90:893-1127).  1 = position solcycfrac in [0, 1] of the mean solar cycle AvgCyc11 with
+ *   NRLSSI2's adjust_solcyc_amplitudes / interpolate_indices (NRLSSI2.F90:236-332): needs solcycfrac (GEOSRAD_EINPUT otherwise, as the
+ *   reference's _FAIL).  The GridComp-level entry point geosrad_sw_driver_rrtmg_dev refuses it like SORADCORE does
+ *   (GEOS_SolarGridComp.F90:6286-6292).
  *   rpart (the reference's column-partition size) is accepted and ignored: the GPU batches internally. */
 int geosrad_rrtmg_sw(geosrad_ctx *ctx, int rpart, int ncol, int nlay, double scon, double adjes, const void *coszen, int isolvar,
                      const void *play, const void *plev, const void *tlay,
@@ -186,7 +189,8 @@ int geosrad_rrtmg_sw(geosrad_ctx *ctx, int rpart, int ncol, int nlay, double sco
                      void *nirr, void *nirf, void *parr, void *parf, void *uvrr, void *uvrf, void *fswband,
                      void *cotdtp, void *cotdhp, void *cotdmp, void *cotdlp,
                      void *cotntp, void *cotnhp, void *cotnmp, void *cotnlp,
-                     int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar);
+                     int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar,
+                     const void *solcycfrac);
 /* same, DEVICE pointers, asynchronous on `stream`; input assertions are reported by geosrad_check() */
 int geosrad_rrtmg_sw_dev(geosrad_ctx *ctx, void *stream, int rpart, int ncol, int nlay, double scon, double adjes,
                          const void *coszen, int isolvar,
@@ -202,13 +206,15 @@ int geosrad_rrtmg_sw_dev(geosrad_ctx *ctx, void *stream, int rpart, int ncol, in
                          void *nirr, void *nirf, void *parr, void *parf, void *uvrr, void *uvrf, void *fswband,
                          void *cotdtp, void *cotdhp, void *cotdmp, void *cotdlp,
                          void *cotntp, void *cotnhp, void *cotnmp, void *cotnlp,
-                         int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar);
+                         int do_drfband, void *drband, void *dfband, const void *bndscl, const void *indsolvar,
+                         const void *solcycfrac);
 /* Debug / test hook: taug, taur Fortran (nlay,112,ncol) and the solar source ssi (112,ncol) [sfluxzen when
  * isolvar < 0] as the reference's taumol_sw leaves them (SW/rrtmg_sw_taumol.F90:27); host pointers. */
 int geosrad_rrtmg_sw_taumol(geosrad_ctx *ctx, int ncol, int nlay, double scon, int isolvar,
                             const void *play, const void *plev, const void *tlay,
                             const void *h2ovmr, const void *o3vmr, const void *co2vmr, const void *ch4vmr, const void *o2vmr,
-                            const void *bndscl, const void *indsolvar, void *taug, void *taur, void *ssi);
+                            const void *bndscl, const void *indsolvar, const void *solcycfrac,
+                            void *taug, void *taur, void *ssi);
 /* Debug / test hook: the McICA cloud optics of the solver's own sub-columns - delta-scaled optical depth, single-scattering
  * albedo and asymmetry parameter, Fortran (nlay,112,ncol), as the reference's cldprmc_sw leaves taucmc, ssacmc, asmcmc
  * (SW/rrtmg_sw_cldprmc.F90:36-418; 0, 1, 0 in clear cells); host pointers. */

@@ -230,7 +230,7 @@ def sw_cldprmc(cldy, ciwpmc, clwpmc, rei, rel, iceflag=3, liqflag=1, prec="f32")
 
 
 def rrtmg_sw(inp, prec="f32", scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqflg=1, iaer=0, normFlx=0, do_drfband=False,
-             indsolvar=None, bndscl=None):
+             indsolvar=None, bndscl=None, solcycfrac=None):
     """Full rrtmg_sw restatement (rrtmg_sw_rad.F90:68).  `inp` from synth.make_columns (needs coszen, albedos)."""
     L = lib()
     sfx = _sfx(prec); dt = dtype_of(sfx)
@@ -249,6 +249,7 @@ def rrtmg_sw(inp, prec="f32", scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqfl
     ci = ctypes.c_int
     ind = None if indsolvar is None else _p(np.array(indsolvar, dtype=dt))
     bs = None if bndscl is None else _p(np.array(bndscl, dtype=dt))
+    scf = None if solcycfrac is None else _p(np.array([solcycfrac], dtype=dt))
     rc = getattr(L, f"oracle_rrtmg_sw_{sfx}")(
         ci(ncol), ci(nlay), R(scon), R(adjes), _p(c("coszen")), ci(isolvar), _p(c("play")), _p(plev), _p(c("tlay")),
         _p(c("h2ovmr")), _p(c("o3vmr")), _p(c("co2vmr")), _p(c("ch4vmr")), _p(c("o2vmr")), ci(iceflg), ci(liqflg),
@@ -256,9 +257,49 @@ def rrtmg_sw(inp, prec="f32", scon=1361.0, adjes=1.0, isolvar=0, iceflg=3, liqfl
         ci(iaer), _p(aer[0]), _p(aer[1]), _p(aer[2]), _p(c("asdir")), _p(c("asdif")), _p(c("aldir")), _p(c("aldif")),
         ci(int(inp["cloudLM"])), ci(int(inp["cloudMH"])), ci(normFlx), _p(out["clearCounts"]), _p(out["swuflx"]), _p(out["swdflx"]),
         _p(out["swuflxc"]), _p(out["swdflxc"]), _p(out["nirr"]), _p(out["nirf"]), _p(out["parr"]), _p(out["parf"]), _p(out["uvrr"]),
-        _p(out["uvrf"]), _p(out["fswband"]), _p(out["cot"]), ci(1 if do_drfband else 0), _p(out["drband"]), _p(out["dfband"]), bs, ind)
+        _p(out["uvrf"]), _p(out["fswband"]), _p(out["cot"]), ci(1 if do_drfband else 0), _p(out["drband"]), _p(out["dfband"]), bs, ind, scf)
     out["rc"] = rc
     return out
+
+
+def nrlssi2_adjust(solcycfr, indsolvar, prec="f32"):
+    """adjust_solcyc_amplitudes restatement (NRLSSI2.F90:236-271) -> indsolvar_scl(2); raises where the reference error-stops"""
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    R = ctypes.c_float if sfx == "f32" else ctypes.c_double
+    o = np.zeros(2, dtype=dt)
+    if getattr(lib(), f"oracle_nrlssi2_adjust_{sfx}")(R(dt(solcycfr)), _p(np.array(indsolvar, dtype=dt)), _p(o)):
+        raise ValueError("RRTMG_SW: solcycfr must be in [0,1]")
+    return o
+
+
+def nrlssi2_interp(solcycfr, prec="f32"):
+    """interpolate_indices restatement (NRLSSI2.F90:277-332) -> (Mg, SB)"""
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    R = ctypes.c_float if sfx == "f32" else ctypes.c_double
+    o = np.zeros(2, dtype=dt)
+    if getattr(lib(), f"oracle_nrlssi2_interp_{sfx}")(R(dt(solcycfr)), _p(o)):
+        raise ValueError("RRTMG_SW: solcycfr must be in [0,1]")
+    return o[0], o[1]
+
+
+def nrlssi2_means(indsolvar=None, prec="f32"):
+    """initialize_NRLSSI2's isolvar = 1 cycle means (NRLSSI2.F90:160-232) -> (<svar_f>, <svar_s>)"""
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    o = np.zeros(2, dtype=dt)
+    getattr(lib(), f"oracle_nrlssi2_means_{sfx}")(None if indsolvar is None else _p(np.array(indsolvar, dtype=dt)), _p(o))
+    return o[0], o[1]
+
+
+def sw_solar_isolvar1(scon, solcycfrac, indsolvar=None, prec="f32"):
+    """svar_f, svar_s, svar_i of the isolvar = 1 branch of the solar-variability block (rrtmg_sw_rad.F90:906-930,994-1008,1060-1079)"""
+    sfx = _sfx(prec); dt = dtype_of(sfx)
+    R = ctypes.c_float if sfx == "f32" else ctypes.c_double
+    o = np.zeros(3, dtype=dt)
+    rc = getattr(lib(), f"oracle_sw_solar_isolvar1_{sfx}")(R(dt(scon)), None if indsolvar is None else _p(np.array(indsolvar, dtype=dt)),
+                                                          _p(np.array([solcycfrac], dtype=dt)), _p(o))
+    if rc:
+        raise ValueError(f"isolvar 1: rc {rc}")
+    return o
 
 
 def irrad(ch, prec="f32", trace=True):

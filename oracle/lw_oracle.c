@@ -14,12 +14,15 @@
 #define FABS fabsf
 #define SQRT sqrtf
 #define LOG10 log10f
+#define FLOOR floorf
 #include "lw_oracle_impl.h"
 #include "sw_oracle_impl.h"
 #include "chou_oracle_impl.h"
 #include "chou_sw_oracle_impl.h"
 #include "gridcomp_oracle_impl.h"
 #undef LOG10
+#undef FLOOR
+#undef NSOLFRAC
 #undef REAL
 #undef SFX
 #undef EXP
@@ -40,6 +43,7 @@
 #define FABS fabs
 #define SQRT sqrt
 #define LOG10 log10
+#define FLOOR floor
 #include "lw_oracle_impl.h"
 #include "sw_oracle_impl.h"
 #include "chou_oracle_impl.h"

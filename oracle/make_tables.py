@@ -14,11 +14,30 @@ from geosradiation_gridcomp_amd.tableblob import read_blob, write_blob
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geosradiation_gridcomp_amd", "data")
 
 
+def add_avg_cycle(path, kind):
+    """AvgCyc11 of the Mg and SB indices (NRLSSI2.F90:60-117: `mgavgcyc`, `sbavgcyc`, 134 values each, module-private) recovered
+    through the public interpolate_indices(): at solcycfr = 0 / 1 it returns elements 1 / 134, at the node (n-2) * intrvl_len +
+    intrvl_len_hf element n.  Checked: the r8 recovery IS a 6- (Mg) / 4-decimal (SB) number - the source literal - and the r4
+    recovery is that literal rounded to fp32, for all 134 elements.  Appended to the SW blob (isolvar = 1 needs them)."""
+    dt = reflib.dtype_of(kind)
+    il = dt(1.0) / dt(132); ilh = dt(0.5) * il
+    pts = [dt(0.0)] + [dt(n - 2) * il + ilh for n in range(2, 134)] + [dt(1.0)]
+    m8 = np.array([reflib.nrlssi2_interp(p, "r8") for p in [0.0] + [(n - 2) / 132 + 0.5 / 132 for n in range(2, 134)] + [1.0]], dtype=np.float64)
+    lit_mg, lit_sb = np.round(m8[:, 0], 6), np.round(m8[:, 1], 4)
+    assert np.abs(lit_mg - m8[:, 0]).max() < 1e-15 and np.abs(lit_sb - m8[:, 1]).max() < 1e-11
+    mk = np.array([reflib.nrlssi2_interp(p, kind) for p in pts], dtype=dt)
+    assert np.array_equal(mk[:, 0], lit_mg.astype(dt)) and np.array_equal(mk[:, 1], lit_sb.astype(dt))
+    rb, arr = read_blob(path)
+    arr["mgavgcyc"] = lit_mg.astype(dt); arr["sbavgcyc"] = lit_sb.astype(dt)
+    write_blob(path, rb, arr)
+
+
 def main():
     os.makedirs(DATA, exist_ok=True)
     for kind in ("r4", "r8"):
         reflib.dump_lw_tables(os.path.join(DATA, f"rrtmg_lw_{kind}.grtb"), kind)
         reflib.dump_sw_tables(os.path.join(DATA, f"rrtmg_sw_{kind}.grtb"), kind)
+        add_avg_cycle(os.path.join(DATA, f"rrtmg_sw_{kind}.grtb"), kind)
         reflib.dump_chou_lw_tables(os.path.join(DATA, f"chou_lw_{kind}.grtb"), kind)
         reflib.dump_chou_sw_tables(os.path.join(DATA, f"chou_sw_{kind}.grtb"), kind)
     # condensate-inhomogeneity tables: beta (ih=1) and gamma (ih=2).  r4 is recovered bit-exactly through the

@@ -687,6 +687,39 @@ subroutine ref_sw_cldprmc(ncol, nlay, iceflag, liqflag, cldy, ciwpmc, clwpmc, re
    deallocate(l)
 end subroutine ref_sw_cldprmc
 
+! NRLSSI2 (SW/src/NRLSSI2.F90; no ESMF/MAPL dependency): the two host routines of the isolvar = 1 branch of the solar-variability
+! block (rrtmg_sw_rad.F90:906-930,994-1008) and the cycle means initialize_NRLSSI2 keeps for it (NRLSSI2.F90:160-232)
+subroutine ref_nrlssi2_adjust(solcycfr, indsolvar, scl) bind(C, name='ref_nrlssi2_adjust')
+   use NRLSSI2, only: adjust_solcyc_amplitudes
+   implicit none
+   real, intent(in) :: solcycfr, indsolvar(2)
+   real, intent(out) :: scl(2)
+   call adjust_solcyc_amplitudes(solcycfr, indsolvar, scl)
+end subroutine
+
+subroutine ref_nrlssi2_interp(solcycfr, Mg, SB) bind(C, name='ref_nrlssi2_interp')
+   use NRLSSI2, only: interpolate_indices
+   implicit none
+   real, intent(in) :: solcycfr
+   real, intent(out) :: Mg, SB
+   call interpolate_indices(solcycfr, Mg, SB)
+end subroutine
+
+subroutine ref_nrlssi2_means(has_ind, indsolvar, mean_f, mean_s) bind(C, name='ref_nrlssi2_means')
+   use iso_c_binding
+   use NRLSSI2, only: initialize_NRLSSI2, isolvar_1_mean_svar_f, isolvar_1_mean_svar_s
+   implicit none
+   integer(c_int), value :: has_ind
+   real, intent(in) :: indsolvar(2)
+   real, intent(out) :: mean_f, mean_s
+   if (has_ind /= 0) then
+      call initialize_NRLSSI2(1, indsolvar)
+   else
+      call initialize_NRLSSI2(1)
+   end if
+   mean_f = isolvar_1_mean_svar_f; mean_s = isolvar_1_mean_svar_s
+end subroutine
+
 ! Chou-Suarez LW coefficient tables (irrad_constants, rad_constants): data modules only -- irrad.F90 itself is not
 ! buildable here (module gettau -> MAPL_ConstantsMod).
 subroutine ref_chou_lw_dump_tables(cpath, n) bind(C, name='ref_chou_lw_dump_tables')

@@ -232,3 +232,29 @@ def sw_cldprmc(cldy, ciwpmc, clwpmc, rei, rel, iceflag=3, liqflag=1, kind="r4"):
         for k in range(4):
             out[k][c0:c1] = o[k]
     return out
+
+
+# ---- NRLSSI2 host routines of the isolvar = 1 branch (NRLSSI2.F90:160-332) -----------------------------------------
+def nrlssi2_adjust(solcycfr, indsolvar, kind="r4"):
+    """adjust_solcyc_amplitudes (NRLSSI2.F90:236-271) -> indsolvar_scl(2)"""
+    dt = dtype_of(kind)
+    f = np.array([solcycfr], dtype=dt); i = _c(indsolvar, dt); o = np.zeros(2, dtype=dt)
+    lib(kind).ref_nrlssi2_adjust(_p(f), _p(i), _p(o))
+    return o
+
+
+def nrlssi2_interp(solcycfr, kind="r4"):
+    """interpolate_indices (NRLSSI2.F90:277-332) -> (Mg, SB)"""
+    dt = dtype_of(kind)
+    f = np.array([solcycfr], dtype=dt); mg = np.zeros(1, dtype=dt); sb = np.zeros(1, dtype=dt)
+    lib(kind).ref_nrlssi2_interp(_p(f), _p(mg), _p(sb))
+    return mg[0], sb[0]
+
+
+def nrlssi2_means(indsolvar=None, kind="r4"):
+    """initialize_NRLSSI2(1 [, indsolvar]) (NRLSSI2.F90:160-232) -> (isolvar_1_mean_svar_f, isolvar_1_mean_svar_s)"""
+    dt = dtype_of(kind)
+    i = np.ones(2, dtype=dt) if indsolvar is None else _c(indsolvar, dt)
+    mf = np.zeros(1, dtype=dt); ms = np.zeros(1, dtype=dt)
+    lib(kind).ref_nrlssi2_means(ctypes.c_int(0 if indsolvar is None else 1), _p(i), _p(mf), _p(ms))
+    return mf[0], ms[0]

@@ -7,6 +7,8 @@
  * PINNING STATUS
  *   setcoef_sw, taumol_sw (14 bands, solar source), cldprmc_sw : PINNED -- bit-identical to the reference's
  *       own Fortran (oracle/_ref builds those files; tests/test_oracle_sw.py) and to tests/golden/sw_*.npz.
+ *   NRLSSI2 adjust_solcyc_amplitudes, interpolate_indices, the isolvar = 1 cycle means : PINNED -- bit-identical to the
+ *       reference's NRLSSI2.F90 (no ESMF/MAPL dependency; oracle/_ref builds it) over solcycfrac x indsolvar grids.
  *   reftra_sw, vrtqdr_sw, spcvmc_sw band integration, rrtmg_sw driver (albedo->band map, solar variability,
  *       normFlx): "parity unpinned" -- rrtmg_sw_spcvmc.F90 and rrtmg_sw_rad.F90 `use ESMF`/`use MAPL`, which
  *       this image lacks, so the reference cannot be built for them here and the reference has no golden
@@ -18,7 +20,7 @@ typedef struct {
     const REAL *preflog, *tref, *oneminus, *grav, *avogad, *rrsw_scon;
     const REAL *extliq1, *ssaliq1, *asyliq1, *extice2, *ssaice2, *asyice2, *extice3, *ssaice3, *asyice3, *fdlice3,
         *extice4, *ssaice4, *asyice4, *abari, *bbari, *cbari, *dbari, *ebari, *fbari;
-    const REAL *Iint, *Fint, *Sint, *Mg_avg, *Mg_0, *SB_avg, *SB_0;
+    const REAL *Iint, *Fint, *Sint, *Mg_avg, *Mg_0, *SB_avg, *SB_0, *mgavgcyc, *sbavgcyc;
     const int *ngb, *icxa;
     /* per band, index 16..29 */
     const REAL *absa[30], *absb[30], *selfref[30], *forref[30], *sfluxref[30], *irradnce[30], *facbrght[30], *snsptdrk[30],
@@ -38,7 +40,7 @@ int SFX(oracle_sw_set_table)(const char *name, const void *p)
     SET("extice4", extice4) SET("ssaice4", ssaice4) SET("asyice4", asyice4) SET("abari", abari) SET("bbari", bbari)
     SET("cbari", cbari) SET("dbari", dbari) SET("ebari", ebari) SET("fbari", fbari)
     SET("Iint", Iint) SET("Fint", Fint) SET("Sint", Sint) SET("Mg_avg", Mg_avg) SET("Mg_0", Mg_0) SET("SB_avg", SB_avg)
-    SET("SB_0", SB_0) SET("ngb", ngb) SET("icxa", icxa)
+    SET("SB_0", SB_0) SET("mgavgcyc", mgavgcyc) SET("sbavgcyc", sbavgcyc) SET("ngb", ngb) SET("icxa", icxa)
     SET("b20_absch4", absch4) SET("b24_abso3a", abso3a24) SET("b24_abso3b", abso3b24) SET("b24_rayla", rayla24)
     SET("b24_raylb", raylb24) SET("b25_abso3a", abso3a25) SET("b25_abso3b", abso3b25) SET("b29_absh2o", absh2o)
     SET("b29_absco2", absco2)
@@ -597,10 +599,97 @@ int SFX(oracle_sw_cldprmc)(int ncol, int nlay, int iceflag, int liqflag, const i
     return 0;
 }
 
+/* ---- NRLSSI2 host routines of the isolvar = 1 branch (SW/NRLSSI2.F90) ------------------------------------------
+ * nsolfrac = 134 (:57); intrvl_len = 1 / (nsolfrac - 2), intrvl_len_hf = half of it (:120-121). */
+#define NSOLFRAC 134
+/* adjust_solcyc_amplitudes (:236-271): amplitude scaling 1 at the solar minimum, indsolvar at the maximum, linear in between.
+ * Returns 1 where the reference error-stops (solcycfr outside [0, 1]). */
+static int SFX(nrlssi2_adjust)(REAL solcycfr, const REAL *indsolvar, REAL *scl)
+{
+    const REAL solcycfrac_min = (REAL)0.0189, solcycfrac_max = (REAL)0.3750;
+    const REAL fracdiff_min2max = solcycfrac_max - solcycfrac_min, fracdiff_max2min = (REAL)1. - fracdiff_min2max;
+    REAL wgt;
+    if (solcycfr >= 0 && solcycfr < solcycfrac_min) {
+        wgt = (solcycfr + (REAL)1. - solcycfrac_max) / fracdiff_max2min;
+        scl[0] = indsolvar[0] + wgt * ((REAL)1. - indsolvar[0]);
+        scl[1] = indsolvar[1] + wgt * ((REAL)1. - indsolvar[1]);
+    } else if (solcycfr >= solcycfrac_min && solcycfr <= solcycfrac_max) {
+        wgt = (solcycfr - solcycfrac_min) / fracdiff_min2max;
+        scl[0] = (REAL)1. + wgt * (indsolvar[0] - (REAL)1.);
+        scl[1] = (REAL)1. + wgt * (indsolvar[1] - (REAL)1.);
+    } else if (solcycfr > solcycfrac_max && solcycfr <= 1) {
+        wgt = (solcycfr - solcycfrac_max) / fracdiff_max2min;
+        scl[0] = indsolvar[0] + wgt * ((REAL)1. - indsolvar[0]);
+        scl[1] = indsolvar[1] + wgt * ((REAL)1. - indsolvar[1]);
+    } else return 1;
+    return 0;
+}
+
+/* interpolate_indices (:277-332): Mg and SB of the mean cycle AvgCyc11 at solcycfr in [0, 1] */
+static int SFX(nrlssi2_interp)(REAL solcycfr, REAL *Mg, REAL *SB)
+{
+    const SFX(sw_tables_t) *t = &SFX(S);
+    const REAL intrvl_len = (REAL)1.0 / (REAL)(NSOLFRAC - 2), intrvl_len_hf = (REAL)0.5 * intrvl_len;
+    const REAL *mg = t->mgavgcyc - 1, *sb = t->sbavgcyc - 1;      /* 1-based like the reference */
+    if (solcycfr > 0 && solcycfr < 1) {
+        int sfid; REAL fraclo, frachi;
+        if (solcycfr <= intrvl_len_hf) { sfid = 1; fraclo = 0; frachi = intrvl_len_hf; }
+        else if (solcycfr > intrvl_len_hf && solcycfr < (REAL)1. - intrvl_len_hf) {
+            sfid = (int)FLOOR((solcycfr - intrvl_len_hf) * (REAL)(NSOLFRAC - 2)) + 2;
+            fraclo = (REAL)(sfid - 2) * intrvl_len + intrvl_len_hf;
+            frachi = fraclo + intrvl_len;
+        } else { sfid = (NSOLFRAC - 2) + 1; fraclo = (REAL)1. - intrvl_len_hf; frachi = 1; }
+        const REAL intfrac = (solcycfr - fraclo) / (frachi - fraclo);
+        *Mg = mg[sfid] + intfrac * (mg[sfid + 1] - mg[sfid]);
+        *SB = sb[sfid] + intfrac * (sb[sfid + 1] - sb[sfid]);
+    } else if (solcycfr == 0) { *Mg = mg[1]; *SB = sb[1]; }
+    else if (solcycfr == 1) { *Mg = mg[NSOLFRAC]; *SB = sb[NSOLFRAC]; }
+    else return 1;
+    return 0;
+}
+
+/* initialize_NRLSSI2, isolvar == 1 part (:160-232): <svar_f>, <svar_s> over the cycle with the amplitude scaling applied.
+ * indsolvar == NULL: absent optional argument (= 1, 1). */
+static void SFX(nrlssi2_means)(const REAL *indsolvar_opt, REAL *mean_f, REAL *mean_s)
+{
+    const SFX(sw_tables_t) *t = &SFX(S);
+    const REAL intrvl_len = (REAL)1.0 / (REAL)(NSOLFRAC - 2), intrvl_len_hf = (REAL)0.5 * intrvl_len;
+    const REAL *mg = t->mgavgcyc - 1, *sb = t->sbavgcyc - 1;
+    REAL indsolvar[2] = {1, 1};
+    if (indsolvar_opt) { indsolvar[0] = indsolvar_opt[0]; indsolvar[1] = indsolvar_opt[1]; }
+    *mean_f = 1; *mean_s = 1;
+    const int scl1 = indsolvar[0] != 1, scl2 = indsolvar[1] != 1;
+    if (scl1 || scl2) {
+        REAL iscl1_mean = 0, iscl2_mean = 0, iscl1_Mg_mean = 0, iscl2_SB_mean = 0, scl[2];
+        if (scl1) iscl1_mean = ((REAL)1. + indsolvar[0]) / (REAL)2.;
+        if (scl2) iscl2_mean = ((REAL)1. + indsolvar[1]) / (REAL)2.;
+        REAL solcycfr = intrvl_len_hf;
+        for (int n = 2; n <= NSOLFRAC - 1; n++) {
+            SFX(nrlssi2_adjust)(solcycfr, indsolvar, scl);
+            if (scl1) iscl1_Mg_mean = iscl1_Mg_mean + scl[0] * mg[n];
+            if (scl2) iscl2_SB_mean = iscl2_SB_mean + scl[1] * sb[n];
+            solcycfr = solcycfr + intrvl_len;
+        }
+        if (scl1) iscl1_Mg_mean = iscl1_Mg_mean / (REAL)(NSOLFRAC - 2);
+        if (scl2) iscl2_SB_mean = iscl2_SB_mean / (REAL)(NSOLFRAC - 2);
+        if (scl1) *mean_f = (iscl1_Mg_mean - iscl1_mean * *t->Mg_0) / (*t->Mg_avg - *t->Mg_0);
+        if (scl2) *mean_s = (iscl2_SB_mean - iscl2_mean * *t->SB_0) / (*t->SB_avg - *t->SB_0);
+    }
+}
+
+int SFX(oracle_nrlssi2_adjust)(REAL solcycfr, const REAL *indsolvar, REAL *scl) { return SFX(nrlssi2_adjust)(solcycfr, indsolvar, scl); }
+int SFX(oracle_nrlssi2_interp)(REAL solcycfr, REAL *MgSB) { return SFX(nrlssi2_interp)(solcycfr, MgSB, MgSB + 1); }
+void SFX(oracle_nrlssi2_means)(const REAL *indsolvar, REAL *means) { SFX(nrlssi2_means)(indsolvar, means, means + 1); }
+
+/* the scalars of the solar-variability block (SW/rrtmg_sw_rad.F90:893-1127) alone: svar[3] = svar_f, svar_s, svar_i.  isolvar = 1 only. */
+int SFX(oracle_sw_solar_isolvar1)(REAL scon, const REAL *indsolvar, const REAL *solcycfrac, REAL *svar);
+
 /* ---- public: full rrtmg_sw (SW/rrtmg_sw_rad.F90:68-1801 + spcvmc_sw :34-1112), API layouts --------------------
- * isolvar in {-1, 0, 2, 3} (GEOS itself rejects 1: GEOS_SolarGridComp.F90:6286-6292).  indsolvar/bndscl may be NULL.
+ * isolvar in {-1, 0, 1, 2, 3} (1 needs solcycfrac; GEOS itself never passes 1: GEOS_SolarGridComp.F90:6286-6292).
+ * indsolvar / bndscl / solcycfrac may be NULL (absent optional arguments).
  * cot[8] = cotdtp,cotdhp,cotdmp,cotdlp,cotntp,cotnhp,cotnmp,cotnlp (ncol each); drband/dfband (ncol,14) or NULL.
- * Returns 0, 100+k negative input #k, 10/11 invalid cloud flags, 20 invalid isolvar / negative scon, 5 bad super-layers. */
+ * Returns 0, 100+k negative input #k, 10/11 invalid cloud flags, 20 invalid isolvar / negative scon, 21 isolvar 1 without
+ * solcycfrac, 22 solcycfr outside [0, 1], 5 bad super-layers. */
 int SFX(oracle_rrtmg_sw)(int ncol, int nlay, REAL scon, REAL adjes, const REAL *coszen, int isolvar, const REAL *play,
                          const REAL *plev, const REAL *tlay, const REAL *h2ovmr, const REAL *o3vmr, const REAL *co2vmr,
                          const REAL *ch4vmr, const REAL *o2vmr, int iceflgsw, int liqflgsw, const REAL *cld, const REAL *ciwp,
@@ -609,7 +698,7 @@ int SFX(oracle_rrtmg_sw)(int ncol, int nlay, REAL scon, REAL adjes, const REAL *
                          const REAL *asdif, const REAL *aldir, const REAL *aldif, int cloudLM, int cloudMH, int normFlx,
                          int *clearCounts, REAL *swuflx, REAL *swdflx, REAL *swuflxc, REAL *swdflxc, REAL *nirr, REAL *nirf,
                          REAL *parr, REAL *parf, REAL *uvrr, REAL *uvrf, REAL *fswband, REAL *cot, int do_drfband,
-                         REAL *drband, REAL *dfband, const REAL *bndscl, const REAL *indsolvar)
+                         REAL *drband, REAL *dfband, const REAL *bndscl, const REAL *indsolvar, const REAL *solcycfrac)
 {
     const SFX(sw_tables_t) *t = &SFX(S);
     const size_t cl = (size_t)ncol * nlay;
@@ -629,7 +718,15 @@ int SFX(oracle_rrtmg_sw)(int ncol, int nlay, REAL scon, REAL adjes, const REAL *
     REAL ndx[2] = {*t->Mg_avg, *t->SB_avg};
     if (isolvar == 2 && indsolvar) { ndx[0] = indsolvar[0]; ndx[1] = indsolvar[1]; }
     const REAL Iint = *t->Iint, Fint = *t->Fint, Sint = *t->Sint;
-    if (isolvar != -1 && isolvar != 0 && isolvar != 2 && isolvar != 3) return 20;
+    if (isolvar != -1 && isolvar != 0 && isolvar != 1 && isolvar != 2 && isolvar != 3) return 20;
+    /* isolvar == 1 (:906-930): position in AvgCyc11 from solcycfrac, amplitude scaling from indsolvar; (:994-1008, :1060-1079) */
+    if (isolvar == 1) {
+        REAL sv1[3];
+        if (!solcycfrac) return 21;
+        int e = SFX(oracle_sw_solar_isolvar1)(scon, indsolvar, solcycfrac, sv1);
+        if (e) return e;
+        svar[0] = sv1[0]; svar[1] = sv1[1]; svar[2] = sv1[2];
+    }
     if (scon == 0) {
         if (isolvar == -1) { if (bndscl) for (int b = 16; b <= 29; b++) solvar[b] = bndscl[b - 16]; }
         else if (isolvar == 2) { svar[0] = (ndx[0] - *t->Mg_0) / (*t->Mg_avg - *t->Mg_0); svar[1] = (ndx[1] - *t->SB_0) / (*t->SB_avg - *t->SB_0); svar[2] = 1; }
@@ -821,3 +918,23 @@ int SFX(oracle_rrtmg_sw)(int ncol, int nlay, REAL scon, REAL adjes, const REAL *
 #undef LIN1
 #undef LIN2
 #undef NGSW
+
+
+int SFX(oracle_sw_solar_isolvar1)(REAL scon, const REAL *indsolvar, const REAL *solcycfrac, REAL *svar)
+{
+    const SFX(sw_tables_t) *t = &SFX(S);
+    const REAL Iint = *t->Iint, Fint = *t->Fint, Sint = *t->Sint;
+    REAL scl[2] = {1, 1}, Mg_now, SB_now, mean_f, mean_s;
+    if (!solcycfrac) return 21;
+    const REAL solcycfr = *solcycfrac;
+    if (scon < 0) return 20;
+    if (indsolvar && (indsolvar[0] != 1 || indsolvar[1] != 1))
+        if (SFX(nrlssi2_adjust)(solcycfr, indsolvar, scl)) return 22;
+    SFX(nrlssi2_means)(indsolvar, &mean_f, &mean_s);                  /* call initialize_NRLSSI2 (isolvar, indsolvar) (:946) */
+    if (SFX(nrlssi2_interp)(solcycfr, &Mg_now, &SB_now)) return 22;
+    svar[0] = scl[0] * (Mg_now - *t->Mg_0) / (*t->Mg_avg - *t->Mg_0);
+    svar[1] = scl[1] * (SB_now - *t->SB_0) / (*t->SB_avg - *t->SB_0);
+    if (scon == 0) svar[2] = 1;
+    else svar[2] = (scon - (mean_f * Fint + mean_s * Sint)) / Iint;
+    return 0;
+}

@@ -89,6 +89,70 @@ def main_sw():
         print(name, os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
+# isolvar = 1 (rrtmg_sw_rad.F90:906-930,994-1008,1060-1079): the NRLSSI2 host routines it calls (NRLSSI2.F90:160-332, no ESMF/MAPL
+# dependency) run from the reference over a grid of cycle positions x amplitude scalings, and the spectral solar source taumol_sw
+# returns for the resulting svar_f / svar_s / svar_i on the columns of sw_stages_72
+NRL_INDSOLVAR = [(1.0, 1.0), (1.2, 0.8), (0.5, 1.0), (1.0, 1.7), (2.0, 0.3), (0.9, 1.1), (1.0001, 0.9999), (3.0, 3.0)]
+NRL_CASES = [(0.30, (1.15, 0.9), 1361.0), (0.0189, (1.2, 0.8), 1361.0), (0.85, None, 1360.0), (0.5, (1.0, 1.0), 0.0), (0.0, (0.7, 1.3), 1365.5),
+             (1.0, (1.0, 1.7), 1361.0), (0.375, (2.0, 0.3), 0.0)]
+
+
+def nrl_fracs(dt):
+    il = dt(1.0) / dt(132); ilh = dt(0.5) * il
+    rng = np.random.default_rng(1360)
+    f = [dt(0), dt(1), ilh, dt(1) - ilh, dt(0.0189), dt(0.3750), np.nextafter(dt(0.0189), dt(0)), np.nextafter(dt(0.3750), dt(1)),
+         np.nextafter(dt(0), dt(1)), np.nextafter(dt(1), dt(0))]
+    f += [dt(n - 2) * il + ilh for n in (2, 3, 17, 66, 67, 131, 132, 133)]
+    f += [np.nextafter(dt(n - 2) * il + ilh, dt(d)) for n in (2, 40, 99, 133) for d in (0, 1)]
+    f += list(rng.uniform(0, 1, 200 - len(f)).astype(dt))
+    return np.array(f, dtype=dt)
+
+
+def isolvar1_svar(kind, scon, solcycfrac, indsolvar, blob, get=None):
+    """svar_f, svar_s, svar_i as the driver's isolvar = 1 branch forms them (rrtmg_sw_rad.F90:906-930,994-1008,1060-1079) in the
+    kind's precision from the NRLSSI2 routines' results (`get` = reflib by default)."""
+    get = get or reflib
+    R = reflib.dtype_of(kind)
+    fr = R(solcycfrac)
+    scl = np.ones(2, dtype=R)
+    if indsolvar is not None and (R(indsolvar[0]) != 1 or R(indsolvar[1]) != 1):
+        scl = get.nrlssi2_adjust(fr, indsolvar, kind)
+    mf, ms = get.nrlssi2_means(indsolvar, kind)
+    mg, sb = get.nrlssi2_interp(fr, kind)
+    Mg0, Mga, SB0, SBa = (R(blob[k]) for k in ("Mg_0", "Mg_avg", "SB_0", "SB_avg"))
+    Fint, Sint, Iint = R(blob["Fint"]), R(blob["Sint"]), R(blob["Iint"])
+    f = R(R(scl[0] * R(mg - Mg0)) / R(Mga - Mg0))
+    s_ = R(R(scl[1] * R(sb - SB0)) / R(SBa - SB0))
+    i_ = R(1) if scon == 0 else R(R(R(scon) - R(R(mf * Fint) + R(ms * Sint))) / Iint)
+    return np.array([f, s_, i_], dtype=R)
+
+
+def main_nrlssi2():
+    from geosradiation_gridcomp_amd.tableblob import read_blob
+    from geosradiation_gridcomp_amd import _lib
+    kw, _ = SW_CASES["sw_stages_72"]
+    inp = synth.make_columns(**kw)
+    out = {"indsolvar": np.array(NRL_INDSOLVAR), "kw_json": np.array(repr(kw)),
+           "case_solcycfrac": np.array([c[0] for c in NRL_CASES]), "case_scon": np.array([c[2] for c in NRL_CASES]),
+           "case_indsolvar": np.array([(np.nan, np.nan) if c[1] is None else c[1] for c in NRL_CASES])}
+    for kind in ("r4", "r8"):
+        dt = reflib.dtype_of(kind)
+        _, blob = read_blob(os.path.join(_lib.DATA, f"rrtmg_sw_{kind}.grtb"))
+        fr = nrl_fracs(dt)
+        out[f"{kind}_solcycfr"] = fr
+        out[f"{kind}_MgSB"] = np.array([reflib.nrlssi2_interp(f, kind) for f in fr], dtype=dt)
+        out[f"{kind}_scl"] = np.array([[reflib.nrlssi2_adjust(f, ind, kind) for f in fr] for ind in NRL_INDSOLVAR], dtype=dt)
+        out[f"{kind}_means"] = np.array([reflib.nrlssi2_means(ind, kind) for ind in NRL_INDSOLVAR], dtype=dt)
+        out[f"{kind}_means_absent"] = np.array(reflib.nrlssi2_means(None, kind), dtype=dt)
+        sv = np.array([isolvar1_svar(kind, scon, f, ind, blob) for f, ind, scon in NRL_CASES], dtype=dt)
+        out[f"{kind}_case_svar"] = sv
+        # the spectral solar source of taumol_sw (isolvar 1 shares the isolvar <= 2 formula, rrtmg_sw_taumol.F90:325-347) for case 0
+        t = reflib.sw_setcoef_taumol(inp, isolvar=1, svar=list(sv[0]), svar_bnd=np.ones((3, 29), dtype=dt), kind=kind)
+        out[f"{kind}_ssi_case0"] = t["ssi"]
+    np.savez_compressed(os.path.join(HERE, "nrlssi2_isolvar1.npz"), **out)
+    print("nrlssi2_isolvar1", os.path.getsize(os.path.join(HERE, "nrlssi2_isolvar1.npz")))
+
+
 # LW cldprmc with the ice parameterisations GEOS does not default to (rrtmg_lw_cldprmc.F90:138-226,270-316): one batch of cloudy
 # columns, the fluxes of the reference for each iceflag (the generator keeps rei inside every parameterisation's valid range)
 ICE_KW = dict(ncol=16, nlay=72, aerosol=True, cloudy_frac=1.0, start=4400)
@@ -144,8 +208,12 @@ if __name__ == "__main__":
     if "ice" in sys.argv[1:]:
         main_iceflags()
         sys.exit(0)
+    if "nrlssi2" in sys.argv[1:]:
+        main_nrlssi2()
+        sys.exit(0)
     if "sw" not in sys.argv[1:]:
         main()
         main_iceflags()
     if "lw" not in sys.argv[1:]:
         main_sw()
+        main_nrlssi2()

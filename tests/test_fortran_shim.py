@@ -55,14 +55,14 @@ def test_fortran_sw_caller_matches_oracle(tmp_path, kind):
     inp = synth.make_columns(ncol, nlay, start=606, aerosol=True, cloudy_frac=0.6)
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
 
-    def run(isolvar, scon):
+    def run(isolvar, scon, solcycfrac=None):
         with open(fin, "wb") as f:
             np.array([ncol, nlay, ih, int(inp["dyofyr"]), int(inp["cloudLM"]), int(inp["cloudMH"]), 10, 1, isolvar], dtype=np.int32).tofile(f)
             np.array([scon], dtype=np.float32).tofile(f)
             for k in SW_ORDER:
                 np.ascontiguousarray(inp[k], dtype=np.float32).tofile(f)
         env = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
-        subprocess.check_call([exe, str(fin), str(fout)], env=env)
+        subprocess.check_call([exe, str(fin), str(fout)] + ([] if solcycfrac is None else ["0", repr(solcycfrac)]), env=env)
         raw = np.fromfile(fout, dtype=np.uint8)
         rc = int(raw[:4].view(np.int32)[0])
         return rc, raw[4:]
@@ -91,9 +91,21 @@ def test_fortran_sw_caller_matches_oracle(tmp_path, kind):
     for k, v in got.items():
         assert np.abs(v - o[k].astype(np.float64))[..., same].max() <= tol, k
     assert np.abs(cot0 - o["cot"][0])[same].max() <= (1e-9 if kind == "r8" else 1e-4) * max(1.0, o["cot"][0].max())
-    # RC convention: the reference's _FAIL paths return a non-zero RC instead of stopping (GEOS rejects isolvar 1 itself)
+    # RC convention: the reference's _FAIL paths return a non-zero RC instead of stopping: isolvar 1 without SOLCYCFRAC is one
+    # (rrtmg_sw_rad.F90:909-911)
     rc, _ = run(1, 1361.0)
     assert rc != 0
+    # isolvar = 1 with the optional INDSOLVAR / SOLCYCFRAC arguments by keyword
+    rc, raw = run(1, 1361.0, solcycfrac=0.3)
+    assert rc == 0
+    off = 0
+    got1 = {k: take(nl, (nlay + 1, ncol)) for k in ("swuflx", "swdflx")}
+    clib.set_inhomogeneity(ih, kind)
+    o1 = clib.rrtmg_sw(inp, prec=kind, iaer=10, normFlx=1, do_drfband=True, isolvar=1, solcycfrac=0.3, indsolvar=(1.15, 0.9))
+    clib.set_inhomogeneity(0, kind)
+    assert o1["rc"] == 0
+    for k, v in got1.items():
+        assert np.abs(v - o1[k].astype(np.float64))[..., same].max() <= tol, k
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
