@@ -88,11 +88,13 @@ def control_path_only(a, rank, world):
     time.sleep(0.01 * (rank + 1))                      # the "steps": the slowest rank sets the time
     if world > 1:
         dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, torch.device("cpu"))
+    mine = time.perf_counter() - t0
+    per_rank_ms = all_over_ranks(mine * 1e3, world)
+    elapsed = max_over_ranks(mine, world, torch.device("cpu"))
     starts = [shard_start(r, a.ncol) for r in range(world)]
     if rank == 0:
         print(json.dumps({"metric": "control path only (no GPU work)", "value": None, "unit": "columns/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "scaling": "weak",
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "scaling": "weak", "per_rank_ms": per_rank_ms,
                           "config": {"columns_per_gpu": a.ncol, "shard_starts": starts}}))
     if world > 1:
         dist.destroy_process_group()
@@ -107,6 +109,18 @@ def max_over_ranks(seconds, world, device):
     t = torch.tensor([seconds], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_over_ranks(value, world):
+    """every rank's figure on every rank (a straggler GPU shows in the N > 1 line's per_rank_ms)"""
+    if world <= 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64)
+    got = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(got, t)
+    return [float(g.item()) for g in got]
 
 
 def _cpu_worker(args):
@@ -390,10 +404,10 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
                 step()
             torch.cuda.synchronize()
             prof1, nst = ctx.profile_read(), 2
-        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_sw_bands") and v[1] > 0}
+        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_lw_cols") + SW_BAND_KERNELS and v[1] > 0}
         kname = max(cand, key=lambda k: cand[k][0])
         ms, n = prof1[kname]
-        abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(lm, a.real, aerosol)
+        abytes = (algorithmic_bytes_lw if kname.startswith("k_lw") else algorithmic_bytes_sw)(lm, a.real, aerosol)
         per_launch_s = (ms / max(n, 1)) * 1e-3
         achieved = abytes * ncol / (n / nst) / per_launch_s / 1e9
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
@@ -415,12 +429,13 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
 def committed_counters(ckey, kname):
     """PMC figures of the dominant kernel for the exact configuration they were collected on (separate rocprofv3 --pmc passes, FETCH_SIZE
     x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; profiles/tools/save_final.py builds the file from the counter dumps of the round's
-    final build).  bench.py cannot collect counters itself: they need the profiler around the process."""
+    final build).  The fallback of live_counters(): no profiler on the box, a failed pass, several ranks, or bench.py itself being profiled."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r03_counters.json", "r02_traffic.json"):
+    for name in ("r04_counters.json", "r03_counters.json", "r02_traffic.json"):
         try:
             with open(os.path.join(here, name)) as fh:
-                t = json.load(fh)[ckey].get(kname)
+                e = json.load(fh)[ckey]
+            t = e.get(kname) or (e.get("k_sw_bands") if kname == "k_sw_reform" else None)     # rounds 2-3 filed the SW band sweeps under their first name
             if t:
                 return t, "profiles/" + name
         except (OSError, KeyError, ValueError):
@@ -434,11 +449,11 @@ def under_profiler():
     return any(k.startswith(("ROCPROF", "ROCTRACER", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
 
 
-PMC_GROUPS = {"k_sw_bands": ("k_sw_reform", "k_sw_bands"), "k_lw_bands": ("k_lw_bands",), "k_mcica": ("k_mcica",), "k_chou_bands": ("k_chou_bands",),
-              "k_sorad_pass": ("k_sorad_pass",)}
+PMC_GROUPS = {"k_sw_reform": ("k_sw_reform",), "k_sw_bands": ("k_sw_bands",), "k_lw_bands": ("k_lw_bands",), "k_mcica": ("k_mcica",),
+              "k_mcica_sa": ("k_mcica_sa",), "k_chou_bands": ("k_chou_bands",), "k_sorad_pass": ("k_sorad_pass",)}
 
 
-def live_counters(a, argv):
+def live_counters(a, argv, cache=None, configs=False):
     """The dominant kernels' PMC figures of THIS build on THIS box, collected the way MI355X_MICROARCH.md prescribes: rocprofv3 --pmc around a
     short one-stream run of the same workload, one counter group per run (FETCH_SIZE | WRITE_SIZE | the issue counters), the program directly
     behind `--`.  Runs as child processes BEFORE this process touches the GPU.  Returns {kernel group: {...}} per step, or None (no profiler,
@@ -450,9 +465,13 @@ def live_counters(a, argv):
     here = os.path.dirname(os.path.abspath(__file__))
     steps, warm = 2, 1
     keep = [x for x in argv if x in ("--no-aerosol",)]
-    child = [sys.executable, os.path.join(here, "bench.py"), "--no-pmc", "--no-cpu", "--no-parity", "--no-f64", "--no-overlap", "--steps", str(steps),
-             "--warmup", str(warm), "--scheme", a.scheme, "--ncol", str(a.ncol), "--nlay", str(a.nlay), "--cloudy", str(a.cloudy),
-             "--real", str(a.real), "--lit", str(a.lit)] + keep
+    child = [sys.executable, os.path.join(here, "bench.py"), "--no-pmc", "--no-cpu", "--no-parity", "--no-f64", "--no-configs", "--no-overlap",
+             "--steps", str(steps), "--warmup", str(warm), "--scheme", a.scheme, "--ncol", str(a.ncol), "--nlay", str(a.nlay), "--cloudy", str(a.cloudy),
+             "--real", str(a.real), "--lit", str(a.lit), "--coherent", str(a.coherent)] + keep
+    if configs:             # the five legs of BASELINE configs[1] / [2], 3 steps each (configs_gpu)
+        child = [sys.executable, os.path.join(here, "bench.py"), "--configs-only", "--steps", str(steps), "--warmup", str(warm)]
+    if cache:
+        child += ["--inputs-cache", cache]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -506,7 +525,7 @@ def live_counters(a, argv):
 
 def roofline_note(kname, two_streams):
     """what a `launch` of the dominant kernel is and why its fraction of the HBM peak on the compulsory bytes is what it is"""
-    if kname in ("k_lw_bands", "k_sw_bands"):
+    if kname in ("k_lw_bands", "k_lw_cols") + SW_BAND_KERNELS:
         note = ("a `launch` here is the kernel's cloud-free and cloudy instantiation launched back to back over the batch (one HIP-event "
                 "span; in the rocprofv3 kernel stats: the sum of the two instantiations' average durations); the fused k-distribution + "
                 "vertical-sweep kernel parks per-cell state between its two sweeps, so its HBM traffic is a multiple of the compulsory "
@@ -524,6 +543,7 @@ def roofline_note(kname, two_streams):
 
 
 PARITY_COLS = 256
+SW_BAND_KERNELS = ("k_sw_reform", "k_sw_bands")        # the default RRTMG_SW band sweeps | GEOSRAD_SW_PATH=bands (first mapping)
 PARITY_LW = ("uflx", "dflx", "uflxc", "dflxc")
 PARITY_SW = ("swuflx", "swdflx", "swuflxc", "swdflxc")
 
@@ -623,6 +643,11 @@ def lwsw_parity(inp_s, got4, got8, masks4, aerosol, do_lw, do_sw, cloudy):
             res["mcica_mask_flip_rate"] = flips / max(cells, 1)
             res["mcica_cells_with_a_decision"] = cells
         clib.set_inhomogeneity(0, prec)
+        # the bounds the GPU tests assert (tests/test_gpu_fullsize.py::test_c360_share_lw_sw, tests/test_gpu_sw.py): fp64 = BASELINE.json's
+        # 1e-6 W m-2; fp32 LW 4e-3 W m-2 on cloudy columns with aerosols, fp32 SW 5e-3 of the column's TOA flux for every column
+        tol = {"lw_max_abs_Wm2": 4e-3 if rk == 4 else 1e-6, ("sw_max_rel_toa" if rk == 4 else "sw_max_abs_Wm2"): 5e-3 if rk == 4 else 1e-6}
+        res["tolerance"] = tol
+        res["within_tolerance"] = all(res[k] <= v for k, v in tol.items() if k in res)
         out["f32" if rk == 4 else "f64"] = res
     return out
 
@@ -638,8 +663,8 @@ def bench_ranks_per_gpu(a):
     work of many ranks per node; each is its own process with its own context).  For every K the batch is cut into K shards and K
     CHILD processes - started before anything in this process touches the GPU - each run the Fortran callers of the drop-in
     (fortran/lw_driver.F90, sw_driver.F90: the reference's module names and argument lists, host arrays in and out) on one shard,
-    concurrently; a child picks its device from its node-local rank (OMPI_COMM_WORLD_LOCAL_RANK is set to its index: on this box every
-    rank maps to the one GPU).  Reported: the caller-side time of one rrtmg_lw / rrtmg_sw call of the slowest rank, the aggregate rate."""
+    concurrently, all on ONE device (GEOSRAD_DEVICE, default 0, in the children's environment - whatever the node holds; the node-local
+    rank -> device choice of an MPI job is tests/test_host.py::test_device_choice_follows_the_local_mpi_rank's).  Reported: the caller-side time of one rrtmg_lw / rrtmg_sw call of the slowest rank, the aggregate rate."""
     import re
     import subprocess
     import tempfile
@@ -655,7 +680,7 @@ def bench_ranks_per_gpu(a):
             inp[k] = np.zeros_like(inp[k])
     ih = 1 if a.cloudy > 0 else 0
     env0 = dict(os.environ, GEOSRAD_DATA=os.path.join(ROOT, "geosradiation_gridcomp_amd", "data"))
-    env0.pop("GEOSRAD_DEVICE", None)
+    env0["GEOSRAD_DEVICE"] = os.environ.get("GEOSRAD_DEVICE", "0")        # "K processes sharing ONE GPU": every child on the same device
     reps = max(3, a.steps)
     res = {}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
@@ -807,6 +832,329 @@ def bench_mcica(a, rank, world, dev, local_rank, cpu):
         "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0}, "cpu_baseline": cpu}))
 
 
+# ======================================================================================================================================
+# BASELINE.json configs[1] and configs[2] in the default line ("configs"): 100 000 columns x 72 layers each, one launch stream, fp32
+#   cfg1_lw_clear_100k : RRTMG_LW 140 g-points, clear-sky, no aerosol array                            (configs[1])
+#   cfg2_sw_noaer_100k : RRTMG_SW 112 g-points, McICA clouds on 60 % of the columns (ih = 1), no aerosol (configs[2])
+#   cfg2_sorad_100k    : Chou-Suarez sorad on the same columns (8 bands, aerosols)                     (configs[2])
+#   cfg2_irrad_100k    : Chou-Suarez irrad on the same columns (10 bands, trace gases, aerosols)       (configs[0]'s scheme at configs[2]'s size)
+#   cfg2_mcica_200     : the McICA generator stand-alone, 200 sub-columns                              (configs[2])
+# Each entry: value / ms_per_step from CFG_WARMUP + CFG_STEPS steps timed on the host around a device synchronisation; roofline of the leg's
+# dominant kernel (HIP-event launch duration from the same steps, algorithmic bytes of SURVEY 8(d), PMC traffic from a rocprofv3 child run of
+# `bench.py --configs-only`), a cpu_baseline from one pool over the host cores, in-run parity of CFG_PARITY columns against the oracle.
+# ======================================================================================================================================
+CFG_NCOL, CFG_NLAY, CFG_NSUB = 100_000, 72, 200
+CFG_WARMUP, CFG_STEPS = 3, 5
+CFG_PARITY = 64
+CFG_CPU_COLS = 1024
+CFG_START = 30_000_000              # first global column of the configs' batch (disjoint from the headline batch and the CPU samples)
+CFG_NAMES = ("cfg1_lw_clear_100k", "cfg2_sw_noaer_100k", "cfg2_sorad_100k", "cfg2_irrad_100k", "cfg2_mcica_200")
+CFG_KERNEL = {"cfg1_lw_clear_100k": "k_lw_bands", "cfg2_sw_noaer_100k": "k_sw_reform", "cfg2_sorad_100k": "k_sorad_pass",
+              "cfg2_irrad_100k": "k_chou_bands", "cfg2_mcica_200": "k_mcica_sa"}
+IRRAD_IN = ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg", "tv", "ev", "rv",
+            "taua", "ssaa", "asya")
+IRRAD_OUT = ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts")
+SORAD_IN = ("cosz", "pl", "ta", "wa", "oa", "cwc", "fcld", "reff", "taua", "ssaa", "asya", "rsuvbm", "rsuvdf", "rsirbm", "rsirdf")
+SW_LAY = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr", "cldf", "ciwp", "clwp", "rei", "rel", "zm", "alat"]
+
+
+def cfg_algorithmic_bytes(name, nlay=CFG_NLAY, nsub=CFG_NSUB, real_bytes=4):
+    """compulsory bytes per column at the solver API: every input once + every output once"""
+    if name == "cfg1_lw_clear_100k":
+        return algorithmic_bytes_lw(nlay, real_bytes, False)               # 7 608 @72 layers
+    if name == "cfg2_sw_noaer_100k":
+        return algorithmic_bytes_sw(nlay, real_bytes, False)               # 5 356
+    if name == "cfg2_sorad_100k":
+        return 11904 * real_bytes // 4                                     # 2 670 in + 306 out reals
+    if name == "cfg2_irrad_100k":
+        return 19476 * real_bytes // 4                                     # 3 491 in + 1 378 out reals
+    return (5 * nlay + 1) * real_bytes + nsub * nlay * (4 + 2 * real_bytes)    # generator: 174 244
+
+
+def cfg_inputs(ncol, start, want_chou=True):
+    """the two column batches of the configs: cloud-free without aerosols (configs[1]) and 60 % cloudy with aerosols (configs[2]; the
+    Chou-Suarez inputs are the same columns in that scheme's units and ordering)"""
+    from geosradiation_gridcomp_amd import synth
+    clr = synth.make_columns(ncol, CFG_NLAY, start=start, cloudy_frac=0.0, aerosol=False)
+    cld = synth.make_columns(ncol, CFG_NLAY, start=start, cloudy_frac=0.6, aerosol=True)
+    ch = synth.chou_lw_inputs(cld, aerosol=True) if want_chou else None
+    cs = synth.chou_sw_inputs(cld, aerosol=True) if want_chou else None
+    return clr, cld, ch, cs
+
+
+def _cache_put(cdir, key, d):
+    os.makedirs(os.path.join(cdir, key), exist_ok=True)
+    scal = {}
+    for k, v in d.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1:
+            np.save(os.path.join(cdir, key, k + ".npy"), v)
+        else:
+            scal[k] = (float(v) if isinstance(v, (float, np.floating)) else int(v))
+    with open(os.path.join(cdir, key, "scalars.json"), "w") as fh:
+        json.dump(scal, fh)
+
+
+def _cache_get(cdir, key):
+    d = os.path.join(cdir or "", key)
+    if not cdir or not os.path.exists(os.path.join(d, "scalars.json")):
+        return None
+    with open(os.path.join(d, "scalars.json")) as fh:
+        out = dict(json.load(fh))
+    for f in os.listdir(d):
+        if f.endswith(".npy"):
+            out[f[:-4]] = np.load(os.path.join(d, f), mmap_mode="r")
+    return out
+
+
+def _cfg_cpu_worker(args):
+    start, n = args
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib, reflib
+    clr, cld, ch, cs = cfg_inputs(n, start)
+    t = {}
+    ref = reflib.available("r4")
+    clib.lib()
+    if ref:
+        reflib.lib("r4"); reflib.set_inhomogeneity(0, "r4")
+        t0 = time.perf_counter(); reflib.rrtmg_lw(clr, "r4", psize=4); t["cfg1_lw_clear_100k"] = time.perf_counter() - t0
+    else:
+        clib.set_inhomogeneity(0, "f32")
+        t0 = time.perf_counter(); clib.rrtmg_lw(clr, "f32"); t["cfg1_lw_clear_100k"] = time.perf_counter() - t0
+    clib.set_inhomogeneity(1, "f32")
+    t0 = time.perf_counter(); clib.rrtmg_sw(cld, prec="f32", iaer=0, normFlx=1); t["cfg2_sw_noaer_100k"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); clib.sorad(cs, "f32"); t["cfg2_sorad_100k"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); clib.irrad(ch, "f32"); t["cfg2_irrad_100k"] = time.perf_counter() - t0
+    a = (cld["zm"], cld["alat"], int(cld["dyofyr"]), cld["play"], cld["cldf"], cld["ciwp"], cld["clwp"], CFG_NSUB)
+    if ref:
+        reflib.set_inhomogeneity(1, "r4")
+        t0 = time.perf_counter(); reflib.mcica(*a, kind="r4"); t["cfg2_mcica_200"] = time.perf_counter() - t0
+    else:
+        t0 = time.perf_counter(); clib.mcica(*a, prec="f32"); t["cfg2_mcica_200"] = time.perf_counter() - t0
+    return t
+
+
+def configs_cpu_baseline(per_core=CFG_CPU_COLS):
+    """one pool over the host cores, every process runs the five configs on its own `per_core` columns"""
+    import multiprocessing as mp
+    from oracle import reflib
+    ref = reflib.available("r4")
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    with mp.get_context("fork").Pool(cores) as pool:
+        per = pool.map(_cfg_cpu_worker, [(40_000_000 + i * per_core, per_core) for i in range(cores)])
+    what = {"cfg1_lw_clear_100k": ("reference" if ref else "port", "rrtmg_lw = " + ("reference Fortran (oracle/_ref), psize=4" if ref else "plain-C oracle")),
+            "cfg2_sw_noaer_100k": ("port", "rrtmg_sw = plain-C oracle (the reference driver needs ESMF/MAPL: unbuildable here)"),
+            "cfg2_sorad_100k": ("port", "sorad = plain-C oracle (sorad.F90 needs MAPL: unbuildable here)"),
+            "cfg2_irrad_100k": ("port", "irrad = plain-C oracle (irrad.F90 needs MAPL: unbuildable here)"),
+            "cfg2_mcica_200": ("reference" if ref else "port", f"generate_stochastic_clouds(nsubcol={CFG_NSUB}) = "
+                               + ("reference Fortran (oracle/_ref)" if ref else "plain-C oracle"))}
+    out = {}
+    for name in CFG_NAMES:
+        busy = max(p[name] for p in per); mean = sum(p[name] for p in per) / len(per)
+        out[name] = {"value": cores * per_core / busy, "unit": "columns/s", "cores": cores, "kind": what[name][0],
+                     "sample": f"{cores} processes x {per_core} columns of the config's workload; {what[name][1]}; slowest process {busy:.2f} s",
+                     "single_core_columns_per_s": per_core / mean}
+    return out
+
+
+def configs_gpu(dev, local_rank, start, ncol, warmup, steps, cache=None, want_parity=True, only=None):
+    """the five configuration legs on the device, one after the other, one stream; returns {name: {...}} with the leg's timings, the
+    profile of its kernels and (want_parity) the first CFG_PARITY columns of its outputs"""
+    import torch
+    from geosradiation_gridcomp_amd.api import Context
+    nlay = CFG_NLAY
+    tdt = torch.float32
+    got = _cache_get(cache, "cfg")
+    if got is not None:
+        split = lambda pre: {k[len(pre):]: v for k, v in got.items() if k.startswith(pre)}
+        clr, cld, ch, cs = split("clr_"), split("cld_"), split("ch_"), split("cs_")
+    else:
+        clr, cld, ch, cs = cfg_inputs(ncol, start)
+    stream = torch.cuda.current_stream().cuda_stream
+    to = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev, dtype=tdt)
+    zeros = lambda *sh: torch.zeros(*sh, device=dev, dtype=tdt)
+    ns = min(CFG_PARITY, ncol)
+    ctx = Context(4, device=local_rank)
+    res = {}
+
+    def run(name, step, kernel, sample):
+        for _ in range(warmup):
+            step()
+        ctx.check(stream)
+        ctx.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        ctx.check(stream)
+        prof = ctx.profile_read()
+        ctx.profile(False)
+        if isinstance(kernel, tuple):                     # the band sweeps have two mappings (GEOSRAD_SW_PATH): the one that ran
+            kernel = next((k for k in kernel if prof.get(k, (0, 0))[1] > 0), kernel[0])
+        slot = "k_mcica" if kernel == "k_mcica_sa" else kernel            # the generator's two kernels share a profile slot
+        ms, n = prof.get(slot, (0.0, 0))
+        res[name] = {"ms_per_step": dt_ / steps * 1e3, "value": ncol / (dt_ / steps), "kernel": kernel, "kernel_ms_per_step": ms / steps,
+                     "kernel_launches_per_step": n / steps, "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
+                     "sample": sample() if want_parity else None}
+
+    doy, lm, mh = int(cld["dyofyr"]), int(cld["cloudLM"]), int(cld["cloudMH"])
+    # ---- configs[1]: RRTMG_LW clear-sky -------------------------------------------------------------------------------------------
+    if only is None or "cfg1_lw_clear_100k" in only:
+        d = {k: to(clr[k]) for k in ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat"] + LW_IN2D}
+        for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs"):
+            d[k] = zeros(nlay + 1, ncol)
+        d["clearCounts"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+        ctx.set_inhomogeneity(0)
+        run("cfg1_lw_clear_100k", lambda: ctx.rrtmg_lw_dev(stream, ncol, nlay, True, ptr, 3, 1, int(clr["dyofyr"]), int(clr["cloudLM"]), int(clr["cloudMH"])),
+            "k_lw_bands", lambda: {k: d[k][..., :ns].cpu().numpy() for k in PARITY_LW})
+        del d, ptr
+    # ---- configs[2]: RRTMG_SW with McICA clouds, no aerosol --------------------------------------------------------------------------
+    if only is None or "cfg2_sw_noaer_100k" in only:
+        d = {k: to(cld[k]) for k in SW_LAY + SW_IN}
+        for k in PARITY_SW:
+            d[k] = zeros(nlay + 1, ncol)
+        for k in SW_OUT1:
+            d[k] = zeros(ncol)
+        d["fswband"] = zeros(14, ncol)
+        d["clearCounts_sw"] = torch.zeros((4, ncol), device=dev, dtype=torch.int32)
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+        ctx.set_inhomogeneity(1)
+        run("cfg2_sw_noaer_100k", lambda: ctx.rrtmg_sw_dev(stream, ncol, nlay, 1361.0, 1.0, 0, ptr, 3, 1, doy, 0, lm, mh, normFlx=1),
+            SW_BAND_KERNELS, lambda: {k: d[k][..., :ns].cpu().numpy() for k in PARITY_SW + ("clearCounts_sw",)})
+        del d, ptr
+    # ---- configs[2]: sorad ---------------------------------------------------------------------------------------------------------------
+    if only is None or "cfg2_sorad_100k" in only:
+        d = {k: to(cs[k]) for k in SORAD_IN}
+        for k in ("flx", "flc", "flxu", "flcu"):
+            d[k] = zeros(nlay + 1, ncol)
+        for k in ("fdiruv", "fdifuv", "fdirpar", "fdifpar", "fdirir", "fdifir"):
+            d[k] = zeros(ncol)
+        d["flx_sfc_band"] = zeros(8, ncol)
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+        run("cfg2_sorad_100k", lambda: ctx.sorad_dev(stream, ncol, nlay, 8, ptr, cs["co2"], cs["ict"], cs["icb"], cs["hk_uv"], cs["hk_ir"]),
+            "k_sorad_pass", lambda: {k: d[k][..., :ns].cpu().numpy() for k in ("flx", "flc", "flxu", "flcu")})
+        del d, ptr
+    # ---- irrad (taua / ssaa / asya are in-out, rescaled in place: the inputs are restored every step, inside the timed region) ------------
+    if only is None or "cfg2_irrad_100k" in only:
+        d = {k: to(ch[k]) for k in IRRAD_IN}
+        for k in IRRAD_OUT:
+            d[k] = zeros(nlay + 1, ncol)
+        d["sfcem"] = zeros(ncol); d["taudiag"] = zeros(10, nlay, ncol)
+        aer0 = {k: d[k].clone() for k in ("taua", "ssaa", "asya")}
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+
+        def irrad_step():
+            for k in aer0:
+                d[k].copy_(aer0[k])
+            ctx.irrad_dev(stream, ncol, nlay, ptr, ch["co2"], True, ch["ict"], ch["icb"], ch["ns"], ch["na"], ch["nb"])
+        run("cfg2_irrad_100k", irrad_step, "k_chou_bands", lambda: {k: d[k][..., :ns].cpu().numpy() for k in ("flxu", "flxd", "flcu", "flcd")})
+        del d, ptr, aer0
+    # ---- configs[2]: the generator stand-alone, 200 sub-columns ------------------------------------------------------------------------
+    if only is None or "cfg2_mcica_200" in only:
+        d = {k: to(cld[k]) for k in ("zm", "alat", "play", "cldf", "ciwp", "clwp")}
+        d["cldy_stoch"] = torch.zeros((ncol, CFG_NSUB, nlay), dtype=torch.int32, device=dev)
+        d["ciwp_stoch"] = zeros(ncol, CFG_NSUB, nlay); d["clwp_stoch"] = zeros(ncol, CFG_NSUB, nlay)
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+        ctx.set_inhomogeneity(1)
+        run("cfg2_mcica_200", lambda: ctx.generate_stochastic_clouds_dev(stream, ncol, CFG_NSUB, nlay, ptr, doy, 1e-20),
+            "k_mcica_sa", lambda: {k: d[k][:ns].cpu().numpy() for k in ("cldy_stoch", "ciwp_stoch", "clwp_stoch")})
+        del d, ptr
+    ctx.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+def configs_parity(res, start):
+    """CFG_PARITY columns of every leg's output against oracle/liboracle.so (the checker; single-threaded, after the timed regions)"""
+    from oracle import clib
+    ns = CFG_PARITY
+    clr, cld, ch, cs = cfg_inputs(ns, start)
+    clib.lib()
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    out = {}
+    g = res.get("cfg1_lw_clear_100k", {}).get("sample")
+    if g:
+        clib.set_inhomogeneity(0, "f32")
+        o = clib.rrtmg_lw(clr, "f32")
+        out["cfg1_lw_clear_100k"] = {"columns": ns, "max_abs_Wm2": max(float(np.abs(f64(g[k]) - f64(o[k])).max()) for k in PARITY_LW),
+                                     "tolerance_Wm2": 2e-3, "oracle": "oracle/liboracle.so (f32), pinned bit for bit to the reference's rrtmg_lw"}
+    g = res.get("cfg2_sw_noaer_100k", {}).get("sample")
+    if g:
+        clib.set_inhomogeneity(1, "f32")
+        q = clib.rrtmg_sw(cld, prec="f32", iaer=0, normFlx=1)
+        same = (g["clearCounts_sw"] == q["clearCounts"]).all(axis=0)
+        rel = np.zeros(ns)
+        for k in PARITY_SW:
+            dk = np.abs(f64(g[k]) - f64(q[k])).max(axis=0)
+            rel = np.maximum(rel, dk if k.endswith("c") else np.where(same, dk, 0.0))
+        out["cfg2_sw_noaer_100k"] = {"columns": ns, "max_rel_toa": float(rel.max()), "tolerance_rel_toa": 5e-4,
+                                     "columns_with_other_clearCounts": int((~same).sum()),
+                                     "oracle": "oracle/liboracle.so (f32): setcoef / taumol / McICA / cldprmc pinned to the reference, two-stream + driver parity unpinned"}
+        clib.set_inhomogeneity(0, "f32")
+    g = res.get("cfg2_sorad_100k", {}).get("sample")
+    if g:
+        o = clib.sorad(cs, "f32")
+        out["cfg2_sorad_100k"] = {"columns": ns, "max_abs_fraction_of_insolation": max(float(np.abs(f64(g[k]) - f64(o[k])).max()) for k in g),
+                                  "tolerance": 2e-5, "oracle": "oracle/liboracle.so (f32), parity unpinned (sorad.F90 needs MAPL)"}
+    g = res.get("cfg2_irrad_100k", {}).get("sample")
+    if g:
+        o = clib.irrad(ch, "f32")
+        out["cfg2_irrad_100k"] = {"columns": ns, "max_abs_Wm2": max(float(np.abs(f64(g[k]) - f64(o[k])).max()) for k in g),
+                                  "tolerance_Wm2": 2e-2, "oracle": "oracle/liboracle.so (f32), parity unpinned (irrad.F90 needs MAPL)"}
+    g = res.get("cfg2_mcica_200", {}).get("sample")
+    if g:
+        clib.set_inhomogeneity(1, "f32")
+        m, ci, cw = clib.mcica(cld["zm"], cld["alat"], int(cld["dyofyr"]), cld["play"], cld["cldf"], cld["ciwp"], cld["clwp"], CFG_NSUB, prec="f32")
+        clib.set_inhomogeneity(0, "f32")
+        flips = int(((g["cldy_stoch"] != 0) != (m != 0)).sum())
+        agree = (g["cldy_stoch"] != 0) == (m != 0)
+        wp = max(float(np.abs(f64(g["ciwp_stoch"]) - f64(ci))[agree].max()), float(np.abs(f64(g["clwp_stoch"]) - f64(cw))[agree].max()))
+        out["cfg2_mcica_200"] = {"columns": ns, "mask_flips": flips, "cells_with_a_decision": int((cld["cldf"] > 0).sum()) * CFG_NSUB,
+                                 "max_abs_water_path_g_m2": wp, "oracle": "oracle/liboracle.so (f32), pinned bit for bit to the reference's generator"}
+    return out
+
+
+def configs_only(a, local_rank):
+    """`bench.py --configs-only`: the five legs alone (what the rocprofv3 child runs of the default line execute; also the command behind
+    profiles/r04_configs_kernel_stats.csv)"""
+    import torch
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    res = configs_gpu(dev, local_rank, CFG_START, CFG_NCOL, a.warmup, a.steps, a.inputs_cache or None, want_parity=False)
+    print(json.dumps({"configs": configs_assemble(res, None, None, None, CFG_NCOL, a.steps, a.warmup)}))
+
+
+def configs_assemble(res, parity, cpu, live, ncol, steps, warmup):
+    """the `configs` object of the bench line"""
+    out = {}
+    for name in CFG_NAMES:
+        r = res.get(name)
+        if r is None:
+            continue
+        kern = r["kernel"]
+        abytes = cfg_algorithmic_bytes(name)
+        lps = max(r["kernel_launches_per_step"], 1e-9)
+        launch_s = r["kernel_ms_per_step"] / lps * 1e-3
+        achieved = abytes * (ncol / lps) / launch_s / 1e9 if launch_s > 0 else 0.0
+        t = (live or {}).get(kern)
+        e = {"value": r["value"], "unit": "columns/s", "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup, "columns": ncol,
+             "layers": CFG_NLAY, "dtype": "u32 (KISS) + f32" if name == "cfg2_mcica_200" else "f32",
+             "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                          "traffic": None if t is None else t["traffic_bytes"] / lps,
+                          "traffic_source": None if t is None else "measured in this run: rocprofv3 --pmc child runs of `bench.py --configs-only` (3 steps per config, same columns)",
+                          "algorithmic_bytes_per_column": abytes, "avg_launch_ms": r["kernel_ms_per_step"] / lps,
+                          "launches_per_step": r["kernel_launches_per_step"], "columns_per_launch": ncol / lps},
+             "kernels_ms_per_step": r["kernels_ms_per_step"], "cpu_baseline": (cpu or {}).get(name), "parity": (parity or {}).get(name)}
+        if t is not None and "valu_util" in t:
+            e["roofline_compute"] = {"kernel": kern, "valu_util": t["valu_util"], "wait_frac": t.get("wait_frac"),
+                                     "resident_waves_per_simd": t.get("resident_waves_per_simd"),
+                                     "lane_ops_per_column": round(t["valu_insts"] * 64.0 / ncol) if "valu_insts" in t else None}
+        out[name] = e
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -837,9 +1185,16 @@ def main():
     ap.add_argument("--ranks-per-gpu", default="",
                     help="K1,K2,...: for each K, K child processes (Fortran drop-in callers, host arrays) share the GPU on 1/K of the batch each; "
                          "aggregate columns/s per K (what the MPI ranks of a node get)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default line (lwsw, N = 1): skip the `configs` object - BASELINE configs[1] / [2] (RRTMG_LW clear-sky; RRTMG_SW + sorad + "
+                         "irrad + the 200-sub-column generator; 100 000 columns each) timed after the headline's legs")
+    ap.add_argument("--configs-only", action="store_true", help="run only the five configuration legs (the PMC child of the default line)")
+    ap.add_argument("--inputs-cache", default="", help="internal: directory with the parent run's generated inputs (np.save files)")
     ap.add_argument("--control-path-only", action="store_true",
                     help="no GPU work: launcher, rank -> shard, barrier, MAX over ranks and rank 0's JSON line only (CPU rehearsal / tests)")
     a = ap.parse_args()
+    import warnings
+    warnings.filterwarnings("ignore", message="The given NumPy array is not writable")      # inputs mapped read-only from the cache
     if "WORLD_SIZE" not in os.environ:
         if a.gpus > 1:                   # the driver may start us as a plain `python bench.py --gpus N`: become the launcher
             sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
@@ -860,13 +1215,42 @@ def main():
     if a.ranks_per_gpu:
         return bench_ranks_per_gpu(a)
 
-    live = None
-    if rank == 0 and a.gpus == 1 and world == 1 and not a.no_pmc and a.scheme in ("lwsw", "lw", "sw", "chou", "irrad", "sorad") \
-            and not under_profiler():
-        live = live_counters(a, sys.argv[1:])          # child processes, before this one touches the GPU
-    cpu = None
+    if a.configs_only:
+        return configs_only(a, local_rank)
+    # the `configs` object rides on the default line only (one GPU, fp32 headline, every column lit)
+    want_cfg = (rank == 0 and world == 1 and a.gpus == 1 and a.scheme == "lwsw" and a.real == 4 and a.lit == 1.0 and a.coherent == 1
+                and not a.no_configs and not a.host_api and not os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"))
+    want_pmc = (rank == 0 and a.gpus == 1 and world == 1 and not a.no_pmc and a.scheme in ("lwsw", "lw", "sw", "chou", "irrad", "sorad")
+                and not under_profiler())
+    live = live_cfg = cache = None
+    inp_main = None
+    if want_pmc and not a.inputs_cache:
+        # the generated inputs are written once (np.save, memory-backed directory) and mapped by the rocprofv3 child runs and by this process,
+        # instead of being generated again by each of them; removed at exit
+        import atexit, shutil, tempfile
+        from geosradiation_gridcomp_amd import synth as _synth
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else os.environ.get("TMPDIR", "/tmp")
+        cache = tempfile.mkdtemp(prefix="geosrad_bench_", dir=base)
+        atexit.register(shutil.rmtree, cache, True)
+        if a.scheme in ("lwsw", "lw", "sw") and a.coherent == 1 and not os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"):
+            inp_main = _synth.make_columns(a.ncol, a.nlay, start=shard_start(rank, a.ncol), cloudy_frac=a.cloudy, aerosol=not a.no_aerosol)
+            _cache_put(cache, "main", inp_main)
+        if want_cfg:
+            clr, cld, ch, cs = cfg_inputs(CFG_NCOL, CFG_START)
+            _cache_put(cache, "cfg", {**{"clr_" + k: v for k, v in clr.items()}, **{"cld_" + k: v for k, v in cld.items()},
+                                      **{"ch_" + k: v for k, v in ch.items()}, **{"cs_" + k: v for k, v in cs.items()}})
+            del clr, cld, ch, cs
+    elif a.inputs_cache:
+        cache = a.inputs_cache
+    if want_pmc:
+        live = live_counters(a, sys.argv[1:], cache)          # child processes, before this one touches the GPU
+        if want_cfg:
+            live_cfg = live_counters(a, sys.argv[1:], cache, configs=True)
+    cpu = cpu_cfg = None
     if a.lit < 1.0:
         a.no_cpu = True           # the CPU leg times LW and SW on the same columns: not the --lit workload
+    if want_cfg and not a.no_cpu:
+        cpu_cfg = configs_cpu_baseline()
     if rank == 0 and a.gpus == 1 and not a.no_cpu:                 # before any GPU initialisation in this process (fork pool)
         if a.scheme == "heartbeat":
             cpu = heartbeat_cpu_baseline(a.nlay)
@@ -912,7 +1296,9 @@ def main():
 
     # ---- inputs resident in HBM -------------------------------------------------------------------------------
     ncol, nlay = a.ncol, a.nlay
-    inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
+    inp = inp_main if inp_main is not None else _cache_get(cache, "main")
+    if inp is None or inp["play"].shape != (nlay, ncol):
+        inp = synth.make_columns(ncol, nlay, start=shard_start(rank, ncol), cloudy_frac=a.cloudy, aerosol=aerosol)
     if os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"):
         # experiment (profiles/): the batch's cloud-free columns first - the library's clear | cloudy partition is then the identity and every
         # array in the caller's column order is read fully coalesced
@@ -1036,6 +1422,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = all_over_ranks(elapsed / a.steps * 1e3, world)
     elapsed = max_over_ranks(elapsed, world, torch.device("cpu"))
     ctx.check(stream)
     prof = ctx.profile_read()
@@ -1073,7 +1460,8 @@ def main():
 
     # ---- the tolerance-qualifying precision and the in-run parity figures (N = 1, RRTMG schemes, every column lit) ---------------------
     f64_leg = parity = None
-    want_parity = rank == 0 and world == 1 and (do_lw or do_sw) and lit is None and a.coherent == 1 and not a.no_parity
+    want_parity = (rank == 0 and world == 1 and (do_lw or do_sw) and lit is None and a.coherent == 1 and not a.no_parity
+                   and not os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"))         # the parity sample is taken in the generator's column order
     if want_parity:
         ns = min(PARITY_COLS, ncol)
         keys = (PARITY_LW if do_lw else ()) + (PARITY_SW if do_sw else ()) + (("clearCounts",) if do_lw else ()) + (("clearCounts_sw",) if do_sw else ())
@@ -1101,23 +1489,33 @@ def main():
         if f64_leg is not None and "f64" in parity:
             f64_leg["max_abs_err_vs_oracle_Wm2"] = max(parity["f64"].get("lw_max_abs_Wm2", 0.0), parity["f64"].get("sw_max_abs_Wm2", 0.0))
 
+    cfg_out = None
+    if want_cfg:
+        if f64_leg is None:               # the headline's context and arrays are still alive: release the device memory first
+            ctx.close()
+            d = ptr = None
+            torch.cuda.empty_cache()
+        cres = configs_gpu(dev, local_rank, CFG_START, CFG_NCOL, CFG_WARMUP, CFG_STEPS, cache, want_parity=not a.no_parity)
+        cpar = configs_parity(cres, CFG_START) if not a.no_parity else None
+        cfg_out = configs_assemble(cres, cpar, cpu_cfg, live_cfg, CFG_NCOL, CFG_STEPS, CFG_WARMUP)
+
     if rank == 0:
         total_cols = world * ncol * a.steps
         value = total_cols / elapsed
         # dominant kernel = largest total time; its algorithmic bytes are those of the solver it belongs to
         # (compulsory bytes at the solver API, every input read once + every output written once)
-        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_sw_bands", "k_chou_bands", "k_sorad_pass") and v[1] > 0}
+        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_lw_cols", "k_chou_bands", "k_sorad_pass", "k_sorad_col") + SW_BAND_KERNELS and v[1] > 0}
         kname = max(cand, key=lambda k: cand[k][0])
         ms, n = prof1[kname]
         launches_per_step = n / (2 if prof1 is not prof else a.steps)
         if kname == "k_chou_bands":
             abytes = 19476 * a.real // 4                # Chou irrad 3 491 in + 1 378 out reals @72 layers
-        elif kname == "k_sorad_pass":
+        elif kname in ("k_sorad_pass", "k_sorad_col"):
             abytes = 11904 * a.real // 4                # Chou sorad 2 670 in + 306 out reals
         else:
-            abytes = (algorithmic_bytes_lw if kname == "k_lw_bands" else algorithmic_bytes_sw)(nlay, a.real, aerosol)
+            abytes = (algorithmic_bytes_lw if kname.startswith("k_lw") else algorithmic_bytes_sw)(nlay, a.real, aerosol)
         per_launch_s = (ms / max(n, 1)) * 1e-3
-        ncol_k = ncol_sw if kname == "k_sw_bands" else ncol          # columns the dominant kernel's launches cover
+        ncol_k = ncol_sw if kname in SW_BAND_KERNELS else ncol          # columns the dominant kernel's launches cover
         achieved = abytes * (ncol_k / launches_per_step) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel: measured by this run's own rocprofv3 --pmc child runs (live_counters), else from the
         # passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc runs) - those only for the exact configuration they
@@ -1171,16 +1569,24 @@ def main():
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items() if v[1] > 0},
             "cpu_baseline": cpu,
         }
+        if world > 1:
+            out["per_rank_ms"] = per_rank_ms             # each rank's own ms per step between the two barriers (value uses the MAX)
         if compute is not None:
             out["roofline_compute"] = compute
         if f64_leg is not None:
             out["f64"] = f64_leg
         if parity is not None:
+            bad = [k for k, v in parity.items() if not v.get("within_tolerance", True)]
+            if bad:
+                print("bench.py: in-run parity OUTSIDE the tolerance for " + ", ".join(bad) + ": " + json.dumps({k: parity[k] for k in bad}), file=sys.stderr)
+            out["parity_ok"] = not bad
             out["parity"] = parity.get("f32" if a.real == 4 else "f64")
             if a.real == 4 and "f64" in parity:
                 out["f64"]["parity"] = parity["f64"]
         if host_api is not None:
             out["host_api"] = host_api
+        if cfg_out is not None:
+            out["configs"] = cfg_out
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -16,7 +16,7 @@ EXPORTS = [
     "geosrad_create", "geosrad_create_multi", "geosrad_pick_device", "geosrad_destroy", "geosrad_last_error", "geosrad_real_kind", "geosrad_set_chunk",
     "geosrad_workspace_bytes", "geosrad_set_tables_lw", "geosrad_load_tables_lw", "geosrad_set_inhomogeneity",
     "geosrad_load_inhomogeneity", "geosrad_set_corr_lengths", "geosrad_rrtmg_lw", "geosrad_rrtmg_lw_dev",
-    "geosrad_check", "geosrad_profile", "geosrad_profile_read", "geosrad_kernel_name", "geosrad_rrtmg_lw_taumol", "geosrad_mcica", "geosrad_clearcounts",
+    "geosrad_check", "geosrad_profile", "geosrad_profile_read", "geosrad_kernel_name", "geosrad_kernel_label", "geosrad_rrtmg_lw_taumol", "geosrad_mcica", "geosrad_clearcounts",
     "geosrad_set_tables_sw", "geosrad_load_tables_sw", "geosrad_rrtmg_sw", "geosrad_rrtmg_sw_dev", "geosrad_rrtmg_sw_taumol", "geosrad_mcica_dev",
     "geosrad_set_tables_chou_lw", "geosrad_load_tables_chou_lw", "geosrad_irrad", "geosrad_irrad_dev",
     "geosrad_lw_driver_rrtmg_dev", "geosrad_sw_driver_rrtmg_dev", "geosrad_lw_update_flx_dev", "geosrad_sw_update_export_dev",
@@ -80,6 +80,8 @@ def lib():
         L.geosrad_workspace_bytes.restype = ctypes.c_size_t
         L.geosrad_workspace_bytes.argtypes = [ctypes.c_void_p]
         L.geosrad_kernel_name.restype = ctypes.c_char_p
+        L.geosrad_kernel_label.restype = ctypes.c_char_p
+        L.geosrad_kernel_label.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.geosrad_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]
         L.geosrad_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]
         L.geosrad_pick_device.argtypes = [ctypes.c_int]

@@ -508,12 +508,13 @@ class Context:
         self._chk(self.L.geosrad_profile(self.h, ctypes.c_int(1 if enable else 0)))
 
     def profile_read(self):
-        """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
+        """{kernel name: (total ms, launches)} measured with HIP events on the launch stream; the names are those of the kernels that ran
+        (a rocprofv3 kernel trace of the same run shows them as geosrad::<name><...>)."""
         out = {}
         for k in range(14):
             ms = ctypes.c_double(); n = ctypes.c_long()
             self._chk(self.L.geosrad_profile_read(self.h, ctypes.c_int(k), ctypes.byref(ms), ctypes.byref(n)))
-            out[self.L.geosrad_kernel_name(ctypes.c_int(k)).decode()] = (ms.value, n.value)
+            out[self.L.geosrad_kernel_label(self.h, ctypes.c_int(k)).decode()] = (ms.value, n.value)
         return out
 
     def check(self, stream=0):

@@ -2635,8 +2635,16 @@ extern "C" {
 int geosrad_pick_device(int ndev)
 {
     if (ndev <= 0) return 0;
-    static const char *vars[] = {"GEOSRAD_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID",
-                                 "PMI_LOCAL_RANK"};
+    // an explicit device id is taken as it is: out of range (a stale or mistyped GEOSRAD_DEVICE) is an error (-1 -> GEOSRAD_ENODEV from
+    // geosrad_create), not another GPU; only the launchers' node-local ranks wrap around the device count
+    if (const char *e = getenv("GEOSRAD_DEVICE")) {
+        if (*e) {
+            char *end = nullptr;
+            const long r = strtol(e, &end, 10);
+            return (end == e || *end || r < 0 || r >= ndev) ? -1 : (int)r;
+        }
+    }
+    static const char *vars[] = {"OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "PMI_LOCAL_RANK"};
     for (const char *v : vars) {
         const char *e = getenv(v);
         if (!e || !*e) continue;
@@ -3114,6 +3122,20 @@ const char *geosrad_kernel_name(int kernel_id)
                                  "k_sw_validate", "k_sw_setcoef", "k_sw_bands", "k_sw_reduce", "k_chou_prep", "k_chou_bands",
                                  "k_sorad_prep", "k_sorad_pass"};
     return kernel_id >= 0 && kernel_id < 14 ? nm[kernel_id] : "";
+}
+
+// the name of the kernel that runs in a profile slot under THIS context's kernel paths (GEOSRAD_SW_PATH / _LW_PATH / _SORAD_PATH), as it
+// appears in rocprofv3's kernel trace
+const char *geosrad_kernel_label(geosrad_ctx *c, int kernel_id)
+{
+    if (!c) return geosrad_kernel_name(kernel_id);
+    switch (kernel_id) {
+    case 4: return c->lw_cols_path ? "k_lw_cols" : "k_lw_bands";
+    case 8: return c->sw_path == 2 ? "k_sw_reform" : "k_sw_bands";
+    case 9: return c->sw_path == 2 ? "k_swr_reduce" : "k_sw_reduce";
+    case 13: return c->sorad_col_path ? "k_sorad_col" : "k_sorad_pass";
+    default: return geosrad_kernel_name(kernel_id);
+    }
 }
 
 int geosrad_check(geosrad_ctx *c, void *stream) { return c ? c->check((hipStream_t)stream) : GEOSRAD_EINVAL; }

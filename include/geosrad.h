@@ -63,14 +63,14 @@ enum {
  * The reference keeps its state in module variables of the process; here it lives in a context.  One context = one HIP
  * device (geosrad_create) or several (geosrad_create_multi, SURVEY 8b: the host-pointer solver entry points then cut [0, ncol) into
  * contiguous shards, one per device, processed concurrently; results bitwise those of one device).
- * device_id = GEOSRAD_DEVICE_AUTO: the device geosrad_pick_device chooses - GEOSRAD_DEVICE if set, else the launcher's node-local
- * MPI rank (OMPI_COMM_WORLD_LOCAL_RANK, SLURM_LOCALID, MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID, PMI_LOCAL_RANK) modulo the number
- * of visible devices - what the Fortran drop-in uses, so the ranks of a GEOS job (GEOS_SolarGridComp.F90:3701-3709 balances their
+ * device_id = GEOSRAD_DEVICE_AUTO: the device geosrad_pick_device chooses - GEOSRAD_DEVICE if set (taken as it is: an id outside
+ * [0, ndev) is GEOSRAD_ENODEV, not another GPU), else the launcher's node-local MPI rank (OMPI_COMM_WORLD_LOCAL_RANK, SLURM_LOCALID,
+ * MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID, PMI_LOCAL_RANK) modulo the number of visible devices - what the Fortran drop-in uses, so the ranks of a GEOS job (GEOS_SolarGridComp.F90:3701-3709 balances their
  * work) spread over a node's GPUs without configuration. */
 #define GEOSRAD_DEVICE_AUTO (-1)
 int geosrad_create(geosrad_ctx **ctx, int device_id, int real_kind /* 4 | 8 */);
 int geosrad_create_multi(geosrad_ctx **ctx, const int *device_ids, int ndev, int real_kind);
-int geosrad_pick_device(int ndev);      /* pure function of the environment; no device needed */
+int geosrad_pick_device(int ndev);      /* pure function of the environment; no device needed; -1 = GEOSRAD_DEVICE out of range */
 int geosrad_destroy(geosrad_ctx *ctx);
 const char *geosrad_last_error(const geosrad_ctx *ctx);
 int geosrad_real_kind(const geosrad_ctx *ctx);
@@ -149,7 +149,10 @@ int geosrad_check(geosrad_ctx *ctx, void *stream);
  * returns the accumulated milliseconds and launch count of one kernel. */
 int geosrad_profile(geosrad_ctx *ctx, int enable);
 int geosrad_profile_read(geosrad_ctx *ctx, int kernel_id, double *total_ms, long *launches);
-const char *geosrad_kernel_name(int kernel_id);
+const char *geosrad_kernel_name(int kernel_id);      /* the slot's generic name (the default path's first mapping) */
+/* the kernel that runs in that slot under the context's kernel paths, as it is named in a rocprofv3 kernel trace
+ * (k_sw_reform | k_sw_bands, k_lw_bands | k_lw_cols, k_sorad_pass | k_sorad_col ...) */
+const char *geosrad_kernel_label(geosrad_ctx *ctx, int kernel_id);
 
 /* Debug / test hooks: gas optical depth and Planck fraction as the reference's taumol leaves them,
  * Fortran (nlay,140,ncol), host pointers; ncol*nlay*140 reals each.  Uses the same kernels as

@@ -2,6 +2,7 @@
 columns [rank*n, (rank+1)*n) -- and only a barrier + MAX all-reduce of the elapsed time cross ranks."""
 import os
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -61,7 +62,35 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["shard_starts"] == [0, 1000]
     assert out["ms_per_step"] >= 20.0                    # the slower rank (2 x 10 ms) sets the time
+    assert len(out["per_rank_ms"]) == 2 and out["per_rank_ms"][1] >= out["per_rank_ms"][0] >= 10.0 and max(out["per_rank_ms"]) == out["ms_per_step"]
     # a rank count that contradicts --gpus is refused, not silently run on one GPU
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--control-path-only"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "one rank per GPU" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 path of bench.py on a GPU, as the driver's multi-GPU run takes it (launcher -> two ranks -> barrier, MAX over ranks, one
+    JSON line), rehearsed with both ranks on the box's one device (GEOSRAD_BENCH_REHEARSAL=1: gloo carries the barrier and the MAX - the
+    path has no data exchange).  Started as a child process; 2 x 20 000 columns."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GEOSRAD_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ncol", "20000",
+                        "--no-cpu", "--no-parity"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["columns_per_gpu"] == 20000
+    assert out["value"] == pytest.approx(2 * 20000 / (out["ms_per_step"] * 1e-3), rel=1e-9)
+    assert len(out["per_rank_ms"]) == 2 and max(out["per_rank_ms"]) <= out["ms_per_step"] * (1 + 1e-9) and min(out["per_rank_ms"]) > 0
+    roof = out["roofline"]
+    assert roof["kernel"] in ("k_sw_reform", "k_lw_bands") and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    assert roof["achieved"] == pytest.approx(roof["algorithmic_bytes_per_column"] * roof["columns_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert "configs" not in out and "cpu_baseline" in out

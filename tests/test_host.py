@@ -48,6 +48,9 @@ def test_device_choice_follows_the_local_mpi_rank():
     assert pick(4, MV2_COMM_WORLD_LOCAL_RANK="6") == 2
     assert pick(8, GEOSRAD_DEVICE="2", OMPI_COMM_WORLD_LOCAL_RANK="5") == 2          # the explicit choice wins
     assert pick(8, SLURM_LOCALID="x7") == 0 and pick(0, SLURM_LOCALID="3") == 0      # unparsable / no device: 0
+    # an explicit id is never wrapped: out of range or unparsable -> -1, which geosrad_create turns into GEOSRAD_ENODEV
+    assert pick(4, GEOSRAD_DEVICE="5") == -1 and pick(4, GEOSRAD_DEVICE="3x") == -1 and pick(4, GEOSRAD_DEVICE="-2") == -1
+    assert pick(4, GEOSRAD_DEVICE="3", SLURM_LOCALID="9") == 3
 
 
 def test_product_never_imports_oracle():
@@ -152,7 +155,7 @@ def test_bench_does_not_spawn_profiler_children_under_a_profiler(monkeypatch):
     monkeypatch.delenv("ROCPROF_OUTPUT_PATH")
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.under_profiler()
-    assert set(bench.PMC_GROUPS) >= {"k_sw_bands", "k_lw_bands", "k_chou_bands", "k_sorad_pass"}
+    assert set(bench.PMC_GROUPS) >= {"k_sw_reform", "k_sw_bands", "k_lw_bands", "k_chou_bands", "k_sorad_pass", "k_mcica_sa"}
 
 
 def test_bench_counter_passes_are_parsed_as_the_guide_prescribes(tmp_path, monkeypatch):
@@ -186,14 +189,18 @@ with open(os.path.join(d, "h", "1", "x_counter_collection.csv"), "w") as f:
 ''')
     fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
-    a = argparse.Namespace(scheme="lwsw", ncol=97200, nlay=72, cloudy=0.6, real=4, lit=1.0)
+    a = argparse.Namespace(scheme="lwsw", ncol=97200, nlay=72, cloudy=0.6, real=4, lit=1.0, coherent=1)
     r = bench.live_counters(a, [])
-    assert set(r) == {"k_sw_bands", "k_lw_bands"}                       # k_partition belongs to no group; the two k_sw_reform instantiations to one
-    sw, lw = r["k_sw_bands"], r["k_lw_bands"]
+    assert set(r) == {"k_sw_reform", "k_lw_bands"}                      # k_partition belongs to no group; the two k_sw_reform instantiations to one
+    sw, lw = r["k_sw_reform"], r["k_lw_bands"]
     assert sw["traffic_bytes"] == pytest.approx(2 * (2 * 1000.0 + 500.0) * 1024.0) and lw["traffic_bytes"] == pytest.approx((2 * 1000.0 + 500.0) * 1024.0)
     assert sw["valu_insts"] == pytest.approx(2 * 3.0e6)
     assert lw["valu_util"] == pytest.approx(round(2.0e6 * 4 / (8.0e4 / 8 * 1024), 3)) and lw["wait_frac"] == 0.5
     assert lw["resident_waves_per_simd"] == pytest.approx(round(4 * 5.0e6 / (8.0e4 / 8 * 1024), 2))
+    # the child of the `configs` object runs the five legs alone
+    fake_cfg = fake.read_text().replace('assert "--no-pmc" in a and "--no-overlap" in a', 'assert "--configs-only" in a and "--inputs-cache" in a')
+    fake.write_text(fake_cfg)
+    assert set(bench.live_counters(a, [], cache="/nonexistent", configs=True)) == {"k_sw_reform", "k_lw_bands"}
     # a failing pass -> None (bench.py then quotes the committed figures and says so)
     fake.write_text("#!/bin/sh\\nexit 3\\n")
     assert bench.live_counters(a, []) is None
