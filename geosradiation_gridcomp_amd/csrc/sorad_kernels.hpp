@@ -5,14 +5,21 @@
 //
 // sorad is 35 independent spectral passes (5 UV/PAR bands + 3 NIR bands x 10 k-values), each a set of delta-Eddington layers (no
 // vertical dependence, fp64, the expensive part) + first-order vertical recurrences (adding over up to 8 sky situations):
-//   k_sorad_prep   : per column   - scaled absorber amounts, cloud-group covers, cloud top
-//   k_sorad_cloud  : per (column, optics group: UV/PAR + 3 NIR bands) - getvistau / getnirtau
-//   k_sorad_pass   : per (column, pass), lane = column - deledd of the clear / cloudy portion of every layer, CLDFLX; the per-level arrays of
-//                    the pass in HBM scratch planes [array][level][column] (coalesced); k_sorad_sum adds the passes up (default path)
+//   k_sorad_class  : per column   - which of the three cloud groups (high / middle / low) hold cloud: the column's CLASS (0..7)
+//   k_partition8   : one block    - stable counting sort of the columns by class -> perm (position -> column), class offsets.  Every later
+//                    kernel works on POSITIONS: workspace arrays are indexed by the position, API arrays by perm[position], so 256-position
+//                    blocks are class-homogeneous (at most 7 mixed blocks) whatever the spatial distribution of the clouds
+//   k_sorad_gather : per (position, aerosol row) - the three aerosol arrays copied into position order (each is read by up to 10 passes)
+//   k_sorad_prep   : per position - scaled absorber amounts, cloud-group covers, cloud top
+//   k_sorad_cloud  : per (position, optics group: UV/PAR + 3 NIR bands) - getvistau / getnirtau
+//   k_sorad_pass<CLS> : per (position, pass), lane = column, one instantiation per class - deledd of the clear / cloudy portion of every
+//                    layer, CLDFLX over exactly the class's sky situations; the per-level arrays of the pass in HBM scratch planes
+//                    [array][level][position] (coalesced); k_sorad_sum adds the passes up (default path)
 //   k_sorad_col    : per column, lanes = (pass, level), the 35 passes on chip: no scratch (GEOSRAD_SORAD_PATH=col)
 //   k_sorad_reduce : per column   - weighted sum over the passes (hk_uv, hk_ir), flux reductions, surface rescaling
 // Sky situations of zero weight (ct = 0: a cloud group without cloud) are skipped: their contribution is `+ x * 0`.
 #pragma once
+#include <type_traits>
 #include "lw_kernels.hpp"
 
 namespace geosrad {
@@ -40,6 +47,10 @@ template <typename R> struct SoradArgs {
     R *cld;          // [SO_NGRP][4][K2][m]: tauclb, tauclf, asycl, ssacl
     R *scr;          // [SO_NPASS][SO_NPLANE][K2][m]: per-pass planes of k_sorad_pass (null on the k_sorad_col path)
     R *psum;         // [SO_NPASS][3][m]: fsdir, fsdif and the all-sky net flux at the surface of the pass
+    R *aer;          // [3][SO_NGATHER][np][m]: taua, ssaa, asya of the NIR bands in position order (k_sorad_gather)
+    uint8_t *cls;    // [m] class of the column: 4 (high group has cloud) + 2 (middle) + 1 (low); in column order
+    int32_t *perm;   // [m] position -> column (stable within a class)
+    int32_t *cls_off;// [9] first position of every class, cls_off[8] = m
 };
 template <typename R> struct SoradOut { R *flx, *flc, *fdiruv, *fdifuv, *fdirpar, *fdifpar, *fdirir, *fdifir, *flxu, *flcu, *flx_sfc_band, *drband, *dfband; };
 
@@ -82,36 +93,120 @@ template <typename R> GR_DEV void so_deledd(R tau1, R ssc1, R g01, R cza1, R &rr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_sorad_prep (:271-357, 416-431, 1534-1541)
+// k_sorad_class: which cloud groups of the column hold cloud (cc1, cc2, cc3 > 0, :416-431): the sky situations of non-zero weight are the
+// 2^(groups with cloud) combinations of their clear / cloudy portions.  `one_class`: every column gets class 7 (identity permutation: the
+// on-chip path k_sorad_col takes the situations per column at run time)
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_class(SoradArgs<R> A, int one_class)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.m) return;
+    int c = 7;
+    if (!one_class) {
+        bool h = false, mid = false, low = false;
+        for (int k = 1; k <= A.np; k++) {
+            const bool cl = A.fcld[(size_t)(k - 1) * A.ld + i] > 0;
+            if (k < A.ict) h = h || cl; else if (k < A.icb) mid = mid || cl; else low = low || cl;
+        }
+        c = (h ? 4 : 0) + (mid ? 2 : 0) + (low ? 1 : 0);
+    }
+    A.cls[i] = (uint8_t)c;
+}
+
+// stable counting sort of the columns by class (one 1024-thread block; cf. k_partition of the RRTMG solvers)
+static __global__ void __launch_bounds__(1024) k_partition8(int ncol, const uint8_t *__restrict__ cls, int32_t *__restrict__ perm,
+                                                     int32_t *__restrict__ off)
+{
+    __shared__ int cnt[8][1024];
+    __shared__ int first[9];
+    const int t = threadIdx.x;
+    const int chunk = (ncol + 1023) / 1024;
+    const int b = t * chunk < ncol ? t * chunk : ncol, e = (b + chunk < ncol) ? b + chunk : ncol;
+    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = b; i < e; i++) {
+        const int q = cls[i] & 7;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] += q == k;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) cnt[k][t] = c[k];
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive Hillis-Steele scan of the eight rows
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = t >= d ? cnt[k][t - d] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) cnt[k][t] += v[k];
+        __syncthreads();
+    }
+    if (t == 0) {
+        first[0] = 0;
+        for (int k = 0; k < 8; k++) first[k + 1] = first[k] + cnt[k][1023];
+        for (int k = 0; k <= 8; k++) off[k] = first[k];
+    }
+    __syncthreads();
+    int at[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) at[k] = first[k] + cnt[k][t] - c[k];
+    for (int i = b; i < e; i++) {
+        const int q = cls[i] & 7;
+        int dst = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (q == k) { dst = at[k]; at[k]++; }
+        perm[dst] = i;
+    }
+}
+
+// the aerosol arrays (m, np, nb >= 8) of the last SO_NGATHER of the 8 bands in position order: row r = (array 0..2, band, layer)
+// -> aer[r][position]
+#ifndef SO_NGATHER
+#define SO_NGATHER 3          // the NIR bands 6..8
+#endif
+template <typename R>
+__global__ void __launch_bounds__(256) k_sorad_gather(SoradArgs<R> A)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;                                  // 0 .. 3 * SO_NGATHER * np - 1
+    if (p >= A.m) return;
+    const int rows = SO_NGATHER * A.np, a = r / rows, q = r - a * rows;
+    const R *src = a == 0 ? A.taua : (a == 1 ? A.ssaa : A.asya);
+    A.aer[(size_t)r * A.m + p] = src[((size_t)(8 - SO_NGATHER) * A.np + q) * A.ld + A.perm[p]];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sorad_prep (:271-357, 416-431, 1534-1541); workspace by position, API arrays by column
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_sorad_prep(SoradArgs<R> A)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.m) return;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= A.m) return;
     const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
+    const int i = A.perm[pos];
 #define AP(a, k) a[(size_t)((k) - 1) * ld + i]
-#define LAY(f, k) A.lay[((size_t)(f) * K2 + (k)) * m + i]
+#define LAY(f, k) A.lay[((size_t)(f) * K2 + (k)) * m + pos]
     const R xtoa = AP(A.pl, 1) > (R)1.e-3 ? AP(A.pl, 1) : (R)1.e-3;
     const R scal0 = xtoa * gr_pow<R>((R)0.5 * xtoa / (R)300., (R).8);
     const R o3toa = (R)1.02 * AP(A.oa, 1) * xtoa * (R)466.7 + (R)1.0e-8;
     const R wvtoa = (R)1.02 * AP(A.wa, 1) * scal0 * ((R)1.0 + (R)0.00135 * (AP(A.ta, 1) - (R)240.)) + (R)1.0e-9;
     R sw = wvtoa, cc1 = 0, cc2 = 0, cc3 = 0;
     int ntop = np + 1; bool found = false;
-    A.swh[(size_t)1 * m + i] = sw;
+    A.swh[(size_t)1 * m + pos] = sw;
     for (int k = 1; k <= np; k++) {
         const R dp = AP(A.pl, k + 1) - AP(A.pl, k);
         const R pa = (R)0.5 * (AP(A.pl, k) + AP(A.pl, k + 1));
         const R scal = dp * gr_pow<R>(pa / (R)300., (R).8);
         const R wh = (R)1.02 * AP(A.wa, k) * scal * ((R)1. + (R)0.00135 * (AP(A.ta, k) - (R)240.)) + (R)1.e-9;
         sw = sw + wh;
-        A.swh[(size_t)(k + 1) * m + i] = sw;
+        A.swh[(size_t)(k + 1) * m + pos] = sw;
         LAY(0, k) = dp; LAY(1, k) = wh; LAY(2, k) = (R)1.02 * AP(A.oa, k) * dp * (R)466.7 + (R)1.e-8; LAY(3, k) = scal;
         const R fc = AP(A.fcld, k);
         if (k < A.ict) cc1 = cc1 > fc ? cc1 : fc; else if (k < A.icb) cc2 = cc2 > fc ? cc2 : fc; else cc3 = cc3 > fc ? cc3 : fc;
         if (fc > (R)0.02 && !found) { found = true; ntop = k; }
     }
-    R *cv = A.colv + i;
+    R *cv = A.colv + pos;
     cv[0 * (size_t)m] = cc1; cv[1 * (size_t)m] = cc2; cv[2 * (size_t)m] = cc3; cv[3 * (size_t)m] = wvtoa; cv[4 * (size_t)m] = o3toa;
     cv[5 * (size_t)m] = scal0; cv[6 * (size_t)m] = (R)ntop;
 #undef AP
@@ -124,20 +219,22 @@ __global__ void __launch_bounds__(256) k_sorad_prep(SoradArgs<R> A)
 template <typename R>
 __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int ib = blockIdx.y;
-    if (i >= A.m) return;
+    if (pos >= A.m) return;
+    if (pos < A.cls_off[1]) return;          // class 0: no cloud group holds cloud, no pass reads the cloud planes
+    const int i = A.perm[pos];
     const SoradDev<R> &T = *Tp;
     const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
     const R dm = (R)0.1, dt = (R)0.30103, da = (R)0.1, t1 = (R)-0.9031;
     const R cosz = A.cosz[i];
-    const R cc[4] = {0, A.colv[0 * (size_t)m + i], A.colv[1 * (size_t)m + i], A.colv[2 * (size_t)m + i]};
-#define CLD(f, k) A.cld[(((size_t)ib * 4 + (f)) * K2 + (k)) * m + i]
+    const R cc[4] = {0, A.colv[0 * (size_t)m + pos], A.colv[1 * (size_t)m + pos], A.colv[2 * (size_t)m + pos]};
+#define CLD(f, k) A.cld[(((size_t)ib * 4 + (f)) * K2 + (k)) * m + pos]
 #define CAIB(a, b, c) T.caib[(((c) - 1) * 9 + ((b) - 1)) * 11 + ((a) - 1)]
 #define CAIF(a, b) T.caif[((b) - 1) * 9 + ((a) - 1)]
 #define N2(tab, j) tab[((j) - 1) * 3 + (ib - 1)]
     for (int k = 1; k <= np; k++) {
-        const R dp_pa = A.lay[((size_t)0 * K2 + k) * m + i] * (R)100.;
+        const R dp_pa = A.lay[((size_t)0 * K2 + k) * m + pos] * (R)100.;
         const R wp = (dp_pa * (R)1.0e3) / (R)9.80665;                 // MAPL_GRAV
         const R r1 = A.reff[((size_t)0 * np + (k - 1)) * ld + i], r2 = A.reff[((size_t)1 * np + (k - 1)) * ld + i],
                 r4 = A.reff[((size_t)3 * np + (k - 1)) * ld + i];
@@ -214,58 +311,95 @@ __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const Sorad
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_sorad_pass: one thread per (column, spectral pass).  Scratch planes of the pass (index q, level k):
-//   0..9  : rr, tt, td, rs, ts of the clear (q = 2 f) and cloudy (q = 2 f + 1) portion of layer k (k = 0 above the model top,
-//           np+1 = surface)
-//   10..25: rra, rxa composites from the surface of the sky situations' variants at the level (q = 10 + 2 v, 11 + 2 v; see CLDFLX below)
-//   26..29: fall, fclr, fupa, fupc
+// k_sorad_pass<R, CLS>: one thread per (position, spectral pass); every lane of a block belongs to class CLS (which cloud groups hold
+// cloud: 4 high + 2 middle + 1 low), so the sky situations of non-zero weight - the NS = 2^(groups with cloud) combinations of the groups'
+// clear / cloudy portions - and everything indexed by them is compile-time: register arrays of exactly NS entries, no predication.
+// Scratch planes of the pass (index q, level k; [q][k][position]):
+//   0..9  : rr, tt, td, rs, ts of the clear (q = 2 f) and cloudy (q = 2 f + 1) portion of layer k (cloudy: only in groups with cloud)
+//   10..25: rra, rxa composites from the surface of the distinct VARIANTS at the level (q = 10 + 2 v, 11 + 2 v; see CLDFLX below)
+//   26..29: fall, fclr, fupa, fupc (class 0: fall, fupa only - one sky situation of weight 1, the clear-sky fluxes are the same numbers)
 // ---------------------------------------------------------------------------------------------------
-template <typename R>
+template <typename R> struct SoL5 { R rr, tt, td, rs, ts; };
+
+// one adding step from the surface: layer l above the composite (rra, rxa) (sorad.F90:751-768, 789-806, 825-842)
+template <typename R> GR_DEV void so_add_up(const SoL5<R> &l, R &rra, R &rxa)
+{
+    const R denm = l.ts / ((R)1. - l.rs * rxa);
+    const R nrra = l.rr + (l.td * rra + (l.tt - l.td) * rxa) * denm;
+    rxa = l.rs + l.ts * rxa * denm; rra = nrra;
+}
+// one adding step from the top: layer l below the composite (tda, tta, rsa) (:700-745); LOW: the reference writes the product of this
+// term as tda * rsa * rr above the low group and tda * rr * rsa inside it
+template <typename R, bool LOW> GR_DEV void so_add_down(const SoL5<R> &l, R &tda, R &tta, R &rsa)
+{
+    const R denm = l.ts / ((R)1. - rsa * l.rs);
+    const R ntta = LOW ? tda * l.tt + (tda * l.rr * rsa + tta - tda) * denm : tda * l.tt + (tda * rsa * l.rr + tta - tda) * denm;
+    const R nrsa = l.rs + l.ts * rsa * denm;
+    tda = tda * l.td; tta = ntta; rsa = nrsa;
+}
+
+template <typename R, int CLS>
 __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int pass = blockIdx.y;
-    if (i >= A.m) return;
+    constexpr bool GH = (CLS & 4) != 0, GM = (CLS & 2) != 0, GL = (CLS & 1) != 0;       // groups with cloud
+    constexpr int NH = GH ? 2 : 1, NM = GM ? 2 : 1, NL = GL ? 2 : 1, NS = NH * NM * NL;
+    int bstart, pass;
+    if (!band_block(A.m, SO_NPASS, bstart, pass)) return;
+    const int lo = A.cls_off[CLS], hi = A.cls_off[CLS + 1];
+    if (bstart >= hi || bstart + (int)blockDim.x <= lo) return;                         // no position of this class in the block
+    const int i = bstart + (int)threadIdx.x;                                            // position
+    if (i < lo || i >= hi) return;
     const SoradDev<R> &T = *Tp;
-    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
+    const int np = A.np, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
     const bool uv = pass < 5;
     const int ib = uv ? pass + 1 : (pass - 5) / 10 + 1, ik = uv ? 0 : (pass - 5) % 10 + 1;   // band in its region, k-value
     const int iv = uv ? ib : ib + 5;                                                         // aerosol band 1..8
     const int grp = uv ? 0 : ib;
-    const R cz = A.cosz[i], dsm = (R)0.602;
+    const int col = A.perm[i];
+    const R cz = A.cosz[col], dsm = (R)0.602;
     const R cc1 = A.colv[0 * (size_t)m + i], cc2 = A.colv[1 * (size_t)m + i], cc3 = A.colv[2 * (size_t)m + i];
     const R wvtoa = A.colv[3 * (size_t)m + i], o3toa = A.colv[4 * (size_t)m + i];
     R *S = A.scr + (size_t)pass * SO_NPLANE * K2 * m + i;
+    using L5 = SoL5<R>;
 #define P(q, k) S[((size_t)(q) * K2 + (k)) * m]
 #define LY(f, j, k) P(2 * (f) + (j) - 1, k)              // f: 0 rr 1 tt 2 td 3 rs 4 ts;  j: 1 clear, 2 cloudy
     // The sweeps below are first-order recurrences over the levels: each step loads a layer's five properties and stores the new
     // composites.  gfx9 tracks loads and stores with one in-order counter, so a load issued after a store cannot be consumed before
     // that store is acknowledged: every sweep therefore requests the NEXT level's properties before it stores the current results.
-    struct L5 { R rr, tt, td, rs, ts; };
     auto ld5 = [&](int j, int k) { L5 l; l.rr = LY(0, j, k); l.tt = LY(1, j, k); l.td = LY(2, j, k); l.rs = LY(3, j, k); l.ts = LY(4, j, k); return l; };
-    // boundary "layers": surface (np+1) and the layer above the model top (0)  (:365-387, 914-936)
-    {
-        const R rb = uv ? A.rsuvbm[i] : A.rsirbm[i], rd = uv ? A.rsuvdf[i] : A.rsirdf[i];
-        const R td0 = uv ? gr_exp<R>(-(wvtoa * T.wk_uv[ib - 1] + o3toa * T.zk_uv[ib - 1]) / cz) : gr_exp<R>(-wvtoa * T.xk_ir[ik - 1] / cz);
-        // the cloudy-portion planes (j = 2) of a group are only read when the group has cloud
-        for (int j = 1; j <= 2; j++) {
-            if (j == 1 || cc3 > 0) { LY(0, j, np + 1) = rb; LY(3, j, np + 1) = rd; LY(2, j, np + 1) = 0; LY(1, j, np + 1) = 0; LY(4, j, np + 1) = 0; }
-            if (j == 1 || cc1 > 0) { LY(0, j, 0) = 0; LY(3, j, 0) = 0; LY(1, j, 0) = 1; LY(4, j, 0) = 1; LY(2, j, 0) = td0; }
-        }
-    }
+    // boundary "layers" (:365-387, 914-936): the surface (np + 1: rr = rb, rs = rd, no transmission) and the layer above the model top
+    // (0: no reflection, tt = ts = 1, td = td0) are the same for both portions and stay in registers
+    const R rb = uv ? A.rsuvbm[col] : A.rsirbm[col], rd = uv ? A.rsuvdf[col] : A.rsirdf[col];
+    const R td0 = uv ? gr_exp<R>(-(wvtoa * T.wk_uv[ib - 1] + o3toa * T.zk_uv[ib - 1]) / cz) : gr_exp<R>(-wvtoa * T.xk_ir[ik - 1] / cz);
     // ---- layers: clear and cloudy portion (:436-520, 996-1068) ---------------------------------------------------------
     struct In6 { R dp, wh, oh, ta, sa, as; };
+    // aerosols: the three NIR bands are read by ten passes each - from the position-ordered copies (k_sorad_gather); the five UV / PAR
+    // bands by one pass each - from the caller's arrays, through the permutation
+    const size_t aer_rows = (size_t)SO_NGATHER * np;
+    const bool from_copy = SO_NGATHER == 8 || !uv;
+    const R *a0 = from_copy ? A.aer + ((size_t)(iv - 1 - (8 - SO_NGATHER)) * np) * m + i : A.taua + ((size_t)(iv - 1) * np) * A.ld + col;
+    const R *a1 = from_copy ? a0 + aer_rows * m : A.ssaa + ((size_t)(iv - 1) * np) * A.ld + col;
+    const R *a2 = from_copy ? a1 + aer_rows * m : A.asya + ((size_t)(iv - 1) * np) * A.ld + col;
+    const size_t astr = from_copy ? (size_t)m : (size_t)A.ld;
     auto ldin = [&](int k) {
         In6 v;
         v.dp = A.lay[((size_t)0 * K2 + k) * m + i]; v.wh = A.lay[((size_t)1 * K2 + k) * m + i]; v.oh = A.lay[((size_t)2 * K2 + k) * m + i];
-        const size_t ja = ((size_t)(iv - 1) * np + (k - 1)) * ld + i;
-        v.ta = A.taua[ja]; v.sa = A.ssaa[ja]; v.as = A.asya[ja];
+        const size_t ja = (size_t)(k - 1) * astr;
+        v.ta = a0[ja]; v.sa = a1[ja]; v.as = a2[ja];
         return v;
     };
-    In6 nin = ldin(1);
-    for (int k = 1; k <= np; k++) {
-        const In6 cin = nin;
-        if (k + 1 <= np) nin = ldin(k + 1);      // before this level's stores (see the note on the in-order memory counter below)
+    struct Cl4 { R tcb, tcf, asyc, ssac; };
+    auto ldcl = [&](int k) {
+        Cl4 c;
+        c.tcb = A.cld[(((size_t)grp * 4 + 0) * K2 + k) * m + i]; c.tcf = A.cld[(((size_t)grp * 4 + 1) * K2 + k) * m + i];
+        c.asyc = A.cld[(((size_t)grp * 4 + 2) * K2 + k) * m + i];
+        c.ssac = uv ? (R)1 : A.cld[(((size_t)grp * 4 + 3) * K2 + k) * m + i];
+        return c;
+    };
+    // the cloudy portion only matters in sky situations of non-zero weight, i.e. when the layer's group has cloud (wave-uniform)
+    auto gcld = [&](int k) { return k < ict ? GH : (k < icb ? GM : GL); };
+    // delta-Eddington properties of layer k: clear portion l1, cloudy portion l2 (only when its group has cloud)
+    auto layer = [&](const In6 &cin, const Cl4 &cl, bool cloudy, L5 &l1, L5 &l2) {
         const R dp = cin.dp, wh = cin.wh, oh = cin.oh, ta_ = cin.ta, sa_ = cin.sa, as_ = cin.as;
         R taurs, tausto, ssatau;
         if (uv) {
@@ -280,16 +414,11 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         const R asysto = as_;
         R tautob = tausto, asytob = asysto / ssatau, ssatob = ssatau / tautob + (R)1.0e-8;
         ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
-        R rrt, ttt, tdt, rst, tst, dum;
-        so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
-        so_deledd<R>(tautob, ssatob, asytob, dsm, rst, tst, dum);
-        LY(0, 1, k) = rrt; LY(1, 1, k) = ttt; LY(2, 1, k) = tdt; LY(3, 1, k) = rst; LY(4, 1, k) = tst;
-        // the cloudy portion only matters in sky situations of non-zero weight, i.e. when the layer's group has cloud
-        const R ccg = k < ict ? cc1 : (k < icb ? cc2 : cc3);
-        if (ccg > 0) {
-            const R tcb = A.cld[(((size_t)grp * 4 + 0) * K2 + k) * m + i], tcf = A.cld[(((size_t)grp * 4 + 1) * K2 + k) * m + i],
-                    asyc = A.cld[(((size_t)grp * 4 + 2) * K2 + k) * m + i];
-            const R ssac = uv ? (R)1 : A.cld[(((size_t)grp * 4 + 3) * K2 + k) * m + i];
+        R dum;
+        so_deledd<R>(tautob, ssatob, asytob, cz, l1.rr, l1.tt, l1.td);
+        so_deledd<R>(tautob, ssatob, asytob, dsm, l1.rs, l1.ts, dum);
+        if (cloudy) {
+            const R tcb = cl.tcb, tcf = cl.tcf, asyc = cl.asyc, ssac = cl.ssac;
             tautob = tausto + tcb;
             ssatob = (uv ? (ssatau + tcb) : (ssatau + ssac * tcb)) / tautob + (R)1.0e-8;
             ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
@@ -298,115 +427,158 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
             R ssatof = (uv ? (ssatau + tcf) : (ssatau + ssac * tcf)) / tautof + (R)1.0e-8;
             ssatof = ssatof < (R)0.999999 ? ssatof : (R)0.999999;
             const R asytof = (uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf)) / (ssatof * tautof);
-            so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
-            so_deledd<R>(tautof, ssatof, asytof, dsm, rst, tst, dum);
-            LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
+            so_deledd<R>(tautob, ssatob, asytob, cz, l2.rr, l2.tt, l2.td);
+            so_deledd<R>(tautof, ssatof, asytof, dsm, l2.rs, l2.ts, dum);
         }
-    }
+    };
+    auto st5 = [&](int j, int k, const L5 &l) { LY(0, j, k) = l.rr; LY(1, j, k) = l.tt; LY(2, j, k) = l.td; LY(3, j, k) = l.rs; LY(4, j, k) = l.ts; };
 
     // ---- CLDFLX (:689-872) ---------------------------------------------------------------------------------------------
-    // The reference builds the composites piecewise (from the top through the high group per ih, on through the middle group per
-    // (ih, im), ...) and re-walks the low / high groups for every sky situation.  Here every sky situation of non-zero weight
-    // s = (ih, im, is) is ONE chain each way over all levels - the same operations on the same values in the same order (the same
-    // results up to the compiler's choice of fused multiply-adds: 3e-16 / 4e-7 of the insolation against the first version) - and the
-    // level is the outer loop:
-    //   sweep U (surface -> top): the composites from the surface (rra, rxa) of all situations, parked per level.  Situations that
-    //     share the portions below a level share the values: 2 variants in the low group, 4 in the middle, 8 in the high group are
-    //     stored (planes 10 + 2 v, 11 + 2 v).
-    //   sweep D (top -> surface): the composites from the top (tda, tta, rsa) stay in registers; at every level the fluxes of all
-    //     situations are formed and summed in the reference's order (ih, im, is); the four flux planes are written once.
-    // Per level and pass: 10 + 4..16 loads and 4..16 stores in U, 10 + 4..16 loads and 4 stores in D - the first version, which walked
-    // situation by situation, read ~80 and wrote ~48 values per level (profiles/r01_v7_chou_pmc_traffic.md: 138 x the algorithmic bytes).
-    // (Computing the layers inside sweep U, which would save their read-back there, is slower: 21.4 instead of 19.4 ms per 100 000
-    // columns, with 214 VGPRs as well as - one portion at a time, scheduling barriers between the deledd calls - with 115.)
-    const int nh = cc1 > 0 ? 2 : 1, nm = cc2 > 0 ? 2 : 1, ns = cc3 > 0 ? 2 : 1;       // portions of non-zero weight
-    // situation s = 4 (ih-1) + 2 (im-1) + (is-1); the portion it uses in layer k; the variant of its surface-side composites at level k
-    auto portion = [&](int s, int k) { return 1 + (k < ict ? (s >> 2) : (k < icb ? ((s >> 1) & 1) : (s & 1))); };
-    auto variant = [&](int s, int k) { return k < ict ? s : (k < icb ? (s & 3) : (s & 1)); };
-    uint32_t act = 0;
-    for (int ih = 1; ih <= nh; ih++) for (int im = 1; im <= nm; im++) for (int is = 1; is <= ns; is++) act |= 1u << (4 * (ih - 1) + 2 * (im - 1) + (is - 1));
+    // A sky situation (ih, im, is) takes the clear (1) or cloudy (2) portion of every layer of the high / middle / low group.  The
+    // reference builds the composites piecewise per group and combines them per situation; here each DISTINCT composite is one chain:
+    //   sweep U (surface -> top): composites from the surface (rra, rxa).  Inside the low group they depend on `is` only (NL chains), in
+    //     the middle group on (im, is) (NM NL chains), in the high group on all three (NS chains); a chain forks where the next group
+    //     begins.  Parked per level and variant v (planes 10 + 2 v, 11 + 2 v).
+    //   sweep D (top -> surface): composites from the top (tda, tta, rsa) in registers: NH chains in the high group, NH NM in the middle,
+    //     NS in the low group; at every level the fluxes of all NS situations are formed from (top chain, parked variant) and summed in
+    //     the reference's order (ih outermost, is innermost); the flux planes are written once.
+    // The operations on a chain are the reference's, in its order (the same results up to the compiler's choice of fused multiply-adds).
+    // Index of situation (ihx, imx, isx), each 0 = clear / 1 = cloudy: t = (ihx NM + imx) NL + isx.
 #define RRAV(k, v) P(10 + 2 * (v), k)
 #define RXAV(k, v) P(11 + 2 * (v), k)
     // ---- sweep U ----
     {
-        R rra[8], rxa[8];
+        R rra[NS], rxa[NS];
 #pragma unroll
-        for (int s = 0; s < 8; s++) { rra[s] = 0; rxa[s] = 0; }
-#pragma unroll
-        for (int s = 0; s < 8; s++)
-            if ((act >> s) & 1u) { rra[s] = LY(0, 1 + (s & 1), np + 1); rxa[s] = LY(3, 1 + (s & 1), np + 1); }
-#pragma unroll
-        for (int v = 0; v < 2; v++)
-            if ((act >> v) & 1u) { RRAV(np + 1, v) = rra[v]; RXAV(np + 1, v) = rxa[v]; }
-        L5 n1 = ld5(1, np), n2 = ld5(2, np);
-        for (int k = np; k >= 1; k--) {
-            const L5 l1 = n1, l2 = n2;
-            if (k - 1 >= 1) { n1 = ld5(1, k - 1); n2 = ld5(2, k - 1); }      // (before this level's stores: in-order memory counter)
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                if (!((act >> s) & 1u)) continue;
-                const L5 &l = portion(s, k) == 1 ? l1 : l2;
-                const R denm = l.ts / ((R)1. - l.rs * rxa[s]);
-                const R nrra = l.rr + (l.td * rra[s] + (l.tt - l.td) * rxa[s]) * denm;
-                rxa[s] = l.rs + l.ts * rxa[s] * denm; rra[s] = nrra;
-            }
-            const int nv = k < ict ? 8 : (k < icb ? 4 : 2);
-#pragma unroll
-            for (int v = 0; v < 8; v++)
-                if (v < nv && ((act >> v) & 1u)) { RRAV(k, v) = rra[v]; RXAV(k, v) = rxa[v]; }
+        for (int v = 0; v < NL; v++) { rra[v] = rb; rxa[v] = rd; RRAV(np + 1, v) = rb; RXAV(np + 1, v) = rd; }
+        // the layers' properties are formed here, on the way up (each layer's inputs requested a level ahead), and parked for sweep D
+        In6 nin = ldin(np);
+        Cl4 ncl{};
+        if (gcld(np)) ncl = ldcl(np);
+        L5 l1, l2;
+#define SO_NEXT_LAYER(k)                                                                                 \
+        {                                                                                                \
+            const In6 cin = nin; const Cl4 ccl = ncl;                                                    \
+            if ((k) - 1 >= 1) { nin = ldin((k) - 1); if (gcld((k) - 1)) ncl = ldcl((k) - 1); }           \
+            layer(cin, ccl, gcld(k), l1, l2);                                                            \
+            st5(1, k, l1);                                                                               \
+            if (gcld(k)) st5(2, k, l2);                                                                  \
         }
+        // low group: layers np .. icb, NL chains
+        int k = np;
+        for (; k >= icb; k--) {
+            SO_NEXT_LAYER(k)
+#pragma unroll
+            for (int v = 0; v < NL; v++) so_add_up<R>(v ? l2 : l1, rra[v], rxa[v]);
+#pragma unroll
+            for (int v = 0; v < NL; v++) { RRAV(k, v) = rra[v]; RXAV(k, v) = rxa[v]; }
+        }
+        // fork: (imx, isx) <- isx
+        if constexpr (GM) {
+#pragma unroll
+            for (int v = 0; v < NL; v++) { rra[NL + v] = rra[v]; rxa[NL + v] = rxa[v]; }
+        }
+        for (; k >= ict; k--) {
+            SO_NEXT_LAYER(k)
+#pragma unroll
+            for (int v = 0; v < NM * NL; v++) so_add_up<R>(v / NL ? l2 : l1, rra[v], rxa[v]);
+#pragma unroll
+            for (int v = 0; v < NM * NL; v++) { RRAV(k, v) = rra[v]; RXAV(k, v) = rxa[v]; }
+        }
+        if constexpr (GH) {
+#pragma unroll
+            for (int v = 0; v < NM * NL; v++) { rra[NM * NL + v] = rra[v]; rxa[NM * NL + v] = rxa[v]; }
+        }
+        for (; k >= 1; k--) {
+            SO_NEXT_LAYER(k)
+#pragma unroll
+            for (int v = 0; v < NS; v++) so_add_up<R>(v / (NM * NL) ? l2 : l1, rra[v], rxa[v]);
+#pragma unroll
+            for (int v = 0; v < NS; v++) { RRAV(k, v) = rra[v]; RXAV(k, v) = rxa[v]; }
+        }
+#undef SO_NEXT_LAYER
     }
     // ---- sweep D ----
+    // weights of the situations (:706-712, 778-781, 816-818)
+    R ct[NS];
+#pragma unroll
+    for (int t = 0; t < NS; t++) {
+        const int ihx = t / (NM * NL), imx = (t / NL) % NM, isx = t % NL;
+        const R ch = ihx ? cc1 : (R)1.0 - cc1;
+        const R cm = imx ? ch * cc2 : ch * ((R)1.0 - cc2);
+        ct[t] = isx ? cm * cc3 : cm * ((R)1.0 - cc3);
+    }
     R fsdir = 0, fsdif = 0, fall_sfc = 0;
     {
-        R tda[8], tta[8], rsa[8];
+        R tda[NS], tta[NS], rsa[NS];
 #pragma unroll
-        for (int s = 0; s < 8; s++) { tda[s] = 0; tta[s] = 0; rsa[s] = 0; }
-#pragma unroll
-        for (int s = 0; s < 8; s++)
-            if ((act >> s) & 1u) { const int j = 1 + (s >> 2); tda[s] = LY(2, j, 0); tta[s] = LY(1, j, 0); rsa[s] = LY(3, j, 0); }
-        for (int k = 1; k <= np + 1; k++) {
-            // everything this level needs is requested before anything is stored
-            L5 l1{}, l2{};
-            if (k <= np) { l1 = ld5(1, k); l2 = ld5(2, k); }
-            const int nv = k < ict ? 8 : (k < icb ? 4 : 2);
-            R bra[8], bxa[8];
-#pragma unroll
-            for (int v = 0; v < 8; v++) { bra[v] = 0; bxa[v] = 0; if (v < nv && ((act >> v) & 1u)) { bra[v] = RRAV(k, v); bxa[v] = RXAV(k, v); } }
+        for (int v = 0; v < NH; v++) { tda[v] = td0; tta[v] = 1; rsa[v] = 0; }
+        // fluxes of level k: the top chain of situation t is TOP(t), its surface-side variant BOT(t) - both depend on the group of k
+        auto level = [&](int k, auto grp_c, const R *bra, const R *bxa) {
+            constexpr int G = decltype(grp_c)::value;                  // 0 high, 1 middle, 2 low group (and the surface)
             R fall = 0, fclr = 0, fupa = 0, fupc = 0;
 #pragma unroll
-            for (int s = 0; s < 8; s++) {      // the reference's order: ih outermost, is innermost
-                if (!((act >> s) & 1u)) continue;
-                const R ch = (s >> 2) ? cc1 : (R)1.0 - cc1;
-                const R cm = ((s >> 1) & 1) ? ch * cc2 : ch * ((R)1.0 - cc2);
-                const R ct = (s & 1) ? cm * cc3 : cm * ((R)1.0 - cc3);
-                const int v = variant(s, k);
-                const R rra = bra[v], rxa = bxa[v];
-                const R denm = (R)1. / ((R)1. - rsa[s] * rxa);
-                const R fdndir = tda[s];
-                const R xx4 = tda[s] * rra, yy = tta[s] - tda[s];
-                const R fdndif = (xx4 * rsa[s] + yy) * denm;
-                const R fupdif = (xx4 + yy * rxa) * denm;
+            for (int t = 0; t < NS; t++) {
+                const int top = G == 0 ? t / (NM * NL) : (G == 1 ? t / NL : t);
+                const int bot = G == 0 ? t : (G == 1 ? t % (NM * NL) : t % NL);
+                const R a_ = bra[bot], x_ = bxa[bot];
+                const R denm = (R)1. / ((R)1. - rsa[top] * x_);
+                const R fdndir = tda[top];
+                const R xx4 = tda[top] * a_, yy = tta[top] - tda[top];
+                const R fdndif = (xx4 * rsa[top] + yy) * denm;
+                const R fupdif = (xx4 + yy * x_) * denm;
                 const R flxdn = fdndir + fdndif - fupdif;
                 // the first sky situation (all-clear portions) starts the weighted sums: 0 + x * ct, as the reference's zeroed arrays give
-                if (s == 0) { fupc = fupdif; fclr = flxdn; fupa = (R)0 + fupdif * ct; fall = (R)0 + flxdn * ct; }
-                else { fupa = fupa + fupdif * ct; fall = fall + flxdn * ct; }
-                if (k == np + 1) { fsdir = fsdir + fdndir * ct; fsdif = fsdif + fdndif * ct; }
+                if (t == 0) { fupc = fupdif; fclr = flxdn; fupa = (R)0 + fupdif * ct[0]; fall = (R)0 + flxdn * ct[0]; }
+                else { fupa = fupa + fupdif * ct[t]; fall = fall + flxdn * ct[t]; }
+                if (k == np + 1) { fsdir = fsdir + fdndir * ct[t]; fsdif = fsdif + fdndif * ct[t]; }
             }
-            P(26, k) = fall; P(27, k) = fclr; P(28, k) = fupa; P(29, k) = fupc;
+            P(26, k) = fall; P(28, k) = fupa;
+            if constexpr (CLS != 0) { P(27, k) = fclr; P(29, k) = fupc; }
             if (k == np + 1) fall_sfc = fall;
+        };
+        using G0 = std::integral_constant<int, 0>; using G1 = std::integral_constant<int, 1>; using G2 = std::integral_constant<int, 2>;
+        int k = 1;
+        for (; k < ict; k++) {                     // high group: NH chains, NS variants below
+            const L5 l1 = ld5(1, k); L5 l2 = l1;   // everything this level needs is requested before anything is stored
+            if constexpr (GH) l2 = ld5(2, k);
+            R bra[NS], bxa[NS];
+#pragma unroll
+            for (int v = 0; v < NS; v++) { bra[v] = RRAV(k, v); bxa[v] = RXAV(k, v); }
+            level(k, G0{}, bra, bxa);
+#pragma unroll
+            for (int v = 0; v < NH; v++) so_add_down<R, false>(v ? l2 : l1, tda[v], tta[v], rsa[v]);
+        }
+        if constexpr (GM) {                        // fork: (ihx, imx) <- ihx
+#pragma unroll
+            for (int v = NH - 1; v >= 0; v--) { tda[v * NM + 1] = tda[v]; tta[v * NM + 1] = tta[v]; rsa[v * NM + 1] = rsa[v];
+                                               tda[v * NM] = tda[v]; tta[v * NM] = tta[v]; rsa[v * NM] = rsa[v]; }
+        }
+        for (; k < icb; k++) {                     // middle group: NH NM chains, NM NL variants below
+            const L5 l1 = ld5(1, k); L5 l2 = l1;
+            if constexpr (GM) l2 = ld5(2, k);
+            R bra[NM * NL], bxa[NM * NL];
+#pragma unroll
+            for (int v = 0; v < NM * NL; v++) { bra[v] = RRAV(k, v); bxa[v] = RXAV(k, v); }
+            level(k, G1{}, bra, bxa);
+#pragma unroll
+            for (int v = 0; v < NH * NM; v++) so_add_down<R, false>(v % NM ? l2 : l1, tda[v], tta[v], rsa[v]);
+        }
+        if constexpr (GL) {                        // fork: t <- (ihx, imx)
+#pragma unroll
+            for (int v = NH * NM - 1; v >= 0; v--) { tda[v * NL + 1] = tda[v]; tta[v * NL + 1] = tta[v]; rsa[v * NL + 1] = rsa[v];
+                                                    tda[v * NL] = tda[v]; tta[v * NL] = tta[v]; rsa[v * NL] = rsa[v]; }
+        }
+        for (; k <= np + 1; k++) {                 // low group and the surface: NS chains, NL variants below
+            L5 l1{}, l2{};
+            if (k <= np) { l1 = ld5(1, k); l2 = l1; if constexpr (GL) l2 = ld5(2, k); }
+            R bra[NL], bxa[NL];
+#pragma unroll
+            for (int v = 0; v < NL; v++) { bra[v] = RRAV(k, v); bxa[v] = RXAV(k, v); }
+            level(k, G2{}, bra, bxa);
             if (k <= np) {
 #pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    if (!((act >> s) & 1u)) continue;
-                    const L5 &l = portion(s, k) == 1 ? l1 : l2;
-                    const R denm = l.ts / ((R)1. - rsa[s] * l.rs);
-                    // (the reference writes the product in this term as tda * rsa * rr above the low group and tda * rr * rsa inside it)
-                    const R ntta = k < icb ? tda[s] * l.tt + (tda[s] * rsa[s] * l.rr + tta[s] - tda[s]) * denm
-                                           : tda[s] * l.tt + (tda[s] * l.rr * rsa[s] + tta[s] - tda[s]) * denm;
-                    const R nrsa = l.rs + l.ts * rsa[s] * denm;
-                    tda[s] = tda[s] * l.td; tta[s] = ntta; rsa[s] = nrsa;
-                }
+                for (int v = 0; v < NS; v++) so_add_down<R, true>(v % NL ? l2 : l1, tda[v], tta[v], rsa[v]);
             }
         }
     }
@@ -420,24 +592,26 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_sorad_sum: per (column, level) -- flux integration over the 35 passes in pass order (Eq. 6.1)
+// k_sorad_sum: per (position, level) -- flux integration over the 35 passes in pass order (Eq. 6.1)
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_sorad_sum(SoradArgs<R> A, SoradOut<R> O)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y + 1;
     if (i >= A.m) return;
-    const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
+    const int ld = A.ld, m = A.m, K2 = A.np + 2;
+    const bool one = i < A.cls_off[1];         // class 0: one sky situation of weight 1 - total-sky = clear-sky, two planes written
     R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll 5
     for (int p = 0; p < SO_NPASS; p++) {
         const R hk = A.hk[p];
         const R *q = A.scr + (((size_t)p * SO_NPLANE + 26) * K2 + k) * m + i;
-        s0 = s0 + q[0] * hk; s1 = s1 + q[(size_t)K2 * m] * hk; s2 = s2 + q[(size_t)2 * K2 * m] * hk; s3 = s3 + q[(size_t)3 * K2 * m] * hk;
+        const R f0 = q[0], f2 = q[(size_t)2 * K2 * m];
+        const R f1 = one ? f0 : q[(size_t)K2 * m], f3 = one ? f2 : q[(size_t)3 * K2 * m];
+        s0 = s0 + f0 * hk; s1 = s1 + f1 * hk; s2 = s2 + f2 * hk; s3 = s3 + f3 * hk;
     }
-    const size_t o = (size_t)(k - 1) * ld + i;
+    const size_t o = (size_t)(k - 1) * ld + A.perm[i];
     O.flx[o] = s0; O.flc[o] = s1; O.flxu[o] = s2; O.flcu[o] = s3;
-    (void)np;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -652,8 +826,9 @@ __global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDe
 template <typename R>
 __global__ void __launch_bounds__(256) k_sorad_reduce(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp, SoradOut<R> O)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.m) return;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= A.m) return;
+    const int i = A.perm[pos];                  // API arrays by column, workspace by position
     const SoradDev<R> &T = *Tp;
     const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2;
 #define OUT2(a, k) a[(size_t)((k) - 1) * ld + i]
@@ -662,29 +837,29 @@ __global__ void __launch_bounds__(256) k_sorad_reduce(SoradArgs<R> A, const Sora
     R fdiruv = 0, fdifuv = 0, fdirpar = 0, fdifpar = 0, fdirir = 0, fdifir = 0, band[8], drb[8], dfb[8];
     for (int b = 0; b < 8; b++) { band[b] = 0; drb[b] = 0; dfb[b] = 0; }
     for (int p = 0; p < SO_NPASS; p++) {
-        const R hk = A.hk[p], fs = A.psum[((size_t)p * 3 + 0) * m + i], fd = A.psum[((size_t)p * 3 + 1) * m + i];
+        const R hk = A.hk[p], fs = A.psum[((size_t)p * 3 + 0) * m + pos], fd = A.psum[((size_t)p * 3 + 1) * m + pos];
         const int b = p < 5 ? p : 5 + (p - 5) / 10;
-        band[b] = band[b] + A.psum[((size_t)p * 3 + 2) * m + i] * hk; drb[b] = drb[b] + fs * hk; dfb[b] = dfb[b] + fd * hk;
+        band[b] = band[b] + A.psum[((size_t)p * 3 + 2) * m + pos] * hk; drb[b] = drb[b] + fs * hk; dfb[b] = dfb[b] + fd * hk;
         if (p < 4) { fdiruv = fdiruv + fs * hk; fdifuv = fdifuv + fd * hk; }
         else if (p == 4) { fdirpar = fs * hk; fdifpar = fd * hk; }
         else { fdirir = fdirir + fs * hk; fdifir = fdifir + fd * hk; }
     }
     // flux reductions: running column amounts, two table look-ups per level
     const R snt = (R)1.0 / A.cosz[i];
-    const R scal0 = A.colv[5 * (size_t)m + i];
-    const int ntop = (int)A.colv[6 * (size_t)m + i];
+    const R scal0 = A.colv[5 * (size_t)m + pos];
+    const int ntop = (int)A.colv[6 * (size_t)m + pos];
     const R cnt = (R)165.22 * snt;
     R so2o = scal0 * cnt, so2c = ((R)789. * A.co2) * scal0;
     const R flx_top = OUT2(O.flx, ntop);
     R dftop = 0, dfsfc = 0;
     for (int k = 1; k <= np + 1; k++) {
-        if (k > 1) { const R sc = A.lay[((size_t)3 * K2 + (k - 1)) * m + i]; so2o = so2o + sc * cnt; so2c = so2c + ((R)789. * A.co2) * sc; }
+        if (k > 1) { const R sc = A.lay[((size_t)3 * K2 + (k - 1)) * m + pos]; so2o = so2o + sc * cnt; so2c = so2c + ((R)789. * A.co2) * sc; }
         R df = (R)0.0633 * ((R)1. - gr_exp<R>((R)-0.000155 * sqrt(so2o)));
         {
             const R u1 = (R)-3.0, du = (R)0.15, w1 = (R)-4.0, dw = (R)0.15;
             const R x0 = u1 + (R)43 * du, y0 = w1 + (R)37 * dw, x1 = u1 - (R)0.5 * du, y1 = w1 - (R)0.5 * dw;
             R ulog = gr_log10<R>(so2c * snt); ulog = ulog < x0 ? ulog : x0;
-            R wlog = gr_log10<R>(A.swh[(size_t)k * m + i] * snt); wlog = wlog < y0 ? wlog : y0;
+            R wlog = gr_log10<R>(A.swh[(size_t)k * m + pos] * snt); wlog = wlog < y0 ? wlog : y0;
             int ic = (int)((ulog - x1) / du + (R)1.), iw = (int)((wlog - y1) / dw + (R)1.);
             ic = ic > 2 ? ic : 2; iw = iw > 2 ? iw : 2; ic = ic < 43 ? ic : 43; iw = iw < 37 ? iw : 37;
             const R dc = ulog - (R)(ic - 2) * du - u1, dd = wlog - (R)(iw - 2) * dw - w1;
