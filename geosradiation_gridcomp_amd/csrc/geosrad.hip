@@ -11,6 +11,9 @@
 #include <tuple>
 #include <vector>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
 #include <atomic>
 #include <functional>
 #include <chrono>
@@ -231,6 +234,75 @@ static const char *LW_NEG_NAMES[21] = {"play", "tlay", "h2ovmr", "o3vmr", "co2vm
 
 }  // namespace
 
+// The copy threads of the host-pointer entry points: created once per context (first chunk that is worth splitting) and parked on a
+// condition variable between chunks - a chunk's gather / scatter is a few milliseconds, a std::thread spawn + join per chunk and
+// direction was a measurable part of it
+class CopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(size_t, size_t)> *job = nullptr;
+    size_t nitems = 0, per = 0;
+    int pending = 0;
+    unsigned long gen = 0;
+    bool quit = false;
+    void loop(int t)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(size_t, size_t)> *f; size_t lo, hi;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen; f = job;
+                lo = (size_t)t * per; hi = lo + per < nitems ? lo + per : nitems;
+            }
+            if (lo < hi) (*f)(lo, hi);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+public:
+    explicit CopyPool(int n) { for (int t = 0; t < n; t++) th.emplace_back([this, t] { loop(t); }); }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+    int size() const { return (int)th.size(); }
+    // fn(lo, hi) over [0, n) cut into size() contiguous pieces; returns when all pieces are done
+    void run(size_t n, const std::function<void(size_t, size_t)> &fn)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = &fn; nitems = n; per = (n + th.size() - 1) / th.size(); pending = (int)th.size(); gen++;
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+// copy threads per context when GEOSRAD_HOST_THREADS is not set: the host's hardware threads shared out among the ranks of the node (the
+// launchers' node-local size; 96 ranks x 8 copy threads would oversubscribe a host), at most 8, at least 1
+static int default_host_threads()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 8;
+    long ranks = 1;
+    static const char *vars[] = {"OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "PMI_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"};
+    for (const char *v : vars) {
+        const char *e = getenv(v);
+        if (!e || !*e) continue;
+        char *end = nullptr;
+        const long r = strtol(e, &end, 10);
+        if (end != e && r >= 1) { ranks = r; break; }
+    }
+    long n = (long)hw / ranks;
+    return (int)(n < 1 ? 1 : (n > 8 ? 8 : n));
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct geosrad_ctx {
     int device = 0, real_kind = 4, chunk = 131072;
@@ -286,7 +358,8 @@ struct geosrad_ctx {
     // the solver runs on it, one DMA brings the outputs back and the threads scatter them - on three streams and two slots, so that
     // the gathering of chunk k+1, the transfers and the kernels of chunk k and the scattering of chunk k-1 overlap.
     struct PipeArr { const void *src; void *dst; size_t rows, ebytes; size_t off; };      // src: copied in; dst: copied back (either may be null)
-    int host_chunk = 16384, host_chunk_default = 16384, host_threads = 8;
+    int host_chunk = 16384, host_chunk_default = 16384, host_threads = default_host_threads();
+    std::unique_ptr<CopyPool> copy_pool;
     size_t host_ld = 0;             // leading dimension (columns) of the caller's arrays when the call covers a shard of them (multi-device context); 0: ncol
     bool host_nt = true;            // non-temporal stores into the staging slots (GEOSRAD_HOST_NT=0: plain memcpy)
     // three staging slots, results copied back to the caller two chunks behind the one being gathered: the host thread then never waits
@@ -350,13 +423,9 @@ struct geosrad_ctx {
         for (auto &it : items) bytes += (size_t)nc * it.a->ebytes;
         const int nt = bytes < ((size_t)4 << 20) ? 1 : host_threads;
         if (nt <= 1) { work(0, items.size()); return; }
-        std::vector<std::thread> th;
-        const size_t per = (items.size() + nt - 1) / nt;
-        for (int t = 0; t < nt; t++) {
-            const size_t lo = t * per, hi = lo + per < items.size() ? lo + per : items.size();
-            if (lo < hi) th.emplace_back(work, lo, hi);
-        }
-        for (auto &t : th) t.join();
+        if (!copy_pool || copy_pool->size() != nt) copy_pool.reset(new CopyPool(nt));
+        const std::function<void(size_t, size_t)> fn = work;
+        copy_pool->run(items.size(), fn);
     }
     // arrs must be ordered: copied in only, copied both ways, copied back only.  run(stream, nc, c0, device base of the slot) enqueues
     // the solver for one chunk whose arrays lie at dev + a.off, dense with leading dimension nc (slots are sized for
@@ -369,15 +438,22 @@ struct geosrad_ctx {
     {
         const int cn = ncol < host_chunk ? ncol : host_chunk;
         const int ld_host = host_ld ? (int)host_ld : ncol;
-        size_t off = 0, in_end = 0, out_begin = (size_t)-1;
-        for (auto &a : arrs) {
-            a.off = off;
-            if (a.dst && out_begin == (size_t)-1) out_begin = off;
-            off += (a.rows * (size_t)cn * a.ebytes + 255) & ~(size_t)255;
-            if (a.src) in_end = off;
-        }
-        if (out_begin == (size_t)-1) out_begin = off;
-        const size_t total = off, in_bytes = in_end, out_bytes = total - out_begin;
+        // a chunk's arrays lie dense in its slot (leading dimension = the chunk's columns): the offsets are those of the chunk's own size, so
+        // that a small chunk moves only its own bytes
+        size_t in_end = 0, out_begin = 0, total = 0;
+        auto layout = [&](int nc_) {
+            size_t off = 0; in_end = 0; out_begin = (size_t)-1;
+            for (auto &a : arrs) {
+                a.off = off;
+                if (a.dst && out_begin == (size_t)-1) out_begin = off;
+                off += (a.rows * (size_t)nc_ * a.ebytes + 255) & ~(size_t)255;
+                if (a.src) in_end = off;
+            }
+            if (out_begin == (size_t)-1) out_begin = off;
+            total = off;
+        };
+        layout(cn);
+        const size_t total_max = total, in_bytes_max = in_end, out_bytes_max = total - out_begin;
 #define PIPECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(GEOSRAD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
         if (!pipe_h2d) {
             PIPECHK(hipStreamCreateWithFlags(&pipe_h2d, hipStreamNonBlocking));
@@ -385,10 +461,11 @@ struct geosrad_ctx {
             for (int s = 0; s < PIPE_SLOTS; s++) for (int e = 0; e < 3; e++) PIPECHK(hipEventCreateWithFlags(&pipe_ev[s][e], hipEventDisableTiming));
             PIPECHK(hipHostMalloc((void **)&pipe_err, PIPE_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
         }
-        if (total > pipe_dev_bytes || in_bytes > pipe_pin_bytes[0] || out_bytes > pipe_pin_bytes[1]) {
+        if (total_max > pipe_dev_bytes || in_bytes_max > pipe_pin_bytes[0] || out_bytes_max > pipe_pin_bytes[1]) {
             PIPECHK(hipDeviceSynchronize());
-            const size_t want_dev = total > pipe_dev_bytes ? total : pipe_dev_bytes;
-            const size_t want_pin[2] = {in_bytes > pipe_pin_bytes[0] ? in_bytes : pipe_pin_bytes[0], out_bytes > pipe_pin_bytes[1] ? out_bytes : pipe_pin_bytes[1]};
+            const size_t want_dev = total_max > pipe_dev_bytes ? total_max : pipe_dev_bytes;
+            const size_t want_pin[2] = {in_bytes_max > pipe_pin_bytes[0] ? in_bytes_max : pipe_pin_bytes[0],
+                                        out_bytes_max > pipe_pin_bytes[1] ? out_bytes_max : pipe_pin_bytes[1]};
             pipe_dev_bytes = pipe_pin_bytes[0] = pipe_pin_bytes[1] = 0;      // a failure below leaves "nothing allocated", not stale sizes
             for (int s = 0; s < PIPE_SLOTS; s++) {
                 if (pipe_dev[s]) { (void)hipFree(pipe_dev[s]); pipe_dev[s] = nullptr; }
@@ -406,17 +483,25 @@ struct geosrad_ctx {
         }
         for (int s = 0; s < PIPE_SLOTS; s++) pipe_err[s] = 0;
         bool input_error = false;
-        const int nchunks = (ncol + cn - 1) / cn;
+        // chunk boundaries.  (Small first chunks that double up to cn - so that the first transfer starts before 171 / 265 MB have been
+        // gathered - were measured: 58.3 against 56.7 ms per RRTMG_LW + RRTMG_SW call pair of 97 200 columns; the call is bound by the
+        // H2D transfer itself, 2.59 GB at the box's 57.5 GB/s = 45 ms, profiles/r04_host_api.md.)
+        std::vector<int> cstart;
+        for (int c = 0; c < ncol; c += cn) cstart.push_back(c);
+        cstart.push_back(ncol);
+        const int nchunks = (int)cstart.size() - 1;
         const bool trace = getenv("GEOSRAD_HOST_TRACE") != nullptr;
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double t_g = 0, t_s = 0, t_w = 0, t_e = 0;
         const double t_begin = now();
         for (int k = 0; k < nchunks + PIPE_LAG; k++) {
             if (k < nchunks) {
-                const int s = k % PIPE_SLOTS, c0 = k * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
+                const int s = k % PIPE_SLOTS, c0 = cstart[k], nc = cstart[k + 1] - c0;
                 double t0 = now();
                 if (k >= PIPE_SLOTS) PIPECHK(hipEventSynchronize(pipe_ev[s][0]));   // the slot's previous transfer has left the staging memory
                 double t1 = now(); t_w += t1 - t0;
+                layout(nc);
+                const size_t in_bytes = in_end, out_bytes = total - out_begin;
                 pipe_copy(arrs, pipe_pin[s][0], 0, ld_host, c0, nc, true);
                 t0 = now(); t_g += t0 - t1;
                 if (k >= PIPE_SLOTS) PIPECHK(hipStreamWaitEvent(pipe_h2d, pipe_ev[s][2], 0));   // ... and its previous chunk has been copied out of the device slot
@@ -433,11 +518,12 @@ struct geosrad_ctx {
                 t_e += now() - t0;
             }
             if (k >= PIPE_LAG && k - PIPE_LAG < nchunks) {
-                const int j = k - PIPE_LAG, s = j % PIPE_SLOTS, c0 = j * cn, nc = (ncol - c0) < cn ? (ncol - c0) : cn;
+                const int j = k - PIPE_LAG, s = j % PIPE_SLOTS, c0 = cstart[j], nc = cstart[j + 1] - c0;
                 double t0 = now();
                 PIPECHK(hipEventSynchronize(pipe_ev[s][2]));
                 double t1 = now(); t_w += t1 - t0;
                 if (err_dev && pipe_err[s]) { input_error = true; break; }      // this chunk (or one enqueued behind it) tripped an input assertion
+                layout(nc);
                 pipe_copy(arrs, pipe_pin[s][1], out_begin, ld_host, c0, nc, false);
                 t_s += now() - t1;
             }
@@ -445,7 +531,7 @@ struct geosrad_ctx {
         if (input_error) { PIPECHK(hipDeviceSynchronize()); return PIPE_FLAGGED; }
         if (trace)
             fprintf(stderr, "geosrad host pipeline: %d columns, %d chunks of %d, %.1f MB in / %.1f MB out per chunk: total %.1f ms = gather %.1f + "
-                            "scatter %.1f + enqueue %.1f + waiting for the GPU %.1f\n", ncol, nchunks, cn, in_bytes / 1e6, out_bytes / 1e6,
+                            "scatter %.1f + enqueue %.1f + waiting for the GPU %.1f\n", ncol, nchunks, cn, in_bytes_max / 1e6, out_bytes_max / 1e6,
                     now() - t_begin, t_g, t_s, t_e, t_w);
 #undef PIPECHK
         return GEOSRAD_OK;
@@ -1749,8 +1835,11 @@ template <typename R> struct Ctx : geosrad_ctx {
         // (the stage-dump instantiation is always k_sw_bands: sw_planes(true))
         const size_t nplanes = (size_t)planes;
         p = take(nplanes * NG_SW * nlay * (((size_t)nc + 255) & ~(size_t)255) * sizeof(R)); if (w) w->cell = (R *)p;
-        p = take((size_t)4 * SWR_SLOTS_MAX * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;      // per band (14) or per quad (32 slots)
-        p = take((size_t)3 * SWR_SLOTS_MAX * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
+        // partial fluxes per slot: the units of k_sw_reform's mapping (23 fp32 / 32 fp64), which also cover the 14 bands of k_sw_bands (the
+        // stage-dump hook always runs that kernel); 14 when GEOSRAD_SW_PATH=bands
+        const size_t slots = sw_path == 2 ? (size_t)(sw_reform_nslot<R>() > NB_SW ? sw_reform_nslot<R>() : NB_SW) : (size_t)NB_SW;
+        p = take((size_t)4 * slots * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
+        p = take((size_t)3 * slots * nc * sizeof(R)); if (w) w->bsfc = (R *)p;
         p = take((size_t)8 * 6 * nc * sizeof(R)); if (w) w->cot = (R *)p;
         return off;
     }

@@ -7,12 +7,14 @@ namespace geosrad {
 
 template <typename R> hipError_t sw_reform_launch(hipStream_t st, const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV)
 {
-    static_assert(SWR_NSLOT <= SWR_SLOTS_MAX && SWR_NCOT <= 6, "workspace slots");
-    const dim3 grid(band_grid(A.ncol, SWR_NSLOT)), blk(256);
+    static_assert(swr_nslot<R> <= SWR_SLOTS_MAX && swr_ncot<R> <= 6, "workspace slots");
+    const dim3 grid(band_grid(A.ncol, swr_nslot<R>)), blk(256);
     hipLaunchKernelGGL((k_sw_reform<R, false>), grid, blk, 0, st, A, T, SV);
     hipLaunchKernelGGL((k_sw_reform<R, true>), grid, blk, 0, st, A, T, SV);
     return hipGetLastError();
 }
+
+template <typename R> int sw_reform_nslot() { return swr_nslot<R>; }
 
 template <typename R> hipError_t sw_reform_reduce(hipStream_t st, const SwArgs<R> &A, const SwOut<R> &O)
 {
@@ -23,10 +25,12 @@ template <typename R> hipError_t sw_reform_reduce(hipStream_t st, const SwArgs<R
 #if !defined(GEOSRAD_PART) || GEOSRAD_PART == 4
 template hipError_t sw_reform_launch<float>(hipStream_t, const SwArgs<float> &, const SwDev<float> &, const SwSolar<float> &);
 template hipError_t sw_reform_reduce<float>(hipStream_t, const SwArgs<float> &, const SwOut<float> &);
+template int sw_reform_nslot<float>();
 #endif
 #if !defined(GEOSRAD_PART) || GEOSRAD_PART == 8
 template hipError_t sw_reform_launch<double>(hipStream_t, const SwArgs<double> &, const SwDev<double> &, const SwSolar<double> &);
 template hipError_t sw_reform_reduce<double>(hipStream_t, const SwArgs<double> &, const SwOut<double> &);
+template int sw_reform_nslot<double>();
 #endif
 
 }  // namespace geosrad

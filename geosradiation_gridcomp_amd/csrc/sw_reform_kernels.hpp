@@ -23,22 +23,28 @@ template <typename B> struct SwrRaylPerG { static constexpr bool value = B::JB >
 #ifndef SWR_U
 #define SWR_U 6
 #endif
+// fp64: every real is a register pair - units of at most 4 g-points, evaluated 2 at a time (SWR_W64), keep the cloudy instantiation at
+// 247 VGPRs = two wavefronts per SIMD (units of 6 evaluated 4 at a time: 256 + 72 spilled into AGPRs, one wavefront)
+#ifndef SWR_U64
+#define SWR_U64 4
+#endif
+template <typename R> constexpr int swr_u = sizeof(R) == 8 ? SWR_U64 : SWR_U;
 // sizes of the units of a band with ng g-points: first unit's size, number of units (the units after the first share the rest evenly in
 // multiples of 2: 8 -> 4 + 4, 10 -> 6 + 4, 12 -> 6 + 6 for SWR_U = 6)
-__host__ __device__ constexpr int swr_nunit(int ng) { return (ng + SWR_U - 1) / SWR_U; }
-__host__ __device__ constexpr int swr_usize(int ng, int u)
+__host__ __device__ constexpr int swr_nunit(int U, int ng) { return (ng + U - 1) / U; }
+__host__ __device__ constexpr int swr_usize(int U, int ng, int u)
 {
-    const int nu = swr_nunit(ng);
+    const int nu = swr_nunit(U, ng);
     if (nu == 1) return ng;
     // nu >= 2: sizes in multiples of 2, as even as possible, larger units first
     const int pairs = ng / 2, base = pairs / nu, extra = pairs % nu;
     return 2 * (base + (u < extra ? 1 : 0));
 }
-__host__ __device__ constexpr int swr_ustart(int ng, int u) { int s = 0; for (int k = 0; k < u; k++) s += swr_usize(ng, k); return s; }
+__host__ __device__ constexpr int swr_ustart(int U, int ng, int u) { int s = 0; for (int k = 0; k < u; k++) s += swr_usize(U, ng, k); return s; }
 // slots of the partial fluxes: units in band order (16..29), ascending inside a band
-__host__ __device__ constexpr int swr_slot0(int jb) { int s = 0; for (int b = 16; b < jb; b++) s += swr_nunit(sw_band_ng(b)); return s; }
-constexpr int SWR_NSLOT = swr_slot0(30);
-constexpr int SWR_NCOT = swr_slot0(27) - swr_slot0(24);       // units of the PAR bands 24-26
+__host__ __device__ constexpr int swr_slot0(int U, int jb) { int s = 0; for (int b = 16; b < jb; b++) s += swr_nunit(U, sw_band_ng(b)); return s; }
+template <typename R> constexpr int swr_nslot = swr_slot0(swr_u<R>, 30);                                   // 23 (fp32), 32 (fp64)
+template <typename R> constexpr int swr_ncot = swr_slot0(swr_u<R>, 27) - swr_slot0(swr_u<R>, 24);          // units of the PAR bands 24-26
 
 // one unit (g-points GO .. GO + NGU - 1 of band B) of one column
 template <typename R, typename B, bool CLD, int GO, int NGU, int SLOT>
@@ -49,7 +55,10 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
     // more than the traffic it saves, so there the five layer properties are parked as well (planes 5 .. 9; the total sky's in cloudy
     // cells: 10 .. 14) and read back - the unit mapping (small state, no spills, two wavefronts per SIMD instead of one) is what fp64 gains
     constexpr bool REFORM = sizeof(R) == 4;
-    constexpr int W = NG >= 4 ? 4 : 2;
+#ifndef SWR_W64
+#define SWR_W64 2
+#endif
+    constexpr int W = sizeof(R) == 8 ? (NG >= SWR_W64 ? SWR_W64 : 2) : (NG >= 4 ? 4 : 2);
     constexpr int NQ = (NG + W - 1) / W;
     constexpr int S = pad4(NGB);
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
@@ -233,7 +242,7 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
     }
 
     // ---- sweep B: TOA -> surface ---------------------------------------------------------------------------------------
-    const size_t qs = (size_t)SWR_NSLOT * (nlay + 1) * n;
+    const size_t qs = (size_t)swr_nslot<R> * (nlay + 1) * n;
     R *const part = A.part + (size_t)SLOT * (nlay + 1) * n;
 #ifdef SWR_PART_NT
 #define PART(kind, lev, val) stg_nt(part + (size_t)(kind) * qs + (size_t)(lev) * n, cb, (R)(val))
@@ -438,9 +447,9 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
         PART(0, lay, cu); PART(1, lay, cd);
         if (CLD && ccol) { PART(2, lay, fu); PART(3, lay, fd); }
     }
-    stg(A.bsfc + (size_t)(0 * SWR_NSLOT + SLOT) * n, cb, sdir);
-    stg(A.bsfc + (size_t)(1 * SWR_NSLOT + SLOT) * n, cb, sfd);
-    stg(A.bsfc + (size_t)(2 * SWR_NSLOT + SLOT) * n, cb, sfu);
+    stg(A.bsfc + (size_t)(0 * swr_nslot<R> + SLOT) * n, cb, sdir);
+    stg(A.bsfc + (size_t)(1 * swr_nslot<R> + SLOT) * n, cb, sfd);
+    stg(A.bsfc + (size_t)(2 * swr_nslot<R> + SLOT) * n, cb, sfu);
 #undef PART
 #undef PST
 #undef PLD
@@ -465,11 +474,11 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
                 if (st > 0) { d[0] += wgt; nn[0] += wgt * st; }
             }
         }
-        constexpr int cs = SLOT - swr_slot0(24);
+        constexpr int cs = SLOT - swr_slot0(swr_u<R>, 24);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            stg(A.cot + (size_t)(k * SWR_NCOT + cs) * n, cb, d[k]);
-            stg(A.cot + (size_t)((4 + k) * SWR_NCOT + cs) * n, cb, nn[k]);
+            stg(A.cot + (size_t)(k * swr_ncot<R> + cs) * n, cb, d[k]);
+            stg(A.cot + (size_t)((4 + k) * swr_ncot<R> + cs) * n, cb, nn[k]);
         }
     }
 }
@@ -480,16 +489,16 @@ GR_DEV void swr_body(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV
 #ifndef SWR_OCC_CLD
 #define SWR_OCC_CLD 3
 #endif
-#ifndef SWR_OCC_CLD64          // fp64 cloudy instantiation: 256 VGPRs with 1 500 spilled at two wavefronts per SIMD
-#define SWR_OCC_CLD64 1
+#ifndef SWR_OCC_CLD64          // fp64 cloudy instantiation: two wavefronts per SIMD with units of 4 evaluated 2 g-points at a time
+#define SWR_OCC_CLD64 2
 #endif
 // block slot -> (band, unit): the units of the 14 bands in SW_BAND_ORDER (heaviest bands first)
 struct SwrUnit { int jb, u; };
-__host__ __device__ constexpr SwrUnit swr_unit_of(int s)
+__host__ __device__ constexpr SwrUnit swr_unit_of(int U, int s)
 {
     constexpr int order[NB_SW] = {17, 29, 20, 21, 23, 18, 19, 24, 27, 16, 25, 26, 28, 22};
     for (int k = 0; k < NB_SW; k++) {
-        const int nu = swr_nunit(sw_band_ng(order[k]));
+        const int nu = swr_nunit(U, sw_band_ng(order[k]));
         if (s < nu) return SwrUnit{order[k], s};
         s -= nu;
     }
@@ -498,15 +507,16 @@ __host__ __device__ constexpr SwrUnit swr_unit_of(int s)
 template <typename R, typename B, bool CLD, int U>
 GR_DEV void swr_unit(const SwArgs<R> &A, const SwDev<R> &T, const SwSolar<R> &SV, int col, int nclear)
 {
-    if constexpr (U < swr_nunit(B::NG))
-        swr_body<R, B, CLD, swr_ustart(B::NG, U), swr_usize(B::NG, U), swr_slot0(B::JB) + U>(A, T, SV, col, nclear);
+    constexpr int UU = swr_u<R>;
+    if constexpr (U < swr_nunit(UU, B::NG))
+        swr_body<R, B, CLD, swr_ustart(UU, B::NG, U), swr_usize(UU, B::NG, U), swr_slot0(UU, B::JB) + U>(A, T, SV, col, nclear);
 }
 
 template <typename R, bool CLD>
 __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? (CLD ? SWR_OCC_CLD : SWR_OCC_CLR) : (CLD ? SWR_OCC_CLD64 : 2))) k_sw_reform(SwArgs<R> A, SwDev<R> T, SwSolar<R> SV)
 {
     int bstart, bslot;       // one-dimensional grid: the units of a column block run together on one XCD (lw_kernels.hpp band_block)
-    if (!band_block(A.ncol, SWR_NSLOT, bstart, bslot)) return;
+    if (!band_block(A.ncol, swr_nslot<R>, bstart, bslot)) return;
     const int nclear = *A.nclear;
     // every column runs the instantiation of its own class (the one mixed block is visited by both kernels, each
     // masking the other class's lanes): a column's arithmetic never depends on its neighbours -> bitwise column independence
@@ -515,7 +525,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? (CLD ? SWR_OCC_CLD : SW
     const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
     if (CLD ? col < nclear : col >= nclear) return;
-    const SwrUnit un = swr_unit_of(bslot);
+    const SwrUnit un = swr_unit_of(swr_u<R>, bslot);
 #ifdef SWR_ONLY_BAND       // register census of one band's unit bodies (profiles/tools/swr_regs.sh)
 #define SWR_ON(B_) (B_::JB == SWR_ONLY_BAND)
 #else
@@ -545,15 +555,15 @@ __global__ void __launch_bounds__(256) k_swr_reduce(SwArgs<R> A, SwOut<R> O)
     const int n = A.ncol, nlay = A.nlay, ld = A.ld;
     const bool ccol = col >= *A.nclear;
     const int pc = A.perm[col];
-    const size_t qs = (size_t)SWR_NSLOT * (nlay + 1) * n;
+    const size_t qs = (size_t)swr_nslot<R> * (nlay + 1) * n;
     R top = 0;
-    for (int s = 0; s < SWR_NSLOT; s++) top += A.part[(size_t)(ccol ? 3 : 1) * qs + ((size_t)s * (nlay + 1) + nlay) * n + col];
+    for (int s = 0; s < swr_nslot<R>; s++) top += A.part[(size_t)(ccol ? 3 : 1) * qs + ((size_t)s * (nlay + 1) + nlay) * n + col];
     R scale = 1;
     if (A.normFlx == 1) scale = top > (R)1e-7 ? top : (R)1e-7;
     if ((int)blockIdx.y <= nlay) {
         const int lev = blockIdx.y;
         R s4[4] = {0, 0, 0, 0};
-        for (int s = 0; s < SWR_NSLOT; s++) {
+        for (int s = 0; s < swr_nslot<R>; s++) {
             const size_t o = ((size_t)s * (nlay + 1) + lev) * n + col;
             s4[0] += A.part[o]; s4[1] += A.part[qs + o];
             if (ccol) { s4[2] += A.part[2 * qs + o]; s4[3] += A.part[3 * qs + o]; }
@@ -568,10 +578,10 @@ __global__ void __launch_bounds__(256) k_swr_reduce(SwArgs<R> A, SwOut<R> O)
     int s = 0;
     for (int ibm = 1; ibm <= NB_SW; ibm++) {
         R dir = 0, fd = 0, fu = 0;
-        const int ns = swr_nunit(sw_band_ng(ibm + 15));
+        const int ns = swr_nunit(swr_u<R>, sw_band_ng(ibm + 15));
         for (int k = 0; k < ns; k++, s++) {
-            dir += A.bsfc[(size_t)(0 * SWR_NSLOT + s) * n + col]; fd += A.bsfc[(size_t)(1 * SWR_NSLOT + s) * n + col];
-            fu += A.bsfc[(size_t)(2 * SWR_NSLOT + s) * n + col];
+            dir += A.bsfc[(size_t)(0 * swr_nslot<R> + s) * n + col]; fd += A.bsfc[(size_t)(1 * swr_nslot<R> + s) * n + col];
+            fu += A.bsfc[(size_t)(2 * swr_nslot<R> + s) * n + col];
         }
         if (ibm == 14 || ibm <= 8) { znirr += dir; znirf += fd; }
         else if (ibm >= 10 && ibm <= 11) { zparr += dir; zparf += fd; }
@@ -587,7 +597,7 @@ __global__ void __launch_bounds__(256) k_swr_reduce(SwArgs<R> A, SwOut<R> O)
     O.nirr[pc] = o6[0]; O.nirf[pc] = o6[1]; O.parr[pc] = o6[2]; O.parf[pc] = o6[3]; O.uvrr[pc] = o6[4]; O.uvrf[pc] = o6[5];
     for (int k = 0; k < 8; k++) {
         R sum = 0;
-        if (ccol) for (int b = 0; b < SWR_NCOT; b++) sum += A.cot[(size_t)(k * SWR_NCOT + b) * n + col];
+        if (ccol) for (int b = 0; b < swr_ncot<R>; b++) sum += A.cot[(size_t)(k * swr_ncot<R> + b) * n + col];
         O.cot[k][pc] = sum;
     }
 }
