@@ -404,7 +404,7 @@ def bench_gridcomp(a, rank, world, dev, local_rank, aerosol, cpu):
                 step()
             torch.cuda.synchronize()
             prof1, nst = ctx.profile_read(), 2
-        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_lw_cols") + SW_BAND_KERNELS and v[1] > 0}
+        cand = {k: v for k, v in prof1.items() if k in LW_BAND_KERNELS + SW_BAND_KERNELS and v[1] > 0}
         kname = max(cand, key=lambda k: cand[k][0])
         ms, n = prof1[kname]
         abytes = (algorithmic_bytes_lw if kname.startswith("k_lw") else algorithmic_bytes_sw)(lm, a.real, aerosol)
@@ -525,7 +525,7 @@ def live_counters(a, argv, cache=None, configs=False):
 
 def roofline_note(kname, two_streams):
     """what a `launch` of the dominant kernel is and why its fraction of the HBM peak on the compulsory bytes is what it is"""
-    if kname in ("k_lw_bands", "k_lw_cols") + SW_BAND_KERNELS:
+    if kname in LW_BAND_KERNELS + SW_BAND_KERNELS:
         note = ("a `launch` here is the kernel's cloud-free and cloudy instantiation launched back to back over the batch (one HIP-event "
                 "span; in the rocprofv3 kernel stats: the sum of the two instantiations' average durations); the fused k-distribution + "
                 "vertical-sweep kernel parks per-cell state between its two sweeps, so its HBM traffic is a multiple of the compulsory "
@@ -544,6 +544,7 @@ def roofline_note(kname, two_streams):
 
 PARITY_COLS = 256
 SW_BAND_KERNELS = ("k_sw_reform", "k_sw_bands")        # the default RRTMG_SW band sweeps | GEOSRAD_SW_PATH=bands (first mapping)
+LW_BAND_KERNELS = ("k_lw_bands", "k_lw_cols", "k_lw_cells+k_lw_sweep")      # RRTMG_LW band sweeps: default | GEOSRAD_LW_PATH=cols | =split
 PARITY_LW = ("uflx", "dflx", "uflxc", "dflxc")
 PARITY_SW = ("swuflx", "swdflx", "swuflxc", "swdflxc")
 
@@ -1504,7 +1505,7 @@ def main():
         value = total_cols / elapsed
         # dominant kernel = largest total time; its algorithmic bytes are those of the solver it belongs to
         # (compulsory bytes at the solver API, every input read once + every output written once)
-        cand = {k: v for k, v in prof1.items() if k in ("k_lw_bands", "k_lw_cols", "k_chou_bands", "k_sorad_pass", "k_sorad_col") + SW_BAND_KERNELS and v[1] > 0}
+        cand = {k: v for k, v in prof1.items() if k in LW_BAND_KERNELS + ("k_chou_bands", "k_sorad_pass", "k_sorad_col") + SW_BAND_KERNELS and v[1] > 0}
         kname = max(cand, key=lambda k: cand[k][0])
         ms, n = prof1[kname]
         launches_per_step = n / (2 if prof1 is not prof else a.steps)

@@ -34,9 +34,10 @@ def build(force=False):
     on-chip RRTMG_LW band sweeps) and sw_reform.hip (the default RRTMG_SW band sweeps) twice each - fp32, fp64."""
     inc = os.path.join(os.path.dirname(HERE), "include", "geosrad.h")
     hpp = {f: os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")}
-    cols_only = {"lw_cols_kernels.hpp", "sw_reform_kernels.hpp"}                       # headers geosrad.hip does not include
+    cols_only = {"lw_cols_kernels.hpp", "sw_reform_kernels.hpp", "lw_split_kernels.hpp"}      # headers geosrad.hip does not include
     deps_main = [os.path.join(CSRC, "geosrad.hip"), inc] + [p for f, p in hpp.items() if f not in cols_only]
     deps_cols = [os.path.join(CSRC, "lw_cols.hip")] + [hpp[f] for f in ("lw_cols_kernels.hpp", "lw_cols.hpp", "lw_kernels.hpp", "lw_device.hpp")]
+    deps_split = [os.path.join(CSRC, "lw_split.hip")] + [hpp[f] for f in ("lw_split_kernels.hpp", "lw_split.hpp", "lw_kernels.hpp", "lw_device.hpp")]
     deps_swq = [os.path.join(CSRC, "sw_reform.hip")] + [hpp[f] for f in ("sw_reform_kernels.hpp", "sw_reform.hpp", "sw_kernels.hpp", "lw_kernels.hpp", "lw_device.hpp")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(os.path.dirname(HERE), "build", "obj")
@@ -46,7 +47,7 @@ def build(force=False):
     # operands moved into register pairs: the SW sweeps lose a third of their instructions and 30 VGPRs without it
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
     units = [("geosrad.hip", part, deps_main) for part in (4, 8, 0)] + [("lw_cols.hip", part, deps_cols) for part in (4, 8)] \
-        + [("sw_reform.hip", part, deps_swq) for part in (4, 8)]
+        + [("sw_reform.hip", part, deps_swq) for part in (4, 8)] + [("lw_split.hip", part, deps_split) for part in (4, 8)]
     extra = os.environ.get("GEOSRAD_HIPCC_FLAGS", "").split()            # kernel experiments (A/B builds) only
     jobs, objs = [], []
     for src, part, deps in units:

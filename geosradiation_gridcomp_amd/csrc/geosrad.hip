@@ -30,6 +30,7 @@
 #include "sorad_kernels.hpp"
 #include "gridcomp_kernels.hpp"
 #include "lw_cols.hpp"
+#include "lw_split.hpp"
 #include "sw_reform.hpp"
 
 using namespace geosrad;
@@ -308,6 +309,7 @@ struct geosrad_ctx {
     int device = 0, real_kind = 4, chunk = 131072;
     bool sorad_col_path = false;    // Chou-Suarez sorad passes: HBM scratch planes, lane = column (default) | GEOSRAD_SORAD_PATH=col: on chip
     bool lw_cols_path = false;      // RRTMG_LW band sweeps: parked cells in HBM (default) | GEOSRAD_LW_PATH=cols: on-chip intermediates
+    bool lw_split_path = false;     //                       | GEOSRAD_LW_PATH=split: k-distribution layer-parallel (k_lw_cells) + recurrences (k_lw_sweep)
     int sw_path = 2;                // RRTMG_SW band sweeps: k_sw_reform (2, default) | GEOSRAD_SW_PATH=bands: k_sw_bands, the first mapping (0)
     std::string last_error;
     hipStream_t stream = nullptr;   // internal stream of the host-pointer entry points
@@ -878,7 +880,8 @@ template <typename R> struct Ctx : geosrad_ctx {
     size_t workspace_bytes() const override { return ws_bytes + ws_sw_bytes + ws_ch_bytes + ws_so_bytes + ws_drvs_bytes[0] + ws_drvs_bytes[1] + io_bytes + tab_bytes + tab_sw_bytes + tab_ch_bytes; }
 
     // ---- workspace -------------------------------------------------------------------------------------
-    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; uint16_t *s1, *s2; R *part; };
+    struct Ws { R *sc; uint32_t *scidx; R *pwvcm; uint8_t *colcloudy, *laycloudy; int32_t *perm, *nclear; R *taucmc, *alpha, *rcorr; uint16_t *s1, *s2; R *part;
+                uint32_t *pfcode; R *pffs; };
     static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t ws_layout(int nc, int nlay, Ws *w, char *base) const
     {
@@ -901,6 +904,9 @@ template <typename R> struct Ctx : geosrad_ctx {
         p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s1 = (uint16_t *)p;
         p = take(NG_LW * clp * sizeof(uint16_t)); if (w) w->s2 = (uint16_t *)p;
         p = take((size_t)6 * NB_LW * (nlay + 1) * nc * sizeof(R)); if (w) w->part = (R *)p;
+        // split path: the Planck-fraction selector of every (band, layer, column) (lw_split_kernels.hpp)
+        p = take(lw_split_path ? NB_LW * cl * 4 : 0); if (w) w->pfcode = (uint32_t *)p;
+        p = take(lw_split_path ? NB_LW * cl * sizeof(R) : 0); if (w) w->pffs = (R *)p;
         return off;
     }
     int ensure_ws(int nc, int nlay)
@@ -1014,6 +1020,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.tauaer = P(I_TAUAER); A.zm = P(I_ZM); A.alat = P(I_ALAT);
             A.sc = w.sc; A.scidx = w.scidx; A.pwvcm = w.pwvcm; A.colcloudy = w.colcloudy; A.perm = w.perm; A.nclear = w.nclear; A.laycloudy = w.laycloudy;
             A.taucmc = w.taucmc; A.alpha = w.alpha; A.rcorr = w.rcorr; A.s1 = w.s1; A.s2 = w.s2; A.part = w.part;
+            A.pfcode = w.pfcode; A.pffs = w.pffs;
             A.err = d_err;
             A.dbg_taug = dbg_taug ? (R *)dbg_taug + (size_t)c0 * NG_LW * nlay : nullptr;
             A.dbg_pfracs = dbg_pfracs ? (R *)dbg_pfracs + (size_t)c0 * NG_LW * nlay : nullptr;
@@ -1059,6 +1066,9 @@ template <typename R> struct Ctx : geosrad_ctx {
                 if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("lw_cols_launch: ") + hipGetErrorString(e));
             } else if (A.dbg_taug) {
                 hipLaunchKernelGGL((k_lw_bands<R, true, true>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
+            } else if (lw_split_path) {
+                hipError_t e = lw_split_launch<R>(st, A, h_T);
+                if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("lw_split_launch: ") + hipGetErrorString(e));
             } else {
                 // (both instantiations band-major, heaviest band first: see band_block in lw_kernels.hpp)
                 hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, A, h_T);
@@ -1096,11 +1106,16 @@ template <typename R> struct Ctx : geosrad_ctx {
                 B.part = rat_part;
                 span_begin(1, st); hipLaunchKernelGGL(k_setcoef<R>, dim3(gx, nlay), blk, 0, st, B, d_T); span_end(st);
                 span_begin(4, st);
+                if (lw_split_path) {
+                    hipError_t e = lw_split_launch<R>(st, B, h_T);
+                    if (e != hipSuccess) return fail(GEOSRAD_EHIP, std::string("lw_split_launch: ") + hipGetErrorString(e));
+                } else {
                 hipLaunchKernelGGL((k_lw_bands<R, false, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
                 if constexpr (sizeof(R) == 4)
                     hipLaunchKernelGGL((k_lw_bands<R, false, false, LW_WIDE_BLOCK>), dim3((unsigned)((nc + LW_WIDE_BLOCK - 1) / LW_WIDE_BLOCK), NB_LW),
                                        dim3(LW_WIDE_BLOCK), lds, st, B, h_T);
                 hipLaunchKernelGGL((k_lw_bands<R, true, false>), dim3(gx, NB_LW), blk, lds, st, B, h_T);
+                }
                 span_end(st);
                 LwOut<R> OR{};
                 const size_t ro = (size_t)r * (nlay + 1) * ncol + c0;
@@ -2795,7 +2810,7 @@ int geosrad_create(geosrad_ctx **out, int device_id, int real_kind)
     c->device = device_id; c->real_kind = real_kind;
     {   // A/B switch for the measurements in profiles/: GEOSRAD_LW_PATH=cols | bands
         const char *e = getenv("GEOSRAD_LW_PATH");
-        if (e) c->lw_cols_path = !strcmp(e, "cols");
+        if (e) { c->lw_cols_path = !strcmp(e, "cols"); c->lw_split_path = !strcmp(e, "split"); }
         e = getenv("GEOSRAD_SW_PATH");
         if (e) c->sw_path = !strcmp(e, "bands") ? 0 : 2;
         if ((e = getenv("GEOSRAD_SORAD_PATH"))) c->sorad_col_path = !strcmp(e, "col");
@@ -3241,7 +3256,7 @@ const char *geosrad_kernel_label(geosrad_ctx *c, int kernel_id)
 {
     if (!c) return geosrad_kernel_name(kernel_id);
     switch (kernel_id) {
-    case 4: return c->lw_cols_path ? "k_lw_cols" : "k_lw_bands";
+    case 4: return c->lw_cols_path ? "k_lw_cols" : (c->lw_split_path ? "k_lw_cells+k_lw_sweep" : "k_lw_bands");
     case 8: return c->sw_path == 2 ? "k_sw_reform" : "k_sw_bands";
     case 9: return c->sw_path == 2 ? "k_swr_reduce" : "k_sw_reduce";
     case 13: return c->sorad_col_path ? "k_sorad_col" : "k_sorad_pass";

@@ -94,6 +94,8 @@ template <typename R> struct LwArgs {
     R *dbg_taug, *dbg_pfracs;    // optional Fortran (nlay,140,ncol) dumps (nullptr in production)
     int32_t *clearCounts;        // (ncol,4)
     uint32_t band_mask;          // bit ib set: k_lw_bands runs band ib (all 16 except in a RATS pass, see lw_rat_bands)
+    uint32_t *pfcode;            // [16][nlay][ncol] split path (lw_split_kernels.hpp): Planck-fraction selector of the (band, layer, column):
+    R *pffs;                     //                  kind | js << 8, and the interpolation weight fs
 };
 
 // RATS passes (GEOS_IrradGridComp.F90:3405-3468) remove one gas: only the bands whose optical depths read that gas's column amount

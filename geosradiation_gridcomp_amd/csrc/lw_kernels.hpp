@@ -427,6 +427,10 @@ template <typename R> GR_DEV R adjcol(R colx, R coldry, R chiref, R thresh, R a,
     return colx;
 }
 
+// Planck fractions of a (layer, column, band): kind 0 none (pf = 0), 1 / 2 fracrefa / fracrefb row 1, 3 / 4 linear between rows js and
+// js + 1 of fracrefa / fracrefb with weight fs
+template <typename R> struct PfSel { int kind, js; R fs; };
+
 // g-independent state of one (layer, column, band); every band uses a subset
 template <typename R> struct Prep {
     Spec<R> sp, sp1, sm, sm2, spl;
@@ -442,14 +446,17 @@ template <typename R> struct Prep {
 #define IND1B(n) (((L.jp - 12) * 5 + (L.jt1 - 1)) * (n))
 #define ADD_SELF() add_linw<R, W, S>(tau, L.selffac, L.selffrac, B.selfref, L.indself - 1, go)
 #define ADD_FOR() add_linw<R, W, S>(tau, L.forfac, L.forfrac, B.forref, L.indfor - 1, go)
-#define PF_CONST(frac) ldw<R, W>(frac, (uint32_t)go * (uint32_t)sizeof(R), pf)
-#define PF_INTERP(frac, s) linw<R, W, S>(pf, (s).fs, frac, (s).js - 1, go)
+// (sel, when asked for: WHICH Planck fractions the layer takes - table and interpolation weights; k_lw_cells parks it for k_lw_sweep)
+#define PF_CONST(frac) do { ldw<R, W>(frac, (uint32_t)go * (uint32_t)sizeof(R), pf);                                \
+                            if (sel) { sel->kind = (frac) == B.fracrefb ? 2 : 1; sel->js = 1; sel->fs = 0; } } while (0)
+#define PF_INTERP(frac, s) do { linw<R, W, S>(pf, (s).fs, frac, (s).js - 1, go);                                    \
+                                if (sel) { sel->kind = (frac) == B.fracrefb ? 4 : 3; sel->js = (s).js; sel->fs = (s).fs; } } while (0)
 #define BAND_DECL(ib, ng, g0)                                                                                   \
     static constexpr int IB = ib, NG = ng, G0 = g0, S = pad4(ng);                                             \
     template <typename R> GR_DEV static void prep(const LwDev<R> &T, const LwArgs<R> &A, const Layer<R> &L, Prep<R> &P)
 #define BAND_EVAL()                                                                                             \
     template <typename R, int W>                                                                                \
-    GR_DEV static void eval(const LwDev<R> &T, const Layer<R> &L, const Prep<R> &P, int go, R (&tau)[W], R (&pf)[W])
+    GR_DEV static void eval(const LwDev<R> &T, const Layer<R> &L, const Prep<R> &P, int go, R (&tau)[W], R (&pf)[W], PfSel<R> *sel = nullptr)
 
 struct Band1 {  // 10-350 cm-1: h2o; minor n2 (:214-291)
     BAND_DECL(1, 10, 0)
@@ -845,6 +852,7 @@ struct Band12 {  // 1800-2080: h2o,co2 | nothing (:2165-2345)
         } else {
 #pragma unroll
             for (int j = 0; j < W; j++) { tau[j] = 0; pf[j] = 0; }
+            if (sel) { sel->kind = 0; sel->js = 1; sel->fs = 0; }
         }
     }
 };
@@ -936,6 +944,7 @@ struct Band15 {  // 2380-2600: n2o,co2 | nothing; minor n2 (:2658-2866)
         } else {
 #pragma unroll
             for (int j = 0; j < W; j++) { tau[j] = 0; pf[j] = 0; }
+            if (sel) { sel->kind = 0; sel->js = 1; sel->fs = 0; }
         }
     }
 };

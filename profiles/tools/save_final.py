@@ -2,14 +2,19 @@
 # profiles/rNN_counters.json - per dominant kernel of a workload: HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction of
 # MI355X_MICROARCH.md), vector-instruction counts and the issue / wait fractions - which bench.py quotes as roofline.traffic / roofline_compute
 import json, re, shutil, sys
-RN = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RN = sys.argv[1] if len(sys.argv) > 1 else "r04"
 S = "gpurun_out/final"
 for f in ("bench_lwsw", "bench_lwsw_one_stream", "bench_lwsw_host_api", "bench_lwsw_half_lit", "bench_cfg1_lw_clear", "bench_lwsw_f64",
-          "bench_gridcomp", "bench_chou", "bench_mcica", "bench_ranks_per_gpu"):
+          "bench_gridcomp", "bench_chou", "bench_mcica", "bench_ranks_per_gpu", "bench_lwsw_one_stream_lw_split"):
     try: shutil.copy(f"{S}/{f}.json", f"profiles/{RN}_final_{f}.json")
     except OSError as e: print("missing", f, e)
 shutil.copy(f"{S}/stats_one/x_kernel_stats.csv", f"profiles/{RN}_final_lwsw_one_stream_kernel_stats.csv")
 shutil.copy(f"{S}/stats_two/x_kernel_stats.csv", f"profiles/{RN}_final_lwsw_two_streams_kernel_stats.csv")
+try:
+    shutil.copy(f"{S}/stats_cfg/x_kernel_stats.csv", f"profiles/{RN}_configs_kernel_stats.csv")       # bench.py --configs-only: the five legs of the `configs` object
+    shutil.copy(f"{S}/pcie.txt", f"profiles/{RN}_pcie.txt")
+except OSError as e:
+    print("missing", e)
 NSIMD = 1024                       # 256 CUs x 4
 
 
@@ -47,7 +52,7 @@ for tag, key, ncol, names in (("lwsw", "lwsw_97200_72_0.6_aer_f32", 97200, ("k_s
              "lane_ops_per_column": round(g("SQ_INSTS_VALU") * 64.0 / ncol), "valu_util": round(g("SQ_ACTIVE_INST_VALU") * 4.0 / simd_cycles, 3) if simd_cycles else None,
              "wait_frac": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 3) if g("SQ_WAVE_CYCLES") else None,
              "issue_stall_frac": round(g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 3) if g("SQ_WAVE_CYCLES") else None}
-        out[key]["k_sw_bands" if name == "k_sw_reform" else name] = e          # bench.py's kernel-group name of the SW band sweeps
+        out[key][name] = e
         print(key, name, "%.2f GB" % ((2 * f + w) / 1e9), "valu_util", e["valu_util"], "wait", e["wait_frac"], "lane ops/col", e["lane_ops_per_column"])
 json.dump(out, open(f"profiles/{RN}_counters.json", "w"), indent=1)
 for f in ("bench_lwsw", "bench_lwsw_one_stream"):
