@@ -710,7 +710,7 @@ def bench_ranks_per_gpu(a):
             for which, exe, ix in (("rrtmg_lw", exe_lw, 0), ("rrtmg_sw", exe_sw, 1)):
                 t0 = time.perf_counter()
                 procs = [subprocess.Popen([exe, files[r][ix], os.path.join(tmp, f"out_{r}.bin"), str(reps)], stdout=subprocess.PIPE, text=True,
-                                          env=dict(env0, OMPI_COMM_WORLD_LOCAL_RANK=str(r))) for r in range(K)]
+                                          env=dict(env0, OMPI_COMM_WORLD_LOCAL_RANK=str(r), OMPI_COMM_WORLD_LOCAL_SIZE=str(K))) for r in range(K)]
                 ms = []
                 for pr in procs:
                     txt = pr.communicate()[0]
@@ -1230,17 +1230,32 @@ def main():
         # instead of being generated again by each of them; removed at exit
         import atexit, shutil, tempfile
         from geosradiation_gridcomp_amd import synth as _synth
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else os.environ.get("TMPDIR", "/tmp")
-        cache = tempfile.mkdtemp(prefix="geosrad_bench_", dir=base)
-        atexit.register(shutil.rmtree, cache, True)
-        if a.scheme in ("lwsw", "lw", "sw") and a.coherent == 1 and not os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"):
-            inp_main = _synth.make_columns(a.ncol, a.nlay, start=shard_start(rank, a.ncol), cloudy_frac=a.cloudy, aerosol=not a.no_aerosol)
-            _cache_put(cache, "main", inp_main)
-        if want_cfg:
-            clr, cld, ch, cs = cfg_inputs(CFG_NCOL, CFG_START)
-            _cache_put(cache, "cfg", {**{"clr_" + k: v for k, v in clr.items()}, **{"cld_" + k: v for k, v in cld.items()},
-                                      **{"ch_" + k: v for k, v in ch.items()}, **{"cs_" + k: v for k, v in cs.items()}})
-            del clr, cld, ch, cs
+        base = None
+        for cand_dir in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):       # ~3 GB (headline batch) + ~7 GB (the configs' batches)
+            try:
+                if os.path.isdir(cand_dir) and os.access(cand_dir, os.W_OK) and shutil.disk_usage(cand_dir).free > (16 << 30):
+                    base = cand_dir
+                    break
+            except OSError:
+                pass
+        try:
+            if base is None:
+                raise OSError("no directory with 16 GB free for the inputs cache")
+            cache = tempfile.mkdtemp(prefix="geosrad_bench_", dir=base)
+            atexit.register(shutil.rmtree, cache, True)
+            if a.scheme in ("lwsw", "lw", "sw") and a.coherent == 1 and not os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"):
+                inp_main = _synth.make_columns(a.ncol, a.nlay, start=shard_start(rank, a.ncol), cloudy_frac=a.cloudy, aerosol=not a.no_aerosol)
+                _cache_put(cache, "main", inp_main)
+            if want_cfg:
+                clr, cld, ch, cs = cfg_inputs(CFG_NCOL, CFG_START)
+                _cache_put(cache, "cfg", {**{"clr_" + k: v for k, v in clr.items()}, **{"cld_" + k: v for k, v in cld.items()},
+                                          **{"ch_" + k: v for k, v in ch.items()}, **{"cs_" + k: v for k, v in cs.items()}})
+                del clr, cld, ch, cs
+        except OSError as e:          # no room: every process generates its own inputs (slower, same numbers)
+            print("bench.py: inputs cache not used (%s)" % e, file=sys.stderr)
+            if cache:
+                shutil.rmtree(cache, True)
+            cache = None
     elif a.inputs_cache:
         cache = a.inputs_cache
     if want_pmc:

@@ -19,6 +19,7 @@
 #include <chrono>
 
 #include <dlfcn.h>
+#include <sched.h>
 #include <cstddef>
 #include <cstdint>
 #include "../../include/geosrad.h"
@@ -287,9 +288,24 @@ public:
 
 // copy threads per context when GEOSRAD_HOST_THREADS is not set: the host's hardware threads shared out among the ranks of the node (the
 // launchers' node-local size; 96 ranks x 8 copy threads would oversubscribe a host), at most 8, at least 1
+// CPUs this process may use at once: the hardware threads it is allowed on, capped by the cgroup's CPU quota (a container that sees 256
+// hardware threads may own 16 of them)
+static int usable_cpus()
+{
+    long n = (long)std::thread::hardware_concurrency();
+    cpu_set_t m;
+    if (sched_getaffinity(0, sizeof m, &m) == 0 && CPU_COUNT(&m) > 0) n = CPU_COUNT(&m);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota> <period>" or "max <period>"
+        long q = 0, per = 0;
+        if (fscanf(f, "%ld %ld", &q, &per) == 2 && q > 0 && per > 0) { const long c = (q + per - 1) / per; if (c < n) n = c; }
+        fclose(f);
+    }
+    return (int)(n < 1 ? 1 : n);
+}
+
 static int default_host_threads()
 {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = (unsigned)usable_cpus();
     if (hw == 0) hw = 8;
     long ranks = 1;
     static const char *vars[] = {"OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "PMI_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"};
