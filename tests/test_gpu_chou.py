@@ -223,3 +223,58 @@ def test_gpu_chou_schemes_match_techmemo_tables(gpu_ctx, rk, tmp_path):
     for got, key in ((toa, "toa"), (sfc, "sfc"), (toa - sfc, "atm")):
         assert abs(got - M.SW_STRATUS[key][0]) <= 8.5, (key, got, M.SW_STRATUS[key])
     assert abs(toa / M.SW_STRATUS["toa"][0] - 1) <= 0.01
+
+
+@pytest.mark.parametrize("rk", [8, 4])
+def test_sorad_all_cloud_group_classes(gpu_ctx, rk):
+    """k_sorad_pass runs one instantiation per CLASS of column - which of the high / middle / low cloud groups (levels < ict, < icb,
+    the rest; sorad.F90:416-431) hold cloud - on columns sorted by class.  The synthetic clouds populate four of the eight classes: here
+    every class is forced (cloud fraction and condensate removed from the groups a class lacks), interleaved so that the sort has work to
+    do, and the batch is also cut into ragged chunks.  Against the oracle; a class's columns alone give the same bits."""
+    from geosradiation_gridcomp_amd import synth
+    from oracle import clib
+    ctx = gpu_ctx[rk]
+    n, nlay = 8 * 37, 72
+    inp = synth.make_columns(n, nlay, start=880_000, cloudy_frac=1.0, aerosol=True)
+    cs = synth.chou_sw_inputs(inp, aerosol=True)
+    ict, icb = int(cs["ict"]), int(cs["icb"])
+    grp = np.where(np.arange(1, nlay + 1) < ict, 4, np.where(np.arange(1, nlay + 1) < icb, 2, 1))     # layer k = 1..np (top-down) -> group bit
+    cls = np.arange(n) % 8                                                                            # interleaved classes 0..7
+    fcld = np.array(cs["fcld"], copy=True); cwc = np.array(cs["cwc"], copy=True)
+    rng = np.random.default_rng(5)
+    for c in range(8):
+        cols = np.where(cls == c)[0]
+        for g in (4, 2, 1):
+            lays = np.where(grp == g)[0]
+            if c & g:      # make sure the group does hold cloud: two layers of it get cloud fraction and condensate
+                pick = rng.choice(lays, size=2, replace=False)
+                fcld[np.ix_(pick, cols)] = rng.uniform(0.2, 0.9, (2, cols.size)).astype(fcld.dtype)
+                cwc[:2, pick[:, None], cols[None, :]] = 2.0e-5
+            else:
+                fcld[np.ix_(lays, cols)] = 0
+                cwc[:, lays[:, None], cols[None, :]] = 0
+    cs = dict(cs, fcld=fcld, cwc=cwc)
+    have = {(4 if (fcld[grp == 4][:, i] > 0).any() else 0) + (2 if (fcld[grp == 2][:, i] > 0).any() else 0) + (1 if (fcld[grp == 1][:, i] > 0).any() else 0)
+            for i in range(n)}
+    assert have == set(range(8))
+    g = ctx.sorad_columns(cs, do_drfband=True)
+    o = clib.sorad(cs, _kind(rk), do_drfband=True)
+    assert o["rc"] == 0
+    tol = 1e-9 if rk == 8 else 2e-5
+    for k in SO_KEYS:
+        assert np.abs(g[k].astype(np.float64) - o[k].astype(np.float64)).max() <= tol, k
+    np.testing.assert_array_equal(g["flx"][:, cls == 0], g["flc"][:, cls == 0])          # class 0: total sky = clear sky
+    assert (np.abs(g["flx"][-1] - g["flc"][-1])[cls == 7] > 1e-4).mean() > 0.9            # class 7: clouds do change the surface flux
+    # a class's columns alone, and ragged chunks of the batch, give the same bits
+    for c in (0, 2, 5, 7):
+        sub = {k: (np.ascontiguousarray(v[..., cls == c]) if isinstance(v, np.ndarray) and v.shape[-1] == n else v) for k, v in cs.items()}
+        p = ctx.sorad_columns(sub, do_drfband=True)
+        for k in SO_KEYS:
+            np.testing.assert_array_equal(p[k], g[k][..., cls == c], err_msg=f"class {c} {k}")
+    ctx.set_chunk(100)
+    try:
+        q = ctx.sorad_columns(cs, do_drfband=True)
+    finally:
+        ctx.set_chunk(131072)
+    for k in SO_KEYS:
+        np.testing.assert_array_equal(q[k], g[k], err_msg=k)
