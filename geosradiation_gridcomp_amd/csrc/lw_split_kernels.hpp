@@ -3,11 +3,13 @@
 //                fused k_lw_bands does inside its downward sweep (taumol, LW/rrtmg_lw_taumol.F90:155-3126, + the Pade index of the
 //                discretised optical depth, rrtmg_lw_rtrnmc.F90:245-283).  Parks per cell the 2-byte index of the total-sky optical depth
 //                (and the gas-only one below a cloudy column's cloud top), per (band, layer, column) which Planck fractions the layer takes.
-//   k_lw_sweep : lane = column, block = 1 024 columns of one band: the two vertical recurrences of rtrnmc (:245-379) from the parked
-//                indices - no table-row gathers, no layer record, 30-100 VGPRs: the recurrences run at 4-8 wavefronts per SIMD.
-// Why: k_lw_bands is bound by the latency of its per-layer chain (record -> table rows -> look-up) at the two wavefronts per SIMD its 220-240
-// VGPRs allow (profiles/r03_lw_units.md); the k-distribution has no vertical dependence, so as a kernel of its own it has 72 x the
-// parallelism and no adding state to carry.  The arithmetic per cell is k_lw_bands' (same operations, same order): bitwise the same fluxes.
+//   k_lw_sweep : lane = column, block = 1 024 / 768 columns of one band: the two vertical recurrences of rtrnmc (:245-379) from the parked
+//                indices - no table-row gathers, no layer record, 121-168 VGPRs: four / three wavefronts per SIMD.
+// Why it was built: k_lw_bands waits on its per-layer chain (record -> table rows -> look-up) at the two wavefronts per SIMD its 220-240 VGPRs
+// allow (profiles/r03_lw_units.md); the k-distribution has no vertical dependence, so as a kernel of its own it has many times the threads
+// and no adding state to carry.  The arithmetic per cell is k_lw_bands' (same operations, same order; the compiler's choice of fused
+// multiply-adds aside).  MEASURED SLOWER than the fused kernel - 4.1 + 3.4 against 5.9 ms per 97 200 columns (profiles/r04_lw_split.md:
+// the k-distribution alone is 70 % of the fused kernel, which overlaps the two halves inside one wavefront) - selectable, not the default.
 #pragma once
 #include "lw_kernels.hpp"
 
@@ -23,7 +25,6 @@ template <typename R, bool CLD> constexpr int lws_block = sizeof(R) == 4 ? (CLD 
 // (2 NG bytes: one or two 16-byte accesses)
 template <int NG> GR_DEV size_t lws_cell(int ncol_pad, int nlay, int g0, uint32_t ucol, int lay)
 {
-    (void)ncol_pad;
     return (size_t)g0 * nlay * ncol_pad + (((size_t)(ucol >> 8) * nlay + lay) * 256u + (ucol & 255u)) * NG;
 }
 // (a lane's run is 4-byte aligned: 2 NG bytes per lane, NG even)
