@@ -454,7 +454,7 @@ PMC_GROUPS = {"k_sw_reform": ("k_sw_reform",), "k_sw_bands": ("k_sw_bands",), "k
               "k_mcica_sa": ("k_mcica_sa",), "k_chou_bands": ("k_chou_bands",), "k_sorad_pass": ("k_sorad_pass",)}
 
 
-def live_counters(a, argv, cache=None, configs=False):
+def live_counters(a, argv, cache=None, configs=False, legs=None, mem_only=False):
     """The dominant kernels' PMC figures of THIS build on THIS box, collected the way MI355X_MICROARCH.md prescribes: rocprofv3 --pmc around a
     short one-stream run of the same workload, one counter group per run (FETCH_SIZE | WRITE_SIZE | the issue counters), the program directly
     behind `--`.  Runs as child processes BEFORE this process touches the GPU.  Returns {kernel group: {...}} per step, or None (no profiler,
@@ -469,8 +469,10 @@ def live_counters(a, argv, cache=None, configs=False):
     child = [sys.executable, os.path.join(here, "bench.py"), "--no-pmc", "--no-cpu", "--no-parity", "--no-f64", "--no-configs", "--no-overlap",
              "--steps", str(steps), "--warmup", str(warm), "--scheme", a.scheme, "--ncol", str(a.ncol), "--nlay", str(a.nlay), "--cloudy", str(a.cloudy),
              "--real", str(a.real), "--lit", str(a.lit), "--coherent", str(a.coherent)] + keep
-    if configs:             # the five legs of BASELINE configs[1] / [2], 3 steps each (configs_gpu)
+    if configs:             # legs of the `configs` object, 3 steps each (configs_gpu); a child run holds legs whose kernels do not share names
         child = [sys.executable, os.path.join(here, "bench.py"), "--configs-only", "--steps", str(steps), "--warmup", str(warm)]
+        if legs:
+            child += ["--configs-legs", ",".join(legs)]
     if cache:
         child += ["--inputs-cache", cache]
     env = dict(os.environ, TMPDIR="/tmp")
@@ -479,13 +481,14 @@ def live_counters(a, argv, cache=None, configs=False):
     sums = {}
     tmp = tempfile.mkdtemp(prefix="geosrad_pmc_", dir="/tmp")
     try:
-        for i, grp in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"])):
+        groups = (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"])
+        for i, grp in enumerate(groups[:2] if mem_only else groups):
             d = os.path.join(tmp, "p%d" % i)
             # a session of its own, so that a pass that overruns can be ended together with the program it started
             pr = subprocess.Popen([prof, "--pmc"] + grp + ["-d", d, "-o", "x", "--output-format", "csv", "--"] + child, cwd="/tmp", env=env,
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                rc = pr.wait(timeout=120)
+                rc = pr.wait(timeout=240 if configs else 120)
             except subprocess.TimeoutExpired:
                 import signal
                 try:
@@ -841,6 +844,11 @@ def bench_mcica(a, rank, world, dev, local_rank, cpu):
 #   cfg2_sorad_100k    : Chou-Suarez sorad on the same columns (8 bands, aerosols)                     (configs[2])
 #   cfg2_irrad_100k    : Chou-Suarez irrad on the same columns (10 bands, trace gases, aerosols)       (configs[0]'s scheme at configs[2]'s size)
 #   cfg2_mcica_200     : the McICA generator stand-alone, 200 sub-columns                              (configs[2])
+#   cfg0_irrad_1000_clear : Chou-Suarez irrad on 1 000 clear-sky columns                                  (configs[0]: the reference's CPU-runnable case)
+#   cfg4_c720_share_137l_rrtmg_standin : RRTMG_LW + RRTMG_SW on configs[4]'s per-GPU share, 388 800 columns x 137 layers (C720 tile / 8), McICA
+#                        clouds + aerosols.  configs[4] names the RRTMGP k-distribution path, whose source and coefficient files are not in
+#                        the reference repository: this leg is the RRTMG kernels at that size - the HBM-pressure / deep-atmosphere
+#                        stress, NOT an RRTMGP number.  The batch is 16 copies of 24 300 generated columns (columns are independent).
 # Each entry: value / ms_per_step from CFG_WARMUP + CFG_STEPS steps timed on the host around a device synchronisation; roofline of the leg's
 # dominant kernel (HIP-event launch duration from the same steps, algorithmic bytes of SURVEY 8(d), PMC traffic from a rocprofv3 child run of
 # `bench.py --configs-only`), a cpu_baseline from one pool over the host cores, in-run parity of CFG_PARITY columns against the oracle.
@@ -850,9 +858,11 @@ CFG_WARMUP, CFG_STEPS = 3, 5
 CFG_PARITY = 64
 CFG_CPU_COLS = 1024
 CFG_START = 30_000_000              # first global column of the configs' batch (disjoint from the headline batch and the CPU samples)
-CFG_NAMES = ("cfg1_lw_clear_100k", "cfg2_sw_noaer_100k", "cfg2_sorad_100k", "cfg2_irrad_100k", "cfg2_mcica_200")
-CFG_KERNEL = {"cfg1_lw_clear_100k": "k_lw_bands", "cfg2_sw_noaer_100k": "k_sw_reform", "cfg2_sorad_100k": "k_sorad_pass",
-              "cfg2_irrad_100k": "k_chou_bands", "cfg2_mcica_200": "k_mcica_sa"}
+CFG_NAMES = ("cfg0_irrad_1000_clear", "cfg1_lw_clear_100k", "cfg2_sw_noaer_100k", "cfg2_sorad_100k", "cfg2_irrad_100k", "cfg2_mcica_200",
+             "cfg4_c720_share_137l_rrtmg_standin")
+CFG0_NCOL = 1000
+CFG4_BASE, CFG4_TILES, CFG4_NLAY, CFG4_START = 24_300, 16, 137, 50_000_000          # 16 x 24 300 = 388 800 = 6 x 720^2 / 8
+CFG4_STEPS, CFG4_WARMUP = 3, 2
 IRRAD_IN = ("ple", "ta", "wa", "oa", "tb", "n2o", "ch4", "cfc11", "cfc12", "cfc22", "cwc", "fcld", "reff", "fs", "tg", "eg", "tv", "ev", "rv",
             "taua", "ssaa", "asya")
 IRRAD_OUT = ("flxu", "flcu", "flau", "flxau", "flxd", "flcd", "flad", "flxad", "dfdts")
@@ -862,6 +872,10 @@ SW_LAY = ["play", "plev", "tlay", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "o2vmr"
 
 def cfg_algorithmic_bytes(name, nlay=CFG_NLAY, nsub=CFG_NSUB, real_bytes=4):
     """compulsory bytes per column at the solver API: every input once + every output once"""
+    if name == "cfg0_irrad_1000_clear":
+        return 19476 * real_bytes // 4
+    if name == "cfg4_c720_share_137l_rrtmg_standin":          # the dominant kernel's solver: RRTMG_SW with aerosols at 137 layers
+        return algorithmic_bytes_sw(CFG4_NLAY, real_bytes, True)
     if name == "cfg1_lw_clear_100k":
         return algorithmic_bytes_lw(nlay, real_bytes, False)               # 7 608 @72 layers
     if name == "cfg2_sw_noaer_100k":
@@ -932,11 +946,25 @@ def _cfg_cpu_worker(args):
         t0 = time.perf_counter(); reflib.mcica(*a, kind="r4"); t["cfg2_mcica_200"] = time.perf_counter() - t0
     else:
         t0 = time.perf_counter(); clib.mcica(*a, prec="f32"); t["cfg2_mcica_200"] = time.perf_counter() - t0
+    # configs[0]: irrad on clear-sky columns (the clear batch in Chou units)
+    ch0 = synth.chou_lw_inputs(clr, aerosol=False)
+    t0 = time.perf_counter(); clib.irrad(ch0, "f32"); t["cfg0_irrad_1000_clear"] = time.perf_counter() - t0
+    # configs[4] stand-in: RRTMG LW + SW at 137 layers on half as many columns
+    n4 = max(64, n // 2)
+    deep = synth.make_columns(n4, CFG4_NLAY, start=start, cloudy_frac=0.6, aerosol=True)
+    t0 = time.perf_counter()
+    if ref:
+        reflib.set_inhomogeneity(1, "r4"); reflib.rrtmg_lw(deep, "r4", psize=4)
+    else:
+        clib.set_inhomogeneity(1, "f32"); clib.rrtmg_lw(deep, "f32")
+    clib.set_inhomogeneity(1, "f32")
+    clib.rrtmg_sw(deep, prec="f32", iaer=10, normFlx=1)
+    t["cfg4_c720_share_137l_rrtmg_standin"] = (time.perf_counter() - t0) * (n / n4)          # per n columns, like the other legs
     return t
 
 
 def configs_cpu_baseline(per_core=CFG_CPU_COLS):
-    """one pool over the host cores, every process runs the five configs on its own `per_core` columns"""
+    """one pool over the host cores, every process runs every leg on its own `per_core` columns"""
     import multiprocessing as mp
     from oracle import reflib
     ref = reflib.available("r4")
@@ -948,7 +976,10 @@ def configs_cpu_baseline(per_core=CFG_CPU_COLS):
             "cfg2_sorad_100k": ("port", "sorad = plain-C oracle (sorad.F90 needs MAPL: unbuildable here)"),
             "cfg2_irrad_100k": ("port", "irrad = plain-C oracle (irrad.F90 needs MAPL: unbuildable here)"),
             "cfg2_mcica_200": ("reference" if ref else "port", f"generate_stochastic_clouds(nsubcol={CFG_NSUB}) = "
-                               + ("reference Fortran (oracle/_ref)" if ref else "plain-C oracle"))}
+                               + ("reference Fortran (oracle/_ref)" if ref else "plain-C oracle")),
+            "cfg0_irrad_1000_clear": ("port", "irrad = plain-C oracle (irrad.F90 needs MAPL: unbuildable here), clear-sky columns"),
+            "cfg4_c720_share_137l_rrtmg_standin": ("port", f"{CFG4_NLAY} layers, half the columns per process: rrtmg_lw = "
+                                                   + ("reference Fortran" if ref else "plain-C oracle") + ", rrtmg_sw = plain-C oracle")}
     out = {}
     for name in CFG_NAMES:
         busy = max(p[name] for p in per); mean = sum(p[name] for p in per) / len(per)
@@ -959,7 +990,7 @@ def configs_cpu_baseline(per_core=CFG_CPU_COLS):
 
 
 def configs_gpu(dev, local_rank, start, ncol, warmup, steps, cache=None, want_parity=True, only=None):
-    """the five configuration legs on the device, one after the other, one stream; returns {name: {...}} with the leg's timings, the
+    """the configuration legs on the device, one after the other, one stream; returns {name: {...}} with the leg's timings, the
     profile of its kernels and (want_parity) the first CFG_PARITY columns of its outputs"""
     import torch
     from geosradiation_gridcomp_amd.api import Context
@@ -1063,6 +1094,55 @@ def configs_gpu(dev, local_rank, start, ncol, warmup, steps, cache=None, want_pa
         run("cfg2_mcica_200", lambda: ctx.generate_stochastic_clouds_dev(stream, ncol, CFG_NSUB, nlay, ptr, doy, 1e-20),
             "k_mcica_sa", lambda: {k: d[k][:ns].cpu().numpy() for k in ("cldy_stoch", "ciwp_stoch", "clwp_stoch")})
         del d, ptr
+    # ---- configs[0]: irrad, 1 000 clear-sky columns (its own size; value = columns of THIS leg / time) ----------------------------------
+    if only is None or "cfg0_irrad_1000_clear" in only:
+        from geosradiation_gridcomp_amd import synth
+        n0 = min(CFG0_NCOL, ncol)
+        ch0 = synth.chou_lw_inputs({k: (np.ascontiguousarray(v[..., :n0]) if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol else v)
+                                    for k, v in clr.items()}, aerosol=False)
+        d = {k: to(ch0[k]) for k in IRRAD_IN}
+        for k in IRRAD_OUT:
+            d[k] = zeros(nlay + 1, n0)
+        d["sfcem"] = zeros(n0); d["taudiag"] = zeros(10, nlay, n0)
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+        ncol_save, ncol = ncol, n0          # run() reports columns / time of the leg's own batch
+        run("cfg0_irrad_1000_clear", lambda: ctx.irrad_dev(stream, n0, nlay, ptr, ch0["co2"], True, ch0["ict"], ch0["icb"], ch0["ns"], ch0["na"], ch0["nb"]),
+            "k_chou_bands", lambda: {k: d[k][..., :min(ns, n0)].cpu().numpy() for k in ("flxu", "flxd", "flcu", "flcd")})
+        res["cfg0_irrad_1000_clear"]["columns"] = n0
+        ncol = ncol_save
+        del d, ptr
+    # ---- configs[4] stand-in: RRTMG LW + SW, 388 800 columns x 137 layers (16 copies of 24 300 generated columns), one stream ------------
+    if (only is None or "cfg4_c720_share_137l_rrtmg_standin" in only) and ncol == CFG_NCOL:
+        from geosradiation_gridcomp_amd import synth
+        deep = _cache_get(cache, "cfg4")
+        if deep is None:
+            deep = synth.make_columns(CFG4_BASE, CFG4_NLAY, start=CFG4_START, cloudy_frac=0.6, aerosol=True)
+        n4, l4 = CFG4_BASE * CFG4_TILES, CFG4_NLAY
+        tile = lambda v: to(v).repeat(*([1] * (np.ndim(v) - 1)), CFG4_TILES)
+        names = ["play", "plev", "tlay", "tlev", "tsfc", "emis", "zm", "alat", "tauaer"] + LW_IN2D + SW_IN + SW_AER
+        d = {k: tile(deep[k]) for k in names}
+        for k in ("uflx", "dflx", "uflxc", "dflxc", "duflx_dTs", "duflxc_dTs") + PARITY_SW:
+            d[k] = zeros(l4 + 1, n4)
+        for k in SW_OUT1:
+            d[k] = zeros(n4)
+        d["fswband"] = zeros(14, n4)
+        d["clearCounts"] = torch.zeros((4, n4), device=dev, dtype=torch.int32)
+        d["clearCounts_sw"] = torch.zeros((4, n4), device=dev, dtype=torch.int32)
+        ptr = {k: v.data_ptr() for k, v in d.items()}
+        ctx.set_inhomogeneity(1)
+        doy4, lm4, mh4 = int(deep["dyofyr"]), int(deep["cloudLM"]), int(deep["cloudMH"])
+
+        def deep_step():
+            ctx.rrtmg_lw_dev(stream, n4, l4, True, ptr, 3, 1, doy4, lm4, mh4)
+            ctx.rrtmg_sw_dev(stream, n4, l4, 1361.0, 1.0, 0, ptr, 3, 1, doy4, 10, lm4, mh4, normFlx=1)
+        ncol_save, nlay_save, ncol = ncol, nlay, n4
+        w_save, s_save = warmup, steps
+        warmup, steps = min(warmup, CFG4_WARMUP), min(steps, CFG4_STEPS)
+        run("cfg4_c720_share_137l_rrtmg_standin", deep_step, SW_BAND_KERNELS,
+            lambda: {k: d[k][..., :ns].cpu().numpy() for k in PARITY_LW + PARITY_SW + ("clearCounts", "clearCounts_sw")})
+        res["cfg4_c720_share_137l_rrtmg_standin"].update(columns=n4, layers=l4, steps=steps, warmup=warmup)
+        ncol, nlay, warmup, steps = ncol_save, nlay_save, w_save, s_save
+        del d, ptr
     ctx.close()
     torch.cuda.empty_cache()
     return res
@@ -1071,6 +1151,7 @@ def configs_gpu(dev, local_rank, start, ncol, warmup, steps, cache=None, want_pa
 def configs_parity(res, start):
     """CFG_PARITY columns of every leg's output against oracle/liboracle.so (the checker; single-threaded, after the timed regions)"""
     from oracle import clib
+    from geosradiation_gridcomp_amd import synth
     ns = CFG_PARITY
     clr, cld, ch, cs = cfg_inputs(ns, start)
     clib.lib()
@@ -1105,6 +1186,28 @@ def configs_parity(res, start):
         o = clib.irrad(ch, "f32")
         out["cfg2_irrad_100k"] = {"columns": ns, "max_abs_Wm2": max(float(np.abs(f64(g[k]) - f64(o[k])).max()) for k in g),
                                   "tolerance_Wm2": 2e-2, "oracle": "oracle/liboracle.so (f32), parity unpinned (irrad.F90 needs MAPL)"}
+    g = res.get("cfg0_irrad_1000_clear", {}).get("sample")
+    if g:
+        o = clib.irrad(synth.chou_lw_inputs(clr, aerosol=False), "f32")
+        out["cfg0_irrad_1000_clear"] = {"columns": ns, "max_abs_Wm2": max(float(np.abs(f64(g[k]) - f64(o[k])).max()) for k in g),
+                                        "tolerance_Wm2": 2e-2, "oracle": "oracle/liboracle.so (f32), parity unpinned (irrad.F90 needs MAPL)"}
+    g = res.get("cfg4_c720_share_137l_rrtmg_standin", {}).get("sample")
+    if g:
+        deep = synth.make_columns(ns, CFG4_NLAY, start=CFG4_START, cloudy_frac=0.6, aerosol=True)
+        clib.set_inhomogeneity(1, "f32")
+        o = clib.rrtmg_lw(deep, "f32")
+        q = clib.rrtmg_sw(deep, prec="f32", iaer=10, normFlx=1)
+        clib.set_inhomogeneity(0, "f32")
+        same_l = (g["clearCounts"] == o["clearCounts"]).all(axis=0); same_s = (g["clearCounts_sw"] == q["clearCounts"]).all(axis=0)
+        e_lw = max(float(np.abs(f64(g[k]) - f64(o[k]))[:, (same_l if not k.endswith("c") else np.ones(ns, bool))].max()) for k in PARITY_LW)
+        rel = np.zeros(ns)
+        for k in PARITY_SW:
+            dk = np.abs(f64(g[k]) - f64(q[k])).max(axis=0)
+            rel = np.maximum(rel, dk if k.endswith("c") else np.where(same_s, dk, 0.0))
+        out["cfg4_c720_share_137l_rrtmg_standin"] = {"columns": ns, "lw_max_abs_Wm2": e_lw, "sw_max_rel_toa": float(rel.max()),
+                                                     "tolerance": {"lw_max_abs_Wm2": 4e-3, "sw_max_rel_toa": 5e-3},
+                                                     "columns_with_other_clearCounts": int((~same_l).sum() + (~same_s).sum()),
+                                                     "oracle": "oracle/liboracle.so (f32) at 137 layers: LW pinned to the reference, SW two-stream parity unpinned"}
     g = res.get("cfg2_mcica_200", {}).get("sample")
     if g:
         clib.set_inhomogeneity(1, "f32")
@@ -1119,16 +1222,17 @@ def configs_parity(res, start):
 
 
 def configs_only(a, local_rank):
-    """`bench.py --configs-only`: the five legs alone (what the rocprofv3 child runs of the default line execute; also the command behind
+    """`bench.py --configs-only [--configs-legs ...]`: the legs alone (what the rocprofv3 child runs of the default line execute; also the command behind
     profiles/r04_configs_kernel_stats.csv)"""
     import torch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    res = configs_gpu(dev, local_rank, CFG_START, CFG_NCOL, a.warmup, a.steps, a.inputs_cache or None, want_parity=False)
+    only = [x for x in a.configs_legs.split(",") if x] or None
+    res = configs_gpu(dev, local_rank, CFG_START, CFG_NCOL, a.warmup, a.steps, a.inputs_cache or None, want_parity=False, only=only)
     print(json.dumps({"configs": configs_assemble(res, None, None, None, CFG_NCOL, a.steps, a.warmup)}))
 
 
-def configs_assemble(res, parity, cpu, live, ncol, steps, warmup):
+def configs_assemble(res, parity, cpu, live, ncol_default, steps_default, warmup_default, live2=None):
     """the `configs` object of the bench line"""
     out = {}
     for name in CFG_NAMES:
@@ -1136,16 +1240,17 @@ def configs_assemble(res, parity, cpu, live, ncol, steps, warmup):
         if r is None:
             continue
         kern = r["kernel"]
+        ncol, steps, warmup = r.get("columns", ncol_default), r.get("steps", steps_default), r.get("warmup", warmup_default)
         abytes = cfg_algorithmic_bytes(name)
         lps = max(r["kernel_launches_per_step"], 1e-9)
         launch_s = r["kernel_ms_per_step"] / lps * 1e-3
         achieved = abytes * (ncol / lps) / launch_s / 1e9 if launch_s > 0 else 0.0
-        t = (live or {}).get(kern)
+        t = ((live2 if name in (CFG_NAMES[0], CFG_NAMES[6]) else live) or {}).get(kern)
         e = {"value": r["value"], "unit": "columns/s", "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup, "columns": ncol,
-             "layers": CFG_NLAY, "dtype": "u32 (KISS) + f32" if name == "cfg2_mcica_200" else "f32",
+             "layers": r.get("layers", CFG_NLAY), "dtype": "u32 (KISS) + f32" if name == "cfg2_mcica_200" else "f32",
              "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                           "traffic": None if t is None else t["traffic_bytes"] / lps,
-                          "traffic_source": None if t is None else "measured in this run: rocprofv3 --pmc child runs of `bench.py --configs-only` (3 steps per config, same columns)",
+                          "traffic_source": None if t is None else "measured in this run: rocprofv3 --pmc child runs of `bench.py --configs-only --configs-legs ...` (3 steps per leg, same columns)",
                           "algorithmic_bytes_per_column": abytes, "avg_launch_ms": r["kernel_ms_per_step"] / lps,
                           "launches_per_step": r["kernel_launches_per_step"], "columns_per_launch": ncol / lps},
              "kernels_ms_per_step": r["kernels_ms_per_step"], "cpu_baseline": (cpu or {}).get(name), "parity": (parity or {}).get(name)}
@@ -1190,7 +1295,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="default line (lwsw, N = 1): skip the `configs` object - BASELINE configs[1] / [2] (RRTMG_LW clear-sky; RRTMG_SW + sorad + "
                          "irrad + the 200-sub-column generator; 100 000 columns each) timed after the headline's legs")
-    ap.add_argument("--configs-only", action="store_true", help="run only the five configuration legs (the PMC child of the default line)")
+    ap.add_argument("--configs-only", action="store_true", help="run only the configuration legs (the PMC child of the default line)")
+    ap.add_argument("--configs-legs", default="", help="with --configs-only: comma list of legs (default: all)")
     ap.add_argument("--inputs-cache", default="", help="internal: directory with the parent run's generated inputs (np.save files)")
     ap.add_argument("--control-path-only", action="store_true",
                     help="no GPU work: launcher, rank -> shard, barrier, MAX over ranks and rank 0's JSON line only (CPU rehearsal / tests)")
@@ -1224,7 +1330,7 @@ def main():
                 and not a.no_configs and not a.host_api and not os.environ.get("GEOSRAD_BENCH_SORTED_CLOUDS"))
     want_pmc = (rank == 0 and a.gpus == 1 and world == 1 and not a.no_pmc and a.scheme in ("lwsw", "lw", "sw", "chou", "irrad", "sorad")
                 and not under_profiler())
-    live = live_cfg = cache = None
+    live = live_cfg = live_cfg2 = cache = None
     inp_main = None
     if want_pmc and not a.inputs_cache:
         # the generated inputs are written once (np.save, memory-backed directory) and mapped by the rocprofv3 child runs and by this process,
@@ -1252,6 +1358,7 @@ def main():
                 _cache_put(cache, "cfg", {**{"clr_" + k: v for k, v in clr.items()}, **{"cld_" + k: v for k, v in cld.items()},
                                           **{"ch_" + k: v for k, v in ch.items()}, **{"cs_" + k: v for k, v in cs.items()}})
                 del clr, cld, ch, cs
+                _cache_put(cache, "cfg4", _synth.make_columns(CFG4_BASE, CFG4_NLAY, start=CFG4_START, cloudy_frac=0.6, aerosol=True))
         except OSError as e:          # no room: every process generates its own inputs (slower, same numbers)
             print("bench.py: inputs cache not used (%s)" % e, file=sys.stderr)
             if cache:
@@ -1261,8 +1368,9 @@ def main():
         cache = a.inputs_cache
     if want_pmc:
         live = live_counters(a, sys.argv[1:], cache)          # child processes, before this one touches the GPU
-        if want_cfg:
-            live_cfg = live_counters(a, sys.argv[1:], cache, configs=True)
+        if want_cfg:      # two sets of child runs: legs that share kernel names (irrad at two sizes; RRTMG at two sizes) must not share a run
+            live_cfg = live_counters(a, sys.argv[1:], cache, configs=True, legs=CFG_NAMES[1:6])
+            live_cfg2 = live_counters(a, sys.argv[1:], cache, configs=True, legs=(CFG_NAMES[0], CFG_NAMES[6]), mem_only=True)
     cpu = cpu_cfg = None
     if a.lit < 1.0:
         a.no_cpu = True           # the CPU leg times LW and SW on the same columns: not the --lit workload
@@ -1518,7 +1626,7 @@ def main():
             torch.cuda.empty_cache()
         cres = configs_gpu(dev, local_rank, CFG_START, CFG_NCOL, CFG_WARMUP, CFG_STEPS, cache, want_parity=not a.no_parity)
         cpar = configs_parity(cres, CFG_START) if not a.no_parity else None
-        cfg_out = configs_assemble(cres, cpar, cpu_cfg, live_cfg, CFG_NCOL, CFG_STEPS, CFG_WARMUP)
+        cfg_out = configs_assemble(cres, cpar, cpu_cfg, live_cfg, CFG_NCOL, CFG_STEPS, CFG_WARMUP, live2=live_cfg2)
 
     if rank == 0:
         total_cols = world * ncol * a.steps

@@ -95,3 +95,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert roof["kernel"] in ("k_sw_reform", "k_lw_bands") and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
     assert roof["achieved"] == pytest.approx(roof["algorithmic_bytes_per_column"] * roof["columns_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
     assert "configs" not in out and "cpu_baseline" in out
+
+
+@pytest.mark.gpu
+def test_bench_configs_legs_alone():
+    """`bench.py --configs-only --configs-legs ...` (what the default line's rocprofv3 child runs execute): two cheap legs, one JSON line with
+    a roofline per leg whose figures are consistent with each other."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--configs-only", "--configs-legs", "cfg0_irrad_1000_clear,cfg1_lw_clear_100k",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["configs"]
+    assert set(out) == {"cfg0_irrad_1000_clear", "cfg1_lw_clear_100k"}
+    for name, e in out.items():
+        roof = e["roofline"]
+        assert e["value"] == pytest.approx(e["columns"] / (e["ms_per_step"] * 1e-3), rel=1e-9) and e["steps"] == 2
+        assert roof["kernel"] == {"cfg0_irrad_1000_clear": "k_chou_bands", "cfg1_lw_clear_100k": "k_lw_bands"}[name]
+        assert roof["achieved"] == pytest.approx(roof["algorithmic_bytes_per_column"] * roof["columns_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-6)
+        assert 0 < roof["frac"] < 1 and roof["avg_launch_ms"] <= e["ms_per_step"]
+    assert out["cfg0_irrad_1000_clear"]["columns"] == 1000 and out["cfg1_lw_clear_100k"]["columns"] == 100_000

@@ -204,3 +204,25 @@ with open(os.path.join(d, "h", "1", "x_counter_collection.csv"), "w") as f:
     # a failing pass -> None (bench.py then quotes the committed figures and says so)
     fake.write_text("#!/bin/sh\\nexit 3\\n")
     assert bench.live_counters(a, []) is None
+
+
+def test_bench_inputs_cache_and_config_bytes(tmp_path):
+    """bench.py hands its generated inputs to its rocprofv3 child runs through np.save files (mapped read-only): arrays and scalars survive
+    the round trip; the algorithmic bytes of the `configs` legs are SURVEY 8(d)'s figures."""
+    import bench
+    from geosradiation_gridcomp_amd import synth
+    inp = synth.make_columns(5, 8, start=3, cloudy_frac=1.0, aerosol=True)
+    bench._cache_put(str(tmp_path), "main", inp)
+    got = bench._cache_get(str(tmp_path), "main")
+    assert set(got) == set(inp)
+    for k, v in inp.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1:
+            np.testing.assert_array_equal(np.asarray(got[k]), v)
+        else:
+            assert got[k] == int(v)
+    assert bench._cache_get(str(tmp_path), "absent") is None and bench._cache_get(None, "main") is None
+    assert bench.cfg_algorithmic_bytes("cfg1_lw_clear_100k") == 7608 and bench.cfg_algorithmic_bytes("cfg2_sw_noaer_100k") == 5356
+    assert bench.cfg_algorithmic_bytes("cfg2_sorad_100k") == 11904 and bench.cfg_algorithmic_bytes("cfg2_irrad_100k") == 19476
+    assert bench.cfg_algorithmic_bytes("cfg2_mcica_200") == 174244
+    assert bench.cfg_algorithmic_bytes("cfg4_c720_share_137l_rrtmg_standin") == bench.algorithmic_bytes_sw(137, 4, True)
+    assert len(bench.CFG_NAMES) == 7 and bench.cfg_algorithmic_bytes("cfg0_irrad_1000_clear") == 19476
