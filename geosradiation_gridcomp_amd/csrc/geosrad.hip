@@ -2457,7 +2457,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             hipLaunchKernelGGL(k_partition8, dim3(1), dim3(1024), 0, st, nc, (const uint8_t *)A.cls, A.perm, A.cls_off);
             if (!col_path) hipLaunchKernelGGL(k_sorad_gather<R>, dim3(gx, (unsigned)(3 * SO_NGATHER * np)), blk, 0, st, A);
             hipLaunchKernelGGL(k_sorad_prep<R>, dim3(gx), blk, 0, st, A);
-            hipLaunchKernelGGL(k_sorad_cloud<R>, dim3(gx, SO_NGRP), blk, 0, st, A, (const SoradDev<R> *)d_O);
+            hipLaunchKernelGGL(k_sorad_cloud<R>, dim3(gx, (unsigned)np), blk, 0, st, A, (const SoradDev<R> *)d_O);
             span_end(st);
             SoradOut<R> O{};
             auto Q = [&](int k) { return out[k] ? (R *)out[k] + c0 : (R *)nullptr; };

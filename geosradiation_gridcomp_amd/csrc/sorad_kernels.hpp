@@ -11,7 +11,7 @@
 //                    blocks are class-homogeneous (at most 7 mixed blocks) whatever the spatial distribution of the clouds
 //   k_sorad_gather : per (position, aerosol row) - the three aerosol arrays copied into position order (each is read by up to 10 passes)
 //   k_sorad_prep   : per position - scaled absorber amounts, cloud-group covers, cloud top
-//   k_sorad_cloud  : per (position, optics group: UV/PAR + 3 NIR bands) - getvistau / getnirtau
+//   k_sorad_cloud  : per (position, layer) - getvistau / getnirtau for the four optics groups (UV/PAR + 3 NIR bands)
 //   k_sorad_pass<CLS> : per (position, pass), lane = column, one instantiation per class - deledd of the clear / cloudy portion of every
 //                    layer, CLDFLX over exactly the class's sky situations; the per-level arrays of the pass in HBM scratch planes
 //                    [array][level][position] (coalesced); k_sorad_sum adds the passes up (default path)
@@ -214,16 +214,22 @@ __global__ void __launch_bounds__(256) k_sorad_prep(SoradArgs<R> A)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_sorad_cloud: getvistau (grp 0) / getnirtau (grp = NIR band 1..3), one thread per (column, group)
+// k_sorad_cloud: getvistau (group 0) / getnirtau (groups 1..3 = NIR bands), one thread per (position, layer): the layer's condensate and
+// radii are read once (through the permutation) for the four optics groups; layers of cloud groups the column's class lacks are skipped
+// (no pass reads their planes)
 // ---------------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const SoradDev<R> *__restrict__ Tp)
 {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ib = blockIdx.y;
+    const int k = (int)blockIdx.y + 1;
     if (pos >= A.m) return;
     if (pos < A.cls_off[1]) return;          // class 0: no cloud group holds cloud, no pass reads the cloud planes
     const int i = A.perm[pos];
+    {
+        const int c = A.cls[i];
+        if (!(k < A.ict ? (c & 4) : (k < A.icb ? (c & 2) : (c & 1)))) return;
+    }
     const SoradDev<R> &T = *Tp;
     const int np = A.np, ld = A.ld, m = A.m, K2 = np + 2, ict = A.ict, icb = A.icb;
     const R dm = (R)0.1, dt = (R)0.30103, da = (R)0.1, t1 = (R)-0.9031;
@@ -233,7 +239,7 @@ __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const Sorad
 #define CAIB(a, b, c) T.caib[(((c) - 1) * 9 + ((b) - 1)) * 11 + ((a) - 1)]
 #define CAIF(a, b) T.caif[((b) - 1) * 9 + ((a) - 1)]
 #define N2(tab, j) tab[((j) - 1) * 3 + (ib - 1)]
-    for (int k = 1; k <= np; k++) {
+    {
         const R dp_pa = A.lay[((size_t)0 * K2 + k) * m + pos] * (R)100.;
         const R wp = (dp_pa * (R)1.0e3) / (R)9.80665;                 // MAPL_GRAV
         const R r1 = A.reff[((size_t)0 * np + (k - 1)) * ld + i], r2 = A.reff[((size_t)1 * np + (k - 1)) * ld + i],
@@ -242,6 +248,7 @@ __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const Sorad
                 h3 = A.cwc[((size_t)2 * np + (k - 1)) * ld + i], h4 = A.cwc[((size_t)3 * np + (k - 1)) * ld + i];
         const R fc = A.fcld[(size_t)(k - 1) * ld + i];
         const R rs = r4 < (R)112.0 ? r4 : (R)112.0;
+        for (int ib = 0; ib < SO_NGRP; ib++) {
         R tc1, tc2, tc3, tc4;
         if (ib == 0) {
             tc1 = r1 <= 0 ? (R)0 : (wp * h1) * T.aib_uv / r1;
@@ -303,6 +310,7 @@ __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const Sorad
             }
         }
         CLD(0, k) = tb; CLD(1, k) = tf; CLD(2, k) = asy; CLD(3, k) = ssa;
+        }
     }
 #undef CLD
 #undef CAIB
