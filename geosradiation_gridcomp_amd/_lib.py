@@ -22,7 +22,7 @@ EXPORTS = [
     "geosrad_lw_driver_rrtmg_dev", "geosrad_sw_driver_rrtmg_dev", "geosrad_lw_update_flx_dev", "geosrad_sw_update_export_dev",
     "geosrad_rad_tendencies_dev", "geosrad_lw_chou_post_dev", "geosrad_sw_driver_chou_dev", "geosrad_rrtmg_lw_rats_dev", "geosrad_lw_driver_rrtmg_rats_dev", "geosrad_lw_update_rats_dev", "geosrad_lw_update_bands_dev", "geosrad_sw_update_surface_dev",
     "geosrad_set_tables_chou_sw", "geosrad_load_tables_chou_sw", "geosrad_sorad", "geosrad_sorad_dev",
-    "geosrad_read_table", "geosrad_rrtmg_sw_cldprmc", "geosrad_lit_index_dev", "geosrad_lit_pack_dev", "geosrad_lit_unpack_dev",
+    "geosrad_read_table", "geosrad_rrtmg_sw_cldprmc", "geosrad_lit_index_dev", "geosrad_lit_pack_dev", "geosrad_lit_unpack_dev", "geosrad_dbg_fast64",
 ]
 
 _lib = None

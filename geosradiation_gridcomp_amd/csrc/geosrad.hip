@@ -3282,6 +3282,30 @@ const char *geosrad_kernel_label(geosrad_ctx *c, int kernel_id)
 
 int geosrad_check(geosrad_ctx *c, void *stream) { return c ? c->check((hipStream_t)stream) : GEOSRAD_EINVAL; }
 
+// test hook: gr_div64 / gr_rcp64 / gr_sqrt64 (lw_kernels.hpp), the division / reciprocal / square root of the fp64 RRTMG_SW instantiation
+static __global__ void k_dbg_fast64(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ q,
+                                    double *__restrict__ r, double *__restrict__ s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { q[i] = geosrad::gr_div64(a[i], b[i]); r[i] = geosrad::gr_rcp64(b[i]); s[i] = geosrad::gr_sqrt64(b[i]); }
+}
+int geosrad_dbg_fast64(int n, const double *a, const double *b, double *quot, double *rcp, double *root)
+{
+    if (n <= 0 || !a || !b || !quot || !rcp || !root) return GEOSRAD_EINVAL;
+    double *d = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    if (hipMalloc(&d, 5 * nb) != hipSuccess) return GEOSRAD_EHIP;
+    int rc = GEOSRAD_OK;
+    if (hipMemcpy(d, a, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d + n, b, nb, hipMemcpyHostToDevice) != hipSuccess) rc = GEOSRAD_EHIP;
+    if (rc == GEOSRAD_OK) {
+        k_dbg_fast64<<<(n + 255) / 256, 256>>>(n, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n);
+        if (hipMemcpy(quot, d + 2 * (size_t)n, nb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(rcp, d + 3 * (size_t)n, nb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(root, d + 4 * (size_t)n, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = GEOSRAD_EHIP;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int geosrad_rrtmg_lw_taumol(geosrad_ctx *c, int ncol, int nlay, const void *play, const void *plev, const void *tlay, const void *tlev,
                             const void *tsfc, const void *emis, const void *h2ovmr, const void *o3vmr, const void *co2vmr,
                             const void *ch4vmr, const void *n2ovmr, const void *o2vmr, const void *cfc11vmr, const void *cfc12vmr,

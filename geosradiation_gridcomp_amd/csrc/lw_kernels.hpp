@@ -30,6 +30,47 @@ template <typename R> GR_DEV R gr_pow(R x, R y);
 template <> GR_DEV float gr_pow<float>(float x, float y) { return powf(x, y); }
 template <> GR_DEV double gr_pow<double>(double x, double y) { return pow(x, y); }
 
+// Double-precision division / reciprocal / square root for operands in the normal range (the optics: optical depths, albedos, cosines):
+// v_rcp_f64 / v_rsq_f64 refined by Newton steps and one residual correction - the sequence the IEEE expansion wraps in v_div_scale /
+// v_div_fmas / v_div_fixup (12 -> 8 instructions) and the library sqrt in range scaling and class tests (18 -> 9).  Not correctly rounded:
+// <= 1 ulp (tests/test_gpu_fastmath.py), against a parity bound of 1e-6 W m-2 that the fp64 instantiations meet at ~1e-9.
+#ifndef GR_FAST64
+#define GR_FAST64 1
+#endif
+GR_DEV double gr_rcp64(double b)
+{
+#if GR_FAST64
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return fma(fma(-b, r, 1.0), r, r);
+#else
+    return 1.0 / b;
+#endif
+}
+GR_DEV double gr_div64(double a, double b)
+{
+#if GR_FAST64
+    const double r = gr_rcp64(b), q = a * r;
+    return fma(fma(-b, q, a), r, q);
+#else
+    return a / b;
+#endif
+}
+GR_DEV double gr_sqrt64(double x)
+{
+#if GR_FAST64
+    if (x == 0.0) return 0.0;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return fma(fma(-g, g, x), h, g);
+#else
+    return sqrt(x);
+#endif
+}
+
 GR_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 constexpr int pad4(int n) { return (n + 3) & ~3; }

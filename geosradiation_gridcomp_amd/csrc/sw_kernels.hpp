@@ -360,16 +360,16 @@ GR_DEV void sw_eval(const SwDev<R> &T, const SwLayer<R> &L, const SwPrep<R> &P, 
 // Fast-path arithmetic of the fp32 instantiation: 1-ulp hardware reciprocal / sqrt / exp2 instead of the correctly rounded
 // (10-instruction) IEEE sequences.  The per-cell two-stream needs ~16 divisions, which made half of the instruction count;
 // the differences (<= 2 ulp per operation) are of the size of fp32 rounding itself and far inside the parity tolerance of
-// the fp32 path (tests/test_gpu_sw.py).  The fp64 instantiation keeps exact IEEE operations (parity <= 1e-6 W m-2).
+// the fp32 path (tests/test_gpu_sw.py).  The fp64 instantiation: exp from the library, division / sqrt by gr_div64 / gr_sqrt64 (<= 1 ulp; parity <= 1e-6 W m-2).
 template <typename R> GR_DEV R f_rcp(R x);
 template <> GR_DEV float f_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
-template <> GR_DEV double f_rcp<double>(double x) { return 1.0 / x; }
+template <> GR_DEV double f_rcp<double>(double x) { return gr_rcp64(x); }
 template <typename R> GR_DEV R f_div(R a, R b);
 template <> GR_DEV float f_div<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-template <> GR_DEV double f_div<double>(double a, double b) { return a / b; }
+template <> GR_DEV double f_div<double>(double a, double b) { return gr_div64(a, b); }
 template <typename R> GR_DEV R f_sqrt(R x);
 template <> GR_DEV float f_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
-template <> GR_DEV double f_sqrt<double>(double x) { return sqrt(x); }
+template <> GR_DEV double f_sqrt<double>(double x) { return gr_sqrt64(x); }
 template <typename R> GR_DEV R f_exp(R x);
 template <> GR_DEV float f_exp<float>(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 template <> GR_DEV double f_exp<double>(double x) { return exp(x); }

@@ -154,6 +154,11 @@ const char *geosrad_kernel_name(int kernel_id);      /* the slot's generic name 
  * (k_sw_reform | k_sw_bands, k_lw_bands | k_lw_cols, k_sorad_pass | k_sorad_col ...) */
 const char *geosrad_kernel_label(geosrad_ctx *ctx, int kernel_id);
 
+/* Test hook (host pointers, n doubles each): a / b, 1 / b and sqrt(b) as the fp64 RRTMG_SW instantiation evaluates them on the device
+ * (hardware reciprocal / reciprocal square root + Newton steps + a residual correction: <= 1 ulp for operands in the normal range;
+ * tests/test_gpu_fastmath.py). */
+int geosrad_dbg_fast64(int n, const double *a, const double *b, double *quot, double *rcp, double *root);
+
 /* Debug / test hooks: gas optical depth and Planck fraction as the reference's taumol leaves them,
  * Fortran (nlay,140,ncol), host pointers; ncol*nlay*140 reals each.  Uses the same kernels as
  * geosrad_rrtmg_lw with an extra store. */
