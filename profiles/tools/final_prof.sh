@@ -19,8 +19,10 @@ b bench_mcica --no-pmc --scheme mcica --no-cpu
 python3 bench.py --ranks-per-gpu 1,2,4,6 --steps 5 > $O/bench_ranks_per_gpu.json 2> $O/bench_ranks_per_gpu.err || echo ranks failed
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/stats_one -o x --output-format csv -- python3 bench.py --no-pmc --no-cpu --no-parity --no-configs --no-overlap --steps 5 --warmup 2 > $O/stats_one.log 2>&1 || echo stats_one failed
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/stats_two -o x --output-format csv -- python3 bench.py --no-pmc --no-cpu --no-parity --no-configs --steps 5 --warmup 2 > $O/stats_two.log 2>&1 || echo stats_two failed
-# the five legs of the default line's `configs` object (BASELINE configs[1] / [2]), alone
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_cfg -o x --output-format csv -- python3 bench.py --configs-only --steps 5 --warmup 3 > $O/stats_cfg.log 2>&1 || echo stats_cfg failed
+# the legs of the default line's `configs` object, one rocprofv3 run per leg (kernels of one name run in several legs)
+for L in cfg0_irrad_1000_clear cfg1_lw_clear_100k cfg2_sw_noaer_100k cfg2_sorad_100k cfg2_irrad_100k cfg2_mcica_200 cfg4_c720_share_137l_rrtmg_standin; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/stats_$L -o x --output-format csv -- python3 bench.py --configs-only --configs-legs $L --steps 5 --warmup 3 > $O/stats_$L.log 2>&1 || echo stats_$L failed
+done
 P1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 P2="SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 pmc() { tag=$1; shift; i=0

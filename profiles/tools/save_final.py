@@ -10,8 +10,20 @@ for f in ("bench_lwsw", "bench_lwsw_one_stream", "bench_lwsw_host_api", "bench_l
     except OSError as e: print("missing", f, e)
 shutil.copy(f"{S}/stats_one/x_kernel_stats.csv", f"profiles/{RN}_final_lwsw_one_stream_kernel_stats.csv")
 shutil.copy(f"{S}/stats_two/x_kernel_stats.csv", f"profiles/{RN}_final_lwsw_two_streams_kernel_stats.csv")
+import csv, os
+rows = []            # per leg: the kernels above 1 % of the leg's GPU time (the whole files stay on the GPU box's scratch)
+for leg in ("cfg0_irrad_1000_clear", "cfg1_lw_clear_100k", "cfg2_sw_noaer_100k", "cfg2_sorad_100k", "cfg2_irrad_100k", "cfg2_mcica_200",
+            "cfg4_c720_share_137l_rrtmg_standin"):
+    try:
+        for r in csv.DictReader(open(f"{S}/stats_{leg}/x_kernel_stats.csv")):
+            if float(r["Percentage"]) >= 1.0 and "at::native" not in r["Name"]:
+                rows.append({"leg": leg, **r})
+    except OSError as e:
+        print("missing", leg, e)
+if rows:
+    with open(f"profiles/{RN}_configs_kernel_stats.csv", "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 try:
-    shutil.copy(f"{S}/stats_cfg/x_kernel_stats.csv", f"profiles/{RN}_configs_kernel_stats.csv")       # bench.py --configs-only: the five legs of the `configs` object
     shutil.copy(f"{S}/pcie.txt", f"profiles/{RN}_pcie.txt")
 except OSError as e:
     print("missing", e)
