@@ -126,33 +126,52 @@ template <typename R> GR_DEV R ch_plancd(const ChouDev<R> &T, int ibn, R t)
     return t * (t * (t * (t * d[4] + d[3]) + d[2]) + d[1]) + d[0];
 }
 
-// tablup (:1887-2011)
+// the table coordinates of tablup in the fp32 instantiation: hardware reciprocal and log2 (1 ulp) instead of the correctly rounded division and
+// the library log10 (~30 instructions per step of a table band); the interpolation is continuous across the cell boundaries they may move
+template <typename R> GR_DEV R ch_rcp(R x) { return (R)1.0 / x; }
+template <typename R> GR_DEV R ch_log10(R x) { return gr_log10<R>(x); }
+#ifndef CH_EXACT_COORD
+template <> GR_DEV float ch_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <> GR_DEV float ch_log10<float>(float x) { return __builtin_amdgcn_logf(x) * 0.30102999566398120f; }
+#endif
+
+// tablup (:1887-2011).  The 14 table entries around the cell (ip, iw) stay in registers (`tv`) and are gathered again only when the lane's
+// cell changes: along a row the accumulated amount s1 and its mean pressure move slowly on the tables' logarithmic axes, and 14 gathers of
+// 64 different addresses per step were what made the five table bands 1.7 x as slow as the k-distribution ones (profiles/r04_README.md)
 template <typename R>
 GR_DEV void ch_tablup(int nh, R dw, R p, R dt, R &s1, R &s2, R &s3, R w1, R p1, R dwe, R dpe, const R *__restrict__ c1,
-                      const R *__restrict__ c2, const R *__restrict__ c3, R &tran)
+                      const R *__restrict__ c2, const R *__restrict__ c3, R &tran, int &cell, R (&tv)[14])
 {
     constexpr int nx = CH_NX;
     s1 = s1 + dw; s2 = s2 + p * dw; s3 = s3 + dt * dw;
-    const R x1 = s1, x1c = (R)1.0 / s1, x2 = s2 * x1c, x3 = s3 * x1c;
-    R we = (gr_log10<R>(x1) - w1) * dwe, pe = (gr_log10<R>(x2) - p1) * dpe;
+    const R x1 = s1, x1c = ch_rcp<R>(s1), x2 = s2 * x1c, x3 = s3 * x1c;
+    R we = (ch_log10<R>(x1) - w1) * dwe, pe = (ch_log10<R>(x2) - p1) * dpe;
     we = we < (R)(nh - 1) ? we : (R)(nh - 1);
     pe = pe < (R)(nx - 1) ? pe : (R)(nx - 1);
     int iw = (int)(we + (R)1.0); iw = iw < nh - 1 ? iw : nh - 1; iw = iw > 2 ? iw : 2;
     const R fw = we - (R)(iw - 1);
     int ip = (int)(pe + (R)1.0); ip = ip < nx - 1 ? ip : nx - 1; ip = ip > 1 ? ip : 1;
     const R fp = pe - (R)(ip - 1);
+    const int cnow = iw * nx + ip;
+    if (cnow != cell) {
+        cell = cnow;
 #define CC(t, a, b) t[((b) - 1) * nx + ((a) - 1)]
-    const R pa = CC(c1, ip, iw - 1) + (CC(c1, ip + 1, iw - 1) - CC(c1, ip, iw - 1)) * fp;
-    const R pb = CC(c1, ip, iw) + (CC(c1, ip + 1, iw) - CC(c1, ip, iw)) * fp;
-    const R pc = CC(c1, ip, iw + 1) + (CC(c1, ip + 1, iw + 1) - CC(c1, ip, iw + 1)) * fp;
-    const R ax = ((pc + pa) * fw + (pc - pa)) * fw * (R)0.5 + pb * ((R)1. - fw * fw);
-    const R ba = CC(c2, ip, iw) + (CC(c2, ip + 1, iw) - CC(c2, ip, iw)) * fp;
-    const R bb = CC(c2, ip, iw + 1) + (CC(c2, ip + 1, iw + 1) - CC(c2, ip, iw + 1)) * fp;
-    const R t1 = ba + (bb - ba) * fw;
-    const R ca = CC(c3, ip, iw) + (CC(c3, ip + 1, iw) - CC(c3, ip, iw)) * fp;
-    const R cb = CC(c3, ip, iw + 1) + (CC(c3, ip + 1, iw + 1) - CC(c3, ip, iw + 1)) * fp;
-    const R t2 = ca + (cb - ca) * fw;
+        tv[0] = CC(c1, ip, iw - 1); tv[1] = CC(c1, ip + 1, iw - 1); tv[2] = CC(c1, ip, iw); tv[3] = CC(c1, ip + 1, iw);
+        tv[4] = CC(c1, ip, iw + 1); tv[5] = CC(c1, ip + 1, iw + 1);
+        tv[6] = CC(c2, ip, iw); tv[7] = CC(c2, ip + 1, iw); tv[8] = CC(c2, ip, iw + 1); tv[9] = CC(c2, ip + 1, iw + 1);
+        tv[10] = CC(c3, ip, iw); tv[11] = CC(c3, ip + 1, iw); tv[12] = CC(c3, ip, iw + 1); tv[13] = CC(c3, ip + 1, iw + 1);
 #undef CC
+    }
+    const R pa = tv[0] + (tv[1] - tv[0]) * fp;
+    const R pb = tv[2] + (tv[3] - tv[2]) * fp;
+    const R pc = tv[4] + (tv[5] - tv[4]) * fp;
+    const R ax = ((pc + pa) * fw + (pc - pa)) * fw * (R)0.5 + pb * ((R)1. - fw * fw);
+    const R ba = tv[6] + (tv[7] - tv[6]) * fp;
+    const R bb = tv[8] + (tv[9] - tv[8]) * fp;
+    const R t1 = ba + (bb - ba) * fw;
+    const R ca = tv[10] + (tv[11] - tv[10]) * fp;
+    const R cb = tv[12] + (tv[13] - tv[12]) * fp;
+    const R t2 = ca + (cb - ca) * fw;
     R xx = ax + (t1 + t2 * x3) * x3;
     xx = xx < (R)0.9999999 ? xx : (R)0.9999999;
     xx = xx > (R)0.0000001 ? xx : (R)0.0000001;
@@ -231,6 +250,7 @@ template <typename R> constexpr size_t chou_bands_lds_bytes(int np) { return CH_
 // running transmittance state of one lane (one k1)
 template <typename R> struct ChState {
     R th2o[6], tcon[3], tco2[6], tn2o[4], tch4[4], tcom[6], tf11, tf12, tf22, x1, x2, x3;
+    R tv[14]; int cell;          // ch_tablup: the table entries of the lane's current cell (a band has at most one table absorber)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -507,7 +527,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
         if (B.h2otable) {
             const R *ha = ibn == 1 ? T.h11 : (ibn == 2 ? T.h21 : T.h81), *hb = ibn == 1 ? T.h12 : (ibn == 2 ? T.h22 : T.h82),
                     *hc = ibn == 1 ? T.h13 : (ibn == 2 ? T.h23 : T.h83);
-            ch_tablup<R>(CH_NH, s_dw[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w11, T.p11, T.dwe, T.dpe, ha, hb, hc, trant);
+            ch_tablup<R>(CH_NH, s_dw[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w11, T.p11, T.dwe, T.dpe, ha, hb, hc, trant, S.cell, S.tv);
             if (B.conbnd) { S.tcon[0] = S.tcon[0] * EX(km, B.con_s); trant = trant * S.tcon[0]; }
         } else if (!B.b10bnd) {        // h2okdis :2017-2143
 #pragma unroll
@@ -530,8 +550,8 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             }
             trant = trant * trn;
         }
-        if (B.co2bnd) ch_tablup<R>(CH_NC, s_dco2[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w12, T.p12, T.dwe, T.dpe, T.c1, T.c2, T.c3, trant);
-        if (B.oznbnd) ch_tablup<R>(CH_NO, s_do3[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w13, T.p13, T.dwe, T.dpe, T.oo1, T.oo2, T.oo3, trant);
+        if (B.co2bnd) ch_tablup<R>(CH_NC, s_dco2[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w12, T.p12, T.dwe, T.dpe, T.c1, T.c2, T.c3, trant, S.cell, S.tv);
+        if (B.oznbnd) ch_tablup<R>(CH_NO, s_do3[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w13, T.p13, T.dwe, T.dpe, T.oo1, T.oo2, T.oo3, trant, S.cell, S.tv);
         if (full && trace) {
             if (B.n2obnd) {            // n2okdis :2148-2214, ch4kdis :2219-2282
                 R xc;
@@ -585,7 +605,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
         for (int q = 0; q < 6; q++) { S.th2o[q] = 1; S.tco2[q] = 1; S.tcom[q] = 1; }
 #pragma unroll
         for (int q = 0; q < 4; q++) { S.tn2o[q] = 1; S.tch4[q] = 1; }
-        S.tcon[0] = S.tcon[1] = S.tcon[2] = 1; S.tf11 = S.tf12 = S.tf22 = 1; S.x1 = S.x2 = S.x3 = 0;
+        S.tcon[0] = S.tcon[1] = S.tcon[2] = 1; S.tf11 = S.tf12 = S.tf22 = 1; S.x1 = S.x2 = S.x3 = 0; S.cell = -1;
     };
 
     // ---- P3: loop 1500 (:802-935): upward / downward emission of every single layer (lanes = layers) ------------------
@@ -632,17 +652,19 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                 layer_tran(km, true, S, trant);
                 taant = trant;
                 if (do_aer) { tranal = tranal * taer[km]; trant = trant * tranal; }
-                if (enn[km] >= (R)0.001) {                    // cldovlp :2513-2601
-                    R *c; int kx, kb, ke;
-                    if (km < ict) { c = &cldhi; kx = ncld0; kb = ict - kx; ke = ict - 1; }
-                    else if (km < icb) { c = &cldmd; kx = ncld1; kb = icb - kx; ke = icb - 1; }
-                    else { c = &cldlw; kx = ncld2; kb = np + 1 - kx; ke = np; }
-                    if (kx == 1 || *c == 0) *c = enn[km];
-                    else {
-                        R v = 0;
+                const R ekm = enn[km];
+                if (ekm >= (R)0.001) {                        // cldovlp :2513-2601
+                    // the group's value is picked and put back with selects: a pointer to one of the three locals would move them to scratch
+                    // memory (a load / store round trip per step, which was 30 % of a cloudy column's time)
+                    const int g = km < ict ? 0 : (km < icb ? 1 : 2);
+                    const int kx = g == 0 ? ncld0 : (g == 1 ? ncld1 : ncld2), ke = g == 0 ? ict - 1 : (g == 1 ? icb - 1 : np), kb = ke + 1 - kx;
+                    const R cur = g == 0 ? cldhi : (g == 1 ? cldmd : cldlw);
+                    R v = ekm;
+                    if (!(kx == 1 || cur == 0)) {
+                        v = 0;
                         for (int k = kb; k <= ke; k++) { const int j = icx[k]; if (j >= k1 && j <= km) v = enn[j] + tcld[j] * v; }
-                        *c = v;
                     }
+                    cldhi = g == 0 ? v : cldhi; cldmd = g == 1 ? v : cldmd; cldlw = g == 2 ? v : cldlw;
                 }
                 fclr = ((R)1.0 - cldhi) * ((R)1.0 - cldmd) * ((R)1.0 - cldlw);
                 if (tq == 0 && ibn != 10) {                   // first terms of Eqs. (8.15), (8.16)
@@ -711,7 +733,11 @@ __global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<
 {
     extern __shared__ __align__(16) unsigned char ch_smem[];
     const ChouDev<R> &T = *Tp;
+#ifdef CH_ONLY_BAND
+    switch (CH_ONLY_BAND - 1) {          // timing experiment: every block of the grid runs this band's body
+#else
     switch (blockIdx.y) {
+#endif
         case 0: chou_band_body<R, 1>(A, T, ch_smem); break;
         case 1: chou_band_body<R, 2>(A, T, ch_smem); break;
         case 2: chou_band_body<R, 3>(A, T, ch_smem); break;
