@@ -523,11 +523,19 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     __syncthreads();
 
     // ---- transmittance of layer km added to a lane's running state (shared by loops 1500 and 3000) -------------------
+    // the band's table constants, read once (inside the lambda they were scalar loads from *Tp in every step of loop 2000)
+    R fkw[6], gkw[18];
+#pragma unroll
+    for (int q = 0; q < 6; q++) fkw[q] = (!B.h2otable && !B.b10bnd) ? T.fkw[(ibn - 1) * 6 + q] : (R)0;
+#pragma unroll
+    for (int q = 0; q < 18; q++) gkw[q] = B.ne > 1 ? T.gkw[q] : (R)0;
+    const R tw1 = B.h2otable ? T.w11 : (B.co2bnd ? T.w12 : T.w13), tp1 = B.h2otable ? T.p11 : (B.co2bnd ? T.p12 : T.p13), tdwe = T.dwe, tdpe = T.dpe;
+    const R *const ha = B.h2otable ? (ibn == 1 ? T.h11 : (ibn == 2 ? T.h21 : T.h81)) : (B.co2bnd ? T.c1 : T.oo1);
+    const R *const hb = B.h2otable ? (ibn == 1 ? T.h12 : (ibn == 2 ? T.h22 : T.h82)) : (B.co2bnd ? T.c2 : T.oo2);
+    const R *const hc = B.h2otable ? (ibn == 1 ? T.h13 : (ibn == 2 ? T.h23 : T.h83)) : (B.co2bnd ? T.c3 : T.oo3);
     auto layer_tran = [&](int km, bool full, ChState<R> &S, R &trant) {
         if (B.h2otable) {
-            const R *ha = ibn == 1 ? T.h11 : (ibn == 2 ? T.h21 : T.h81), *hb = ibn == 1 ? T.h12 : (ibn == 2 ? T.h22 : T.h82),
-                    *hc = ibn == 1 ? T.h13 : (ibn == 2 ? T.h23 : T.h83);
-            ch_tablup<R>(CH_NH, s_dw[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w11, T.p11, T.dwe, T.dpe, ha, hb, hc, trant, S.cell, S.tv);
+            ch_tablup<R>(CH_NH, s_dw[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, tw1, tp1, tdwe, tdpe, ha, hb, hc, trant, S.cell, S.tv);
             if (B.conbnd) { S.tcon[0] = S.tcon[0] * EX(km, B.con_s); trant = trant * S.tcon[0]; }
         } else if (!B.b10bnd) {        // h2okdis :2017-2143
 #pragma unroll
@@ -535,7 +543,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             R trn = 0;
             if (B.ne <= 1) {
 #pragma unroll
-                for (int q = 0; q < 6; q++) trn = trn + T.fkw[(ibn - 1) * 6 + q] * S.th2o[q];
+                for (int q = 0; q < 6; q++) trn = trn + fkw[q] * S.th2o[q];
                 if (B.ne == 1) { S.tcon[0] = S.tcon[0] * EX(km, B.con_s); trn = trn * S.tcon[0]; }
             } else {
 #pragma unroll
@@ -544,14 +552,14 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                 for (int sb = 0; sb < 3; sb++) {
                     R s = 0;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) s = s + T.gkw[sb * 6 + q] * S.th2o[q];
+                    for (int q = 0; q < 6; q++) s = s + gkw[sb * 6 + q] * S.th2o[q];
                     trn = trn + s * S.tcon[sb];
                 }
             }
             trant = trant * trn;
         }
-        if (B.co2bnd) ch_tablup<R>(CH_NC, s_dco2[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w12, T.p12, T.dwe, T.dpe, T.c1, T.c2, T.c3, trant, S.cell, S.tv);
-        if (B.oznbnd) ch_tablup<R>(CH_NO, s_do3[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, T.w13, T.p13, T.dwe, T.dpe, T.oo1, T.oo2, T.oo3, trant, S.cell, S.tv);
+        if (B.co2bnd) ch_tablup<R>(CH_NC, s_dco2[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, tw1, tp1, tdwe, tdpe, ha, hb, hc, trant, S.cell, S.tv);
+        if (B.oznbnd) ch_tablup<R>(CH_NO, s_do3[km], s_pa[km], s_dt[km], S.x1, S.x2, S.x3, tw1, tp1, tdwe, tdpe, ha, hb, hc, trant, S.cell, S.tv);
         if (full && trace) {
             if (B.n2obnd) {            // n2okdis :2148-2214, ch4kdis :2219-2282
                 R xc;
@@ -643,16 +651,29 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             bd1 = bd[k1]; cd1 = cd[k1]; ad1 = ad[k1]; dd1 = dd[k1];
             if (k1 > 0) { bd0 = bd[k1 - 1]; cd0 = cd[k1 - 1]; ad0 = ad[k1 - 1]; dd0 = dd[k1 - 1]; }
         }
+        // the first terms of Eqs. (8.15), (8.16) (the reference adds them at k2 == k1 + 1, in front of that level pair's own term)
+        if (act && ibn != 10) {
+            aau = -au[k1]; acu = -cu[k1]; axu = -bu[k1]; axau = -du[k1];
+            const int k2 = k1 + 1;
+            const R f0 = flad[k2], f1 = flcd[k2], f2 = flxd[k2], f3 = flxad[k2];
+            flad[k2] = f0 + ad1; flcd[k2] = f1 + cd1; flxd[k2] = f2 + bd1; flxad[k2] = f3 + dd1;
+        }
+        __builtin_amdgcn_wave_barrier();
         const int tmax = np + 1 - k1b;                        // uniform: trip count of the lane with the smallest k1
         for (int tq = 0; tq < tmax; tq++) {
             const int k2 = k1 + 1 + tq;
             if (act && k2 <= np + 1) {
                 const int km = k2 - 1;
+                // every LDS operand of the step is requested here, in front of the arithmetic (the aerosol-free set too: without aerosols
+                // du == bu, au == cu, dd == bd, ad == cd and taant == trant, so the same expressions serve both cases and the step has no
+                // uniform branches that would cut the requests into round trips of their own)
+                const R ekm = enn[km], tae = taer[km];
+                const R bu0 = bu[k2 - 1], bu1 = bu[k2], du0 = du[k2 - 1], du1 = du[k2], cu0 = cu[k2 - 1], cu1 = cu[k2], au0 = au[k2 - 1], au1 = au[k2];
+                const R fxd = flxd[k2], fxad = flxad[k2], fcd = flcd[k2], fad = flad[k2];
                 taant = 1; trant = 1; fclr = 1;
                 layer_tran(km, true, S, trant);
                 taant = trant;
-                if (do_aer) { tranal = tranal * taer[km]; trant = trant * tranal; }
-                const R ekm = enn[km];
+                tranal = tranal * tae; trant = trant * tranal;          // taer == 1 without aerosols
                 if (ekm >= (R)0.001) {                        // cldovlp :2513-2601
                     // the group's value is picked and put back with selects: a pointer to one of the three locals would move them to scratch
                     // memory (a load / store round trip per step, which was 30 % of a cloudy column's time)
@@ -667,26 +688,24 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                     cldhi = g == 0 ? v : cldhi; cldmd = g == 1 ? v : cldmd; cldlw = g == 2 ? v : cldlw;
                 }
                 fclr = ((R)1.0 - cldhi) * ((R)1.0 - cldmd) * ((R)1.0 - cldlw);
-                if (tq == 0 && ibn != 10) {                   // first terms of Eqs. (8.15), (8.16)
-                    aau -= au[k1]; acu -= cu[k1]; axu -= bu[k1]; axau -= du[k1];
-                    flad[k2] += ad1; flcd[k2] += cd1; flxd[k2] += bd1; flxad[k2] += dd1;
+                {
+                    // products rounded before they are added, as the reference's `xx = ...; flux = flux + xx` does: a clear column's all-sky and
+                    // clear-sky fluxes stay bit-identical (fclr == 1), which a product fused into one of the two sums would break
+#pragma clang fp contract(off)
+                    const R xu = trant * (bu0 - bu1), xau = taant * (du0 - du1), xcu = trant * (cu0 - cu1), xaa = taant * (au0 - au1);
+                    axu = axu + xu * fclr;
+                    axau = axau + xau * fclr;
+                    acu = acu + xcu;
+                    aau = aau + xaa;
+                    const R xd = k1 == 0 ? -trant * bd1 : trant * (bd0 - bd1);
+                    const R xad = k1 == 0 ? -taant * dd1 : taant * (dd0 - dd1);
+                    const R xc = k1 == 0 ? -trant * cd1 : trant * (cd0 - cd1);
+                    const R xa = k1 == 0 ? -taant * ad1 : taant * (ad0 - ad1);
+                    flxd[k2] = fxd + xd * fclr;
+                    flxad[k2] = fxad + xad * fclr;
+                    flcd[k2] = fcd + xc;
+                    flad[k2] = fad + xa;
                 }
-                R xx = trant * (bu[k2 - 1] - bu[k2]);
-                axu = axu + xx * fclr;
-                if (do_aer) xx = taant * (du[k2 - 1] - du[k2]);
-                axau = axau + xx * fclr;
-                xx = trant * (cu[k2 - 1] - cu[k2]);
-                acu = acu + xx;
-                if (do_aer) xx = taant * (au[k2 - 1] - au[k2]);
-                aau = aau + xx;
-                xx = k1 == 0 ? -trant * bd1 : trant * (bd0 - bd1);
-                flxd[k2] = flxd[k2] + xx * fclr;
-                if (do_aer) xx = k1 == 0 ? -taant * dd1 : taant * (dd0 - dd1);
-                flxad[k2] = flxad[k2] + xx * fclr;
-                xx = k1 == 0 ? -trant * cd1 : trant * (cd0 - cd1);
-                flcd[k2] = flcd[k2] + xx;
-                if (do_aer) xx = k1 == 0 ? -taant * ad1 : taant * (ad0 - ad1);
-                flad[k2] = flad[k2] + xx;
             }
             // lanes touch distinct k2 within a step; between steps the block's ONE wavefront issues its LDS instructions in
             // program order and the LDS executes a wave's instructions in order, so a compiler-level barrier is all that is needed
