@@ -241,11 +241,24 @@ __host__ __device__ constexpr int ch_planes_max()
 #endif
 constexpr int CH_LPC = 64 / CH_CPW;
 // LDS bytes of one column of k_chou_bands for np layers (16-byte multiple), and of a block (CH_CPW columns)
+// LDS of one column: ONE array of np + 2 level records, the band's fields interleaved (bu bd cu cd au ad du dd | flxd flcd flad flxad |
+// enn tcld taer | icx | the band's exponentials and table paths).  A lane's accesses of a step are then one address register (its
+// level) + immediate offsets, instead of one address addition per array; the record length is odd, so the 64 lanes of a step (consecutive
+// levels) fall on different banks.
+constexpr int CH_F_FLUX = 8, CH_F_ENN = 12, CH_F_TCLD = 13, CH_F_TAER = 14, CH_F_ICX = 15, CH_F_EX = 16;
+__host__ __device__ constexpr int ch_nlf(int ibn) { return (CH_F_EX + ch_planes(ibn)) | 1; }
+__host__ __device__ constexpr int ch_nlf_max() { return (CH_F_EX + ch_planes_max()) | 1; }
 template <typename R> constexpr size_t ch_lds_bytes_col(int np)
 {
-    return (((size_t)((ch_planes_max() + 3) * (np + 1) + 12 * (np + 2)) * sizeof(R) + (size_t)(np + 1) * sizeof(int)) + 15) & ~(size_t)15;
+    return ((size_t)(np + 2) * ch_nlf_max() * sizeof(R) + 15) & ~(size_t)15;
 }
 template <typename R> constexpr size_t chou_bands_lds_bytes(int np) { return CH_CPW * ch_lds_bytes_col<R>(np); }
+
+// field F of the level records (see ch_lds_bytes_col): a[k] is record k's field
+template <typename T, int NLF, int F> struct ChFld {
+    T *b;
+    GR_DEV T &operator[](int k) const { return b[k * NLF + F]; }
+};
 
 // running transmittance state of one lane (one k1)
 template <typename R> struct ChState {
@@ -275,24 +288,25 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
     constexpr ChBand B = ch_band(IBN);
     const bool trace = A.trace != 0, do_aer = A.na > 0;
 
-    // ---- LDS carve-up ----------------------------------------------------------------------------------
+    // ---- LDS carve-up (ch_lds_bytes_col) ------------------------------------------------------------------
     ch_smem += (size_t)half * ch_lds_bytes_col<R>(np);
-    R *sp = reinterpret_cast<R *>(ch_smem);
-    auto take = [&](int n) { R *q = sp; sp += n; return q; };
+    R *const lv = reinterpret_cast<R *>(ch_smem);
+    constexpr int NLF = ch_nlf(IBN);
     constexpr bool TAB = B.h2otable || B.co2bnd || B.oznbnd;
-    R *ex = take(ch_nex(IBN) * K1);                       // ex[(j-1)*K1 + k]
-    R *s_pa = TAB ? take(K1) : nullptr, *s_dt = TAB ? take(K1) : nullptr;
-    R *s_dw = B.h2otable ? take(K1) : nullptr, *s_dco2 = B.co2bnd ? take(K1) : nullptr, *s_do3 = B.oznbnd ? take(K1) : nullptr;
-    sp = reinterpret_cast<R *>(ch_smem) + ch_planes_max() * K1;      // the rest sits at band-independent offsets
-    R *bu = take(K2), *bd = take(K2), *cu = take(K2), *cd = take(K2), *au = take(K2), *ad = take(K2), *du = take(K2), *dd = take(K2);
-    R *enn = take(K1), *tcld = take(K1), *taer = take(K1);
-    R *fdn = take(4 * K2);                                // flxd flcd flad flxad
+    constexpr int F_PA = CH_F_EX + ch_nex(IBN), F_DT = F_PA + 1, F_DW = F_PA + 2, F_DCO2 = F_DW + (B.h2otable ? 1 : 0), F_DO3 = F_DCO2 + (B.co2bnd ? 1 : 0);
+    const ChFld<R, NLF, 0> bu{lv}; const ChFld<R, NLF, 1> bd{lv}; const ChFld<R, NLF, 2> cu{lv}; const ChFld<R, NLF, 3> cd{lv};
+    const ChFld<R, NLF, 4> au{lv}; const ChFld<R, NLF, 5> ad{lv}; const ChFld<R, NLF, 6> du{lv}; const ChFld<R, NLF, 7> dd{lv};
+    const ChFld<R, NLF, CH_F_FLUX> flxd{lv}; const ChFld<R, NLF, CH_F_FLUX + 1> flcd{lv}; const ChFld<R, NLF, CH_F_FLUX + 2> flad{lv};
+    const ChFld<R, NLF, CH_F_FLUX + 3> flxad{lv};
+    const ChFld<R, NLF, CH_F_ENN> enn{lv}; const ChFld<R, NLF, CH_F_TCLD> tcld{lv}; const ChFld<R, NLF, CH_F_TAER> taer{lv};
+    const ChFld<int, NLF * (int)(sizeof(R) / sizeof(int)), CH_F_ICX * (int)(sizeof(R) / sizeof(int))> icx{reinterpret_cast<int *>(lv)};
+    const ChFld<R, NLF, F_PA> s_pa{lv}; const ChFld<R, NLF, F_DT> s_dt{lv}; const ChFld<R, NLF, F_DW> s_dw{lv};
+    const ChFld<R, NLF, F_DCO2> s_dco2{lv}; const ChFld<R, NLF, F_DO3> s_do3{lv};
     // the Planck fluxes of layers and levels are dead once loop 1500 has formed the layer emissions: they share the downward-flux
-    // accumulators' space (which are zeroed after it).  The per-k1 results of loop 2000 (4 upward fluxes, 4 transmittances,
+    // accumulators' fields (which are zeroed after it).  The per-k1 results of loop 2000 (4 upward fluxes, 4 transmittances,
     // dfdts) are parked in the band's `part` slots in HBM by the lane that reads them back in P5.
-    R *blayer = fdn, *blevel = fdn + K2;
-    int *icx = reinterpret_cast<int *>(sp);
-#define EX(k, j) ex[((j) - 1) * K1 + (k)]
+    const ChFld<R, NLF, CH_F_FLUX> blayer{lv}; const ChFld<R, NLF, CH_F_FLUX + 1> blevel{lv};
+#define EX(k, j) lv[(k) * NLF + (CH_F_EX - 1) + (j)]
 
     const R *rec = A.rec + (size_t)i * CF_NFIELD * K1;
 
@@ -633,12 +647,11 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
         ad[km] = dn; au[km] = up;
     }
     if (lane == 0) { bu[np + 1] = bs; au[np + 1] = bs; cu[np + 1] = bs; du[np + 1] = bs; }
-    for (int k = lane; k < 4 * K2; k += CH_LPC) fdn[k] = 0;
+    for (int k = lane; k < K2; k += CH_LPC) { flxd[k] = 0; flcd[k] = 0; flad[k] = 0; flxad[k] = 0; }
     __syncthreads();
     R *part = A.part + ((size_t)i * CH_NB + (ibn - 1)) * CH_NKIND * K2;
 
     // ---- P4: loop 2000 (:948-1290): lanes = k1, lock-step walk over k2 --------------------------------------------------
-    R *flxd = fdn, *flcd = fdn + K2, *flad = fdn + 2 * K2, *flxad = fdn + 3 * K2;
     const int ict = A.ict, icb = A.icb;
     for (int k1b = 0; k1b <= np; k1b += CH_LPC) {
         const int k1 = k1b + lane;
