@@ -135,6 +135,15 @@ template <> GR_DEV float ch_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x
 template <> GR_DEV float ch_log10<float>(float x) { return __builtin_amdgcn_logf(x) * 0.30102999566398120f; }
 #endif
 
+// a load through a pointer that was itself read from memory (the table pointers of *Tp): told to be global, or it becomes a flat load
+// with a 64-bit per-lane address
+template <typename T> GR_DEV T ch_ldg(const T *base, uint32_t byteoff)
+{
+    typedef const char __attribute__((address_space(1))) *gchar;
+    typedef const T __attribute__((address_space(1))) *gT;
+    return *(gT)((gchar)base + byteoff);
+}
+
 // tablup (:1887-2011).  The 14 table entries around the cell (ip, iw) stay in registers (`tv`) and are gathered again only when the lane's
 // cell changes: along a row the accumulated amount s1 and its mean pressure move slowly on the tables' logarithmic axes, and 14 gathers of
 // 64 different addresses per step were what made the five table bands 1.7 x as slow as the k-distribution ones (profiles/r04_README.md)
@@ -155,12 +164,12 @@ GR_DEV void ch_tablup(int nh, R dw, R p, R dt, R &s1, R &s2, R &s3, R w1, R p1, 
     const int cnow = iw * nx + ip;
     if (cnow != cell) {
         cell = cnow;
-#define CC(t, a, b) t[((b) - 1) * nx + ((a) - 1)]
-        tv[0] = CC(c1, ip, iw - 1); tv[1] = CC(c1, ip + 1, iw - 1); tv[2] = CC(c1, ip, iw); tv[3] = CC(c1, ip + 1, iw);
-        tv[4] = CC(c1, ip, iw + 1); tv[5] = CC(c1, ip + 1, iw + 1);
-        tv[6] = CC(c2, ip, iw); tv[7] = CC(c2, ip + 1, iw); tv[8] = CC(c2, ip, iw + 1); tv[9] = CC(c2, ip + 1, iw + 1);
-        tv[10] = CC(c3, ip, iw); tv[11] = CC(c3, ip + 1, iw); tv[12] = CC(c3, ip, iw + 1); tv[13] = CC(c3, ip + 1, iw + 1);
-#undef CC
+        // entry (a, b) of a Fortran (nx, n) table sits at (b - 1) nx + (a - 1): wave-uniform base + one per-lane byte offset + immediates
+        const uint32_t o = (uint32_t)(((iw - 2) * nx + (ip - 1)) * (int)sizeof(R)), r1 = nx * sizeof(R), r2 = 2 * nx * sizeof(R), e = sizeof(R);
+        tv[0] = ch_ldg(c1, o); tv[1] = ch_ldg(c1, o + e); tv[2] = ch_ldg(c1, o + r1); tv[3] = ch_ldg(c1, o + r1 + e);
+        tv[4] = ch_ldg(c1, o + r2); tv[5] = ch_ldg(c1, o + r2 + e);
+        tv[6] = ch_ldg(c2, o + r1); tv[7] = ch_ldg(c2, o + r1 + e); tv[8] = ch_ldg(c2, o + r2); tv[9] = ch_ldg(c2, o + r2 + e);
+        tv[10] = ch_ldg(c3, o + r1); tv[11] = ch_ldg(c3, o + r1 + e); tv[12] = ch_ldg(c3, o + r2); tv[13] = ch_ldg(c3, o + r2 + e);
     }
     const R pa = tv[0] + (tv[1] - tv[0]) * fp;
     const R pb = tv[2] + (tv[3] - tv[2]) * fp;
