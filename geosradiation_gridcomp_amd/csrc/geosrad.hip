@@ -1837,6 +1837,10 @@ template <typename R> struct Ctx : geosrad_ctx {
         HIPCHK(hipMalloc((void **)&d_tab_sw, tab_sw_bytes));
         HIPCHK(hipMemcpy(d_tab_sw, S.stage.data(), tab_sw_bytes, hipMemcpyHostToDevice));
         for (auto &f : S.fix) *f.first = (const R *)(d_tab_sw + f.second);
+        // sw_eval reaches a band's upper-atmosphere tables as the lower ones' base + a 32-bit byte offset (one allocation, staged in this order)
+        for (int b = 1; b <= NB_SW; b++)
+            if ((T.b[b].absb && T.b[b].absb < T.b[b].absa) || (T.b[b].x1 && T.b[b].x1 < T.b[b].x0) || tab_sw_bytes >= ((size_t)1 << 32))
+                return fail(GEOSRAD_ETABLE, "internal: RRTMG_SW table staging order");
         HIPCHK(hipMemcpy(d_S, &h_S, sizeof(SwDev<R>), hipMemcpyHostToDevice));
         have_sw = true;
         return GEOSRAD_OK;

@@ -358,10 +358,10 @@ template <typename R, int W> GR_DEV void ldw(const R *__restrict__ tab, uint32_t
 // byte offset of row r (0-based) of a [rows][S] table, columns go..go+W-1
 #define ROWB(r) (((uint32_t)(r) * (uint32_t)S + (uint32_t)go) * (uint32_t)sizeof(R))
 
-template <typename R, int W, int S, bool INIT> GR_DEV void axw(R (&acc)[W], R c, const R *__restrict__ tab, int row, int go)
+template <typename R, int W, int S, bool INIT> GR_DEV void axw(R (&acc)[W], R c, const R *__restrict__ tab, int row, int go, uint32_t byteoff = 0)
 {
     R r[W];
-    ldw<R, W>(tab, ROWB(row), r);
+    ldw<R, W>(tab, ROWB(row) + byteoff, r);
 #pragma unroll
     for (int j = 0; j < W; j++) acc[j] = INIT ? c * r[j] : acc[j] + c * r[j];
 }

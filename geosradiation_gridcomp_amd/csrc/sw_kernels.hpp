@@ -297,25 +297,28 @@ GR_DEV void sw_eval(const SwDev<R> &T, const SwLayer<R> &L, const SwPrep<R> &P, 
     R m[W];
 #pragma unroll
     for (int j = 0; j < W; j++) m[j] = 0;
+    // lower / upper atmosphere differ by lane: ONE wave-uniform base (absa) + the lane's byte offset, which carries the distance to absb for
+    // the upper lanes (both tables sit in the context's one table allocation, absa first: set_tables_sw).  A per-lane choice between the two
+    // POINTERS made every row a flat load with a 64-bit lane address behind a wait for everything in flight.
+    const R *tab = Bt.absa;
+    const uint32_t tsel = L.lower ? 0u : (uint32_t)(reinterpret_cast<const char *>(Bt.absb) - reinterpret_cast<const char *>(Bt.absa));
     if (kind == 2) {
-        const R *tab = L.lower ? Bt.absa : Bt.absb;
         const int off = L.lower ? 9 : 5;
         const R c0 = (R)1. - P.sp.fs, c1 = P.sp.fs;
         // reference order (:398-410): fac000 a(ind0) + fac100 a(ind0+1) + fac010 a(ind0+off) + fac110 a(ind0+off+1) + same for ind1
-        axw<R, W, S, true>(m, c0 * L.fac00, tab, P.ind0 - 1, go);
-        axw<R, W, S, false>(m, c1 * L.fac00, tab, P.ind0, go);
-        axw<R, W, S, false>(m, c0 * L.fac10, tab, P.ind0 - 1 + off, go);
-        axw<R, W, S, false>(m, c1 * L.fac10, tab, P.ind0 + off, go);
-        axw<R, W, S, false>(m, c0 * L.fac01, tab, P.ind1 - 1, go);
-        axw<R, W, S, false>(m, c1 * L.fac01, tab, P.ind1, go);
-        axw<R, W, S, false>(m, c0 * L.fac11, tab, P.ind1 - 1 + off, go);
-        axw<R, W, S, false>(m, c1 * L.fac11, tab, P.ind1 + off, go);
+        axw<R, W, S, true>(m, c0 * L.fac00, tab, P.ind0 - 1, go, tsel);
+        axw<R, W, S, false>(m, c1 * L.fac00, tab, P.ind0, go, tsel);
+        axw<R, W, S, false>(m, c0 * L.fac10, tab, P.ind0 - 1 + off, go, tsel);
+        axw<R, W, S, false>(m, c1 * L.fac10, tab, P.ind0 + off, go, tsel);
+        axw<R, W, S, false>(m, c0 * L.fac01, tab, P.ind1 - 1, go, tsel);
+        axw<R, W, S, false>(m, c1 * L.fac01, tab, P.ind1, go, tsel);
+        axw<R, W, S, false>(m, c0 * L.fac11, tab, P.ind1 - 1 + off, go, tsel);
+        axw<R, W, S, false>(m, c1 * L.fac11, tab, P.ind1 + off, go, tsel);
     } else if (kind == 1) {
-        const R *tab = L.lower ? Bt.absa : Bt.absb;
-        axw<R, W, S, true>(m, L.fac00, tab, P.ind0 - 1, go);
-        axw<R, W, S, false>(m, L.fac10, tab, P.ind0, go);
-        axw<R, W, S, false>(m, L.fac01, tab, P.ind1 - 1, go);
-        axw<R, W, S, false>(m, L.fac11, tab, P.ind1, go);
+        axw<R, W, S, true>(m, L.fac00, tab, P.ind0 - 1, go, tsel);
+        axw<R, W, S, false>(m, L.fac10, tab, P.ind0, go, tsel);
+        axw<R, W, S, false>(m, L.fac01, tab, P.ind1 - 1, go, tsel);
+        axw<R, W, S, false>(m, L.fac11, tab, P.ind1, go, tsel);
     }
     R cont[W];
 #pragma unroll
@@ -346,11 +349,11 @@ GR_DEV void sw_eval(const SwDev<R> &T, const SwLayer<R> &L, const SwPrep<R> &P, 
 #pragma unroll
         for (int j = 0; j < W; j++) tau[j] = tau[j] + L.col[G_CH4] * x[j];
     } else if constexpr (B::JB == 24 || B::JB == 25) {   // + colo3 * abso3a | abso3b (:1478,1513 / :1591,1602)
-        R x[W]; ldw<R, W>(L.lower ? Bt.x0 : Bt.x1, (uint32_t)go * (uint32_t)sizeof(R), x);
+        R x[W]; ldw<R, W>(Bt.x0, (uint32_t)go * (uint32_t)sizeof(R) + (L.lower ? 0u : (uint32_t)(reinterpret_cast<const char *>(Bt.x1) - reinterpret_cast<const char *>(Bt.x0))), x);
 #pragma unroll
         for (int j = 0; j < W; j++) tau[j] = tau[j] + L.col[G_O3] * x[j];
     } else if constexpr (B::JB == 29) {   // lower + colco2 * absco2, upper + colh2o * absh2o (:2031,2050)
-        R x[W]; ldw<R, W>(L.lower ? Bt.x0 : Bt.x1, (uint32_t)go * (uint32_t)sizeof(R), x);
+        R x[W]; ldw<R, W>(Bt.x0, (uint32_t)go * (uint32_t)sizeof(R) + (L.lower ? 0u : (uint32_t)(reinterpret_cast<const char *>(Bt.x1) - reinterpret_cast<const char *>(Bt.x0))), x);
         const R c = L.lower ? L.col[G_CO2] : L.col[G_H2O];
 #pragma unroll
         for (int j = 0; j < W; j++) tau[j] = tau[j] + c * x[j];
