@@ -69,7 +69,9 @@ __global__ void __launch_bounds__(64) k_chou_prep(ChouArgs<R> A)
     const int ncolb = (A.m - col0) < 64 ? (A.m - col0) : 64;
 #define AP(a, k) a[(size_t)((k) - 1) * ld + i]
 #define TL(f, kk) tile[((f) * CHP_KC + (kk)) * 65 + lane]
-    for (int k0 = 0; k0 <= np; k0 += CHP_KC) {
+    {   // blockIdx.y = the tile of CHP_KC levels (chou_prep_tiles(np) of them): a wavefront per (64 columns, tile) instead of one per 64
+        // columns walking the tiles - 10 x the wavefronts of what is a streaming kernel
+        const int k0 = (int)blockIdx.y * CHP_KC;
         const int nk = (np + 1 - k0) < CHP_KC ? (np + 1 - k0) : CHP_KC;
         if (act) {
             for (int kk = 0; kk < nk; kk++) {
@@ -108,11 +110,11 @@ __global__ void __launch_bounds__(64) k_chou_prep(ChouArgs<R> A)
                 for (int f = fg; f < CF_NFIELD; f += 64 / CHP_KC) rec[(size_t)f * K1] = tile[(f * CHP_KC + kk) * 65 + c];
             }
         }
-        __syncthreads();
     }
 #undef AP
 #undef TL
 }
+template <typename R> constexpr int chou_prep_tiles(int np) { return (np + 1 + 32 / (int)sizeof(R) - 1) / (32 / (int)sizeof(R)); }
 
 // planck / plancd (:1341-1376)
 template <typename R> GR_DEV R ch_planck(const ChouDev<R> &T, int ibn, R t)

@@ -379,6 +379,8 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
     // (0: no reflection, tt = ts = 1, td = td0) are the same for both portions and stay in registers
     const R rb = uv ? A.rsuvbm[col] : A.rsirbm[col], rd = uv ? A.rsuvdf[col] : A.rsirdf[col];
     const R td0 = uv ? gr_exp<R>(-(wvtoa * T.wk_uv[ib - 1] + o3toa * T.zk_uv[ib - 1]) / cz) : gr_exp<R>(-wvtoa * T.xk_ir[ik - 1] / cz);
+    // the pass's absorption / Rayleigh coefficients, read once (inside the layer loop they were scalar loads from *Tp per layer)
+    const R k_ry = uv ? T.ry_uv[ib - 1] : T.ry_ir[ib - 1], k_zk = uv ? T.zk_uv[ib - 1] : (R)0, k_wk = uv ? T.wk_uv[ib - 1] : T.xk_ir[ik - 1];
     // ---- layers: clear and cloudy portion (:436-520, 996-1068) ---------------------------------------------------------
     struct In6 { R dp, wh, oh, ta, sa, as; };
     // aerosols: the three NIR bands are read by ten passes each - from the position-ordered copies (k_sorad_gather); the five UV / PAR
@@ -411,12 +413,12 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         const R dp = cin.dp, wh = cin.wh, oh = cin.oh, ta_ = cin.ta, sa_ = cin.sa, as_ = cin.as;
         R taurs, tausto, ssatau;
         if (uv) {
-            taurs = T.ry_uv[ib - 1] * dp;
-            tausto = taurs + T.zk_uv[ib - 1] * oh + T.wk_uv[ib - 1] * wh + ta_ + (R)1.0e-7;
+            taurs = k_ry * dp;
+            tausto = taurs + k_zk * oh + k_wk * wh + ta_ + (R)1.0e-7;
             ssatau = sa_ + taurs;
         } else {
-            taurs = T.ry_ir[ib - 1] * dp;
-            tausto = taurs + T.xk_ir[ik - 1] * wh + ta_ + (R)1.0e-7;
+            taurs = k_ry * dp;
+            tausto = taurs + k_wk * wh + ta_ + (R)1.0e-7;
             ssatau = sa_ + taurs + (R)1.0e-8;
         }
         const R asysto = as_;
