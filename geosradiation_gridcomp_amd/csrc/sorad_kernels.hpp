@@ -329,10 +329,20 @@ __global__ void __launch_bounds__(256) k_sorad_cloud(SoradArgs<R> A, const Sorad
 // ---------------------------------------------------------------------------------------------------
 template <typename R> struct SoL5 { R rr, tt, td, rs, ts; };
 
+// the divisions of the adding equations and of the layers' mixed optical properties (~20 per level and pass in a class-7 column): hardware
+// reciprocal (1 ulp) in the fp32 instantiation, v_rcp_f64 + Newton steps (gr_div64) in the fp64 one, instead of the correctly rounded
+// expansions (10 / 12 instructions each).  deledd keeps the reference's fp64 arithmetic as it is.
+#ifndef SO_EXACT_DIV
+GR_DEV float so_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+GR_DEV double so_div(double a, double b) { return gr_div64(a, b); }
+#else
+template <typename R> GR_DEV R so_div(R a, R b) { return a / b; }
+#endif
+
 // one adding step from the surface: layer l above the composite (rra, rxa) (sorad.F90:751-768, 789-806, 825-842)
 template <typename R> GR_DEV void so_add_up(const SoL5<R> &l, R &rra, R &rxa)
 {
-    const R denm = l.ts / ((R)1. - l.rs * rxa);
+    const R denm = so_div(l.ts, (R)1. - l.rs * rxa);
     const R nrra = l.rr + (l.td * rra + (l.tt - l.td) * rxa) * denm;
     rxa = l.rs + l.ts * rxa * denm; rra = nrra;
 }
@@ -340,7 +350,7 @@ template <typename R> GR_DEV void so_add_up(const SoL5<R> &l, R &rra, R &rxa)
 // term as tda * rsa * rr above the low group and tda * rr * rsa inside it
 template <typename R, bool LOW> GR_DEV void so_add_down(const SoL5<R> &l, R &tda, R &tta, R &rsa)
 {
-    const R denm = l.ts / ((R)1. - rsa * l.rs);
+    const R denm = so_div(l.ts, (R)1. - rsa * l.rs);
     const R ntta = LOW ? tda * l.tt + (tda * l.rr * rsa + tta - tda) * denm : tda * l.tt + (tda * rsa * l.rr + tta - tda) * denm;
     const R nrsa = l.rs + l.ts * rsa * denm;
     tda = tda * l.td; tta = ntta; rsa = nrsa;
@@ -422,7 +432,7 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
             ssatau = sa_ + taurs + (R)1.0e-8;
         }
         const R asysto = as_;
-        R tautob = tausto, asytob = asysto / ssatau, ssatob = ssatau / tautob + (R)1.0e-8;
+        R tautob = tausto, asytob = so_div(asysto, ssatau), ssatob = so_div(ssatau, tautob) + (R)1.0e-8;
         ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
         R dum;
         so_deledd<R>(tautob, ssatob, asytob, cz, l1.rr, l1.tt, l1.td);
@@ -430,13 +440,13 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
         if (cloudy) {
             const R tcb = cl.tcb, tcf = cl.tcf, asyc = cl.asyc, ssac = cl.ssac;
             tautob = tausto + tcb;
-            ssatob = (uv ? (ssatau + tcb) : (ssatau + ssac * tcb)) / tautob + (R)1.0e-8;
+            ssatob = so_div(uv ? (ssatau + tcb) : (ssatau + ssac * tcb), tautob) + (R)1.0e-8;
             ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
-            asytob = (uv ? (asysto + asyc * tcb) : (asysto + asyc * ssac * tcb)) / (ssatob * tautob);
+            asytob = so_div(uv ? (asysto + asyc * tcb) : (asysto + asyc * ssac * tcb), ssatob * tautob);
             const R tautof = tausto + tcf;
-            R ssatof = (uv ? (ssatau + tcf) : (ssatau + ssac * tcf)) / tautof + (R)1.0e-8;
+            R ssatof = so_div(uv ? (ssatau + tcf) : (ssatau + ssac * tcf), tautof) + (R)1.0e-8;
             ssatof = ssatof < (R)0.999999 ? ssatof : (R)0.999999;
-            const R asytof = (uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf)) / (ssatof * tautof);
+            const R asytof = so_div(uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf), ssatof * tautof);
             so_deledd<R>(tautob, ssatob, asytob, cz, l2.rr, l2.tt, l2.td);
             so_deledd<R>(tautof, ssatof, asytof, dsm, l2.rs, l2.ts, dum);
         }
@@ -532,7 +542,7 @@ __global__ void __launch_bounds__(256) k_sorad_pass(SoradArgs<R> A, const SoradD
                 const int top = G == 0 ? t / (NM * NL) : (G == 1 ? t / NL : t);
                 const int bot = G == 0 ? t : (G == 1 ? t % (NM * NL) : t % NL);
                 const R a_ = bra[bot], x_ = bxa[bot];
-                const R denm = (R)1. / ((R)1. - rsa[top] * x_);
+                const R denm = so_div((R)1., (R)1. - rsa[top] * x_);
                 const R fdndir = tda[top];
                 const R xx4 = tda[top] * a_, yy = tta[top] - tda[top];
                 const R fdndif = (xx4 * rsa[top] + yy) * denm;
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDe
                     ssatau = sa_ + taurs + (R)1.0e-8;
                 }
                 const R asysto = as_;
-                R tautob = tausto, asytob = asysto / ssatau, ssatob = ssatau / tautob + (R)1.0e-8;
+                R tautob = tausto, asytob = so_div(asysto, ssatau), ssatob = so_div(ssatau, tautob) + (R)1.0e-8;
                 ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
                 R rrt, ttt, tdt, rst, tst, dum;
                 so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
@@ -725,13 +735,13 @@ __global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDe
                     const R tcb = s_cld[(grp * 4 + 0) * K2 + k], tcf = s_cld[(grp * 4 + 1) * K2 + k], asyc = s_cld[(grp * 4 + 2) * K2 + k];
                     const R ssac = uv ? (R)1 : s_cld[(grp * 4 + 3) * K2 + k];
                     tautob = tausto + tcb;
-                    ssatob = (uv ? (ssatau + tcb) : (ssatau + ssac * tcb)) / tautob + (R)1.0e-8;
+                    ssatob = so_div(uv ? (ssatau + tcb) : (ssatau + ssac * tcb), tautob) + (R)1.0e-8;
                     ssatob = ssatob < (R)0.999999 ? ssatob : (R)0.999999;
-                    asytob = (uv ? (asysto + asyc * tcb) : (asysto + asyc * ssac * tcb)) / (ssatob * tautob);
+                    asytob = so_div(uv ? (asysto + asyc * tcb) : (asysto + asyc * ssac * tcb), ssatob * tautob);
                     const R tautof = tausto + tcf;
-                    R ssatof = (uv ? (ssatau + tcf) : (ssatau + ssac * tcf)) / tautof + (R)1.0e-8;
+                    R ssatof = so_div(uv ? (ssatau + tcf) : (ssatau + ssac * tcf), tautof) + (R)1.0e-8;
                     ssatof = ssatof < (R)0.999999 ? ssatof : (R)0.999999;
-                    const R asytof = (uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf)) / (ssatof * tautof);
+                    const R asytof = so_div(uv ? (asysto + asyc * tcf) : (asysto + asyc * ssac * tcf), ssatof * tautof);
                     so_deledd<R>(tautob, ssatob, asytob, cz, rrt, ttt, tdt);
                     so_deledd<R>(tautof, ssatof, asytof, dsm, rst, tst, dum);
                     LY(0, 2, k) = rrt; LY(1, 2, k) = ttt; LY(2, 2, k) = tdt; LY(3, 2, k) = rst; LY(4, 2, k) = tst;
@@ -754,7 +764,7 @@ __global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDe
                     for (int kk = 1; kk <= np; kk++) {
                         const int j = kk < ict ? ih : (kk < icb ? im : is);
                         const R rr = BLY(0, j, kk), tt = BLY(1, j, kk), td = BLY(2, j, kk), rs = BLY(3, j, kk), ts = BLY(4, j, kk);
-                        const R denm = ts / ((R)1. - rsa * rs);
+                        const R denm = so_div(ts, (R)1. - rsa * rs);
                         // (the reference writes tda*rsa*rr in the high and middle groups and tda*rr*rsa in the low one)
                         const R x3 = kk < icb ? tda * rsa * rr : tda * rr * rsa;
                         const R ntta = tda * tt + (x3 + tta - tda) * denm;
@@ -768,7 +778,7 @@ __global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDe
                     for (int kk = np; kk >= 0; kk--) {
                         const int j = kk >= icb ? is : (kk >= ict ? im : ih);
                         const R rr = BLY(0, j, kk), tt = BLY(1, j, kk), td = BLY(2, j, kk), rs = BLY(3, j, kk), ts = BLY(4, j, kk);
-                        const R denm = ts / ((R)1. - rs * rxa);
+                        const R denm = so_div(ts, (R)1. - rs * rxa);
                         const R nrra = rr + (td * rra + (tt - td) * rxa) * denm;
                         rxa = rs + ts * rxa * denm; rra = nrra;
                         BCP(s_, 3, kk) = rra; BCP(s_, 4, kk) = rxa;
@@ -790,7 +800,7 @@ __global__ void __launch_bounds__(256) k_sorad_col(SoradArgs<R> A, const SoradDe
                         const R ct = is == 1 ? cm * ((R)1.0 - cc3) : cm * cc3;
                         const int s_ = ((ih - 1) * 2 + (im - 1)) * 2 + (is - 1);
                         const R tda = CP(s_, 0, k - 1), tta = CP(s_, 1, k - 1), rsa = CP(s_, 2, k - 1), rra = CP(s_, 3, k), rxa = CP(s_, 4, k);
-                        const R denm = (R)1. / ((R)1. - rsa * rxa);      // Eqs. (6.15), (6.16)
+                        const R denm = so_div((R)1., (R)1. - rsa * rxa);      // Eqs. (6.15), (6.16)
                         const R fdndir = tda;
                         const R xx4 = tda * rra, yy = tta - tda;
                         const R fdndif = (xx4 * rsa + yy) * denm;
