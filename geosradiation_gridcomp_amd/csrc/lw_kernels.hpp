@@ -1553,8 +1553,11 @@ constexpr int LW_WIDE_BLOCK = 768;
 #define LW_WIDE_FROM 32768
 #endif
 GR_DEV bool lw_wide_blocks(int nclear, int ncol) { return nclear >= LW_WIDE_FROM && 5 * (long)nclear >= 4 * (long)ncol; }
+// fp64: two wavefronts per SIMD asked for (256 VGPRs: the cloud-free bodies then spill ~100 registers over the 16 bands, the cloudy ones
+// ~860) instead of the 292-404 registers of one wavefront per SIMD: 15.6 -> 14.55 ms, 97 200 clear-sky columns 11.4 -> 9.5 ms.  fp32 stays
+// unconstrained: asked to fit 2 x 208 registers instead of the 240 it takes it loses (5.99 -> 6.40 ms).
 template <typename R, bool CLD, bool DBG, int BLK = 256>
-__global__ void __launch_bounds__(BLK, BLK == LW_WIDE_BLOCK ? 3 : 1) k_lw_bands(LwArgs<R> A, LwDev<R> T)
+__global__ void __launch_bounds__(BLK, BLK == LW_WIDE_BLOCK ? 3 : (sizeof(R) == 8 ? 2 : 1)) k_lw_bands(LwArgs<R> A, LwDev<R> T)
 {
     int bstart, bslot;
     if (!band_block(A.ncol, NB_LW, bstart, bslot)) return;
