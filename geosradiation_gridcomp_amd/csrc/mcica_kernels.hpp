@@ -102,6 +102,14 @@ template <typename R> GR_DEV R corr_length(const R *am, int doy, R alat)
     return (am[0] + am[1] * gr_exp<R>(-(x * x) / (am[3] * am[3]))) * (R)1.e3;
 }
 
+// tables reached through pointers that were read from *Tp / *Sp: loaded as GLOBAL (a generic pointer makes them flat loads with 64-bit lane
+// address arithmetic)
+template <typename T> GR_DEV T mc_ldg(const T *base, int idx)
+{
+    typedef const T __attribute__((address_space(1))) *gT;
+    return ((gT)base)[idx];
+}
+
 // zcw_lookup (cloud_condensate_inhomogeneity.F90:86-124); xcw Fortran (1000,140)
 template <typename R> GR_DEV R zcw_lookup(const R *__restrict__ xcw, R cdf, R sigma)
 {
@@ -112,10 +120,11 @@ template <typename R> GR_DEV R zcw_lookup(const R *__restrict__ xcw, R cdf, R si
     R rind2 = nf_sub(nf_mul((R)40., sigma), (R)3.);
     int ind2 = (int)rind2; ind2 = ind2 > n2 - 1 ? n2 - 1 : ind2; ind2 = ind2 < 1 ? 1 : ind2;
     rind2 = nf_sub(rind2, (R)ind2);
-    const R *p = xcw + (size_t)(ind2 - 1) * n1 + (ind1 - 1);
+    const int o = (ind2 - 1) * n1 + (ind1 - 1);
+    const R p00 = mc_ldg(xcw, o), p01 = mc_ldg(xcw, o + 1), p10 = mc_ldg(xcw, o + n1), p11 = mc_ldg(xcw, o + n1 + 1);
     const R u1 = nf_sub((R)1.0, rind1), u2 = nf_sub((R)1.0, rind2);
-    const R t1 = nf_mul(nf_mul(u1, u2), p[0]), t2 = nf_mul(nf_mul(u1, rind2), p[n1]);
-    const R t3 = nf_mul(nf_mul(rind1, u2), p[1]), t4 = nf_mul(nf_mul(rind1, rind2), p[n1 + 1]);
+    const R t1 = nf_mul(nf_mul(u1, u2), p00), t2 = nf_mul(nf_mul(u1, rind2), p10);
+    const R t3 = nf_mul(nf_mul(rind1, u2), p01), t4 = nf_mul(nf_mul(rind1, rind2), p11);
     return nf_add(nf_add(nf_add(t1, t2), t3), t4);
 }
 
@@ -211,8 +220,9 @@ GR_DEV void lw_cloud_coef(const LwDev<R> &T, int iceflag, int ib, R reice, R rel
         if (index >= nmax) { if (index == nmax) index = nmax - 1; else { err |= 1u << ERR_ICE_RADIUS_HI; index = nmax - 1; } }
         else if (index <= 0) { if (index == 0) index = 1; else { err |= 1u << ERR_ICE_RADIUS_LO; index = 1; } }
         const R fint = factor - (R)index;
-        const R *p = tab + (size_t)(ib - 1) * nmax + (index - 1);
-        kice = p[0] + fint * (p[1] - p[0]);
+        const int o = (ib - 1) * nmax + (index - 1);
+        const R p0 = mc_ldg(tab, o), p1 = mc_ldg(tab, o + 1);
+        kice = p0 + fint * (p1 - p0);
     }
     {
         const R factor = reliq - (R)1.5;
@@ -220,8 +230,9 @@ GR_DEV void lw_cloud_coef(const LwDev<R> &T, int iceflag, int ib, R reice, R rel
         if (index >= 58) { if (index == 58) index = 57; else { err |= 1u << ERR_LIQ_RADIUS_HI; index = 57; } }
         else if (index <= 0) { if (index == 0) index = 1; else { err |= 1u << ERR_LIQ_RADIUS_LO; index = 1; } }
         const R fint = factor - (R)index;
-        const R *p = T.absliq1 + (size_t)(ib - 1) * 58 + (index - 1);
-        kliq = p[0] + fint * (p[1] - p[0]);
+        const int o = (ib - 1) * 58 + (index - 1);
+        const R p0 = mc_ldg(T.absliq1, o), p1 = mc_ldg(T.absliq1, o + 1);
+        kliq = p0 + fint * (p1 - p0);
     }
 }
 
@@ -237,7 +248,7 @@ GR_DEV SwCldCoef<R> sw_cloud_coef(const SwDev<R> &S, int iceflag, int jb, R radi
     const R epsg = (R)1.e-06;
     const int ib = jb - 16;      // 0-based column of the (n,16:29) tables
     SwCldCoef<R> c;
-#define LIN_T(tab, nmax) ((tab)[(size_t)ib * (nmax) + index - 1] + fint * ((tab)[(size_t)ib * (nmax) + index] - (tab)[(size_t)ib * (nmax) + index - 1]))
+#define LIN_T(tab, nmax) (mc_ldg(tab, ib * (nmax) + index - 1) + fint * (mc_ldg(tab, ib * (nmax) + index) - mc_ldg(tab, ib * (nmax) + index - 1)))
     if (iceflag == 1) {
         const int ic = S.icxa[jb - 15] - 1;
         c.extcoice = S.abari[ic] + S.bbari[ic] / radice;
@@ -277,7 +288,7 @@ GR_DEV SwCldCoef<R> sw_cloud_coef(const SwDev<R> &S, int iceflag, int jb, R radi
         index = clampi(index, 1, 57);
         c.extcoliq = LIN_T(S.extliq1, 58);
         c.ssacoliq = LIN_T(S.ssaliq1, 58);
-        if (fint < 0 && c.ssacoliq > (R)1.) c.ssacoliq = S.ssaliq1[(size_t)ib * 58 + index - 1];
+        if (fint < 0 && c.ssacoliq > (R)1.) c.ssacoliq = mc_ldg(S.ssaliq1, ib * 58 + index - 1);
         c.gliq = LIN_T(S.asyliq1, 58);
         c.forwliq = c.gliq * c.gliq;
     }
