@@ -13,14 +13,16 @@ def _kind(rk):
 
 
 @pytest.mark.parametrize("case", [dict(cloudy_frac=0.0, aer=False, trace=True), dict(cloudy_frac=0.7, aer=True, trace=True),
-                                  dict(cloudy_frac=0.7, aer=False, trace=False), dict(cloudy_frac=1.0, aer=True, trace=True, nlay=137)])
+                                  dict(cloudy_frac=0.7, aer=False, trace=False), dict(cloudy_frac=1.0, aer=True, trace=True, nlay=137),
+                                  dict(cloudy_frac=0.8, aer=True, trace=True, nlay=33, ncol=65), dict(cloudy_frac=0.8, aer=True, trace=True, nlay=64, ncol=3)])
 @pytest.mark.parametrize("rk", [8, 4])
 def test_irrad_matches_oracle(gpu_ctx, rk, case):
     from geosradiation_gridcomp_amd import synth
     from oracle import clib
     ctx = gpu_ctx[rk]
     nlay = case.get("nlay", 72)
-    inp = synth.make_columns(48, nlay, start=1234, cloudy_frac=case["cloudy_frac"], aerosol=True)
+    # 33 / 64 layers: fewer levels than lanes, and np + 1 == 65 (one row in the second pass); 65 / 3 columns: ragged blocks of k_chou_prep
+    inp = synth.make_columns(case.get("ncol", 48), nlay, start=1234, cloudy_frac=case["cloudy_frac"], aerosol=True)
     ch = synth.chou_lw_inputs(inp, aerosol=case["aer"])
     g = ctx.irrad_columns(ch, trace=case["trace"])
     o = clib.irrad(ch, _kind(rk), trace=case["trace"])
