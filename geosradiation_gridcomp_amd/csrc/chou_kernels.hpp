@@ -59,11 +59,13 @@ template <> GR_DEV double gr_log10<double>(double x) { return log10(x); }
 // are level-major with the column index fastest: the transposition goes through an LDS tile of 64 columns x 8 (fp64: 4) levels, so that
 // the inputs are read coalesced (lanes = columns) and the records are written in 32-byte runs (lanes = levels x fields).
 template <typename R>
-__global__ void __launch_bounds__(64) k_chou_prep(ChouArgs<R> A)
+__global__ void __launch_bounds__(256) k_chou_prep(ChouArgs<R> A)
 {
     constexpr int CHP_KC = 32 / (int)sizeof(R);      // levels per tile: one 32-byte run per (column, field)
     __shared__ R tile[CF_NFIELD * CHP_KC * 65];
-    const int lane = threadIdx.x, col0 = blockIdx.x * 64, i = col0 + lane;
+    // 256 threads: the four wavefronts share the tile (46 KB: three blocks = twelve wavefronts per CU instead of three), wavefront w forms
+    // the levels w, w + 4, .. of the tile for the block's 64 columns
+    const int lane = threadIdx.x % 64, wv = threadIdx.x / 64, col0 = blockIdx.x * 64, i = col0 + lane;
     const bool act = i < A.m;
     const int np = A.np, ld = A.ld, K1 = np + 1;
     const int ncolb = (A.m - col0) < 64 ? (A.m - col0) : 64;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(64) k_chou_prep(ChouArgs<R> A)
         const int k0 = (int)blockIdx.y * CHP_KC;
         const int nk = (np + 1 - k0) < CHP_KC ? (np + 1 - k0) : CHP_KC;
         if (act) {
-            for (int kk = 0; kk < nk; kk++) {
+            for (int kk = wv; kk < nk; kk += 4) {
                 const int k = k0 + kk;
                 const int ks = k == 0 ? 1 : k;      // layer 0 copies the top layer's state (:432-453)
                 R dp, pa;
@@ -103,11 +105,11 @@ __global__ void __launch_bounds__(64) k_chou_prep(ChouArgs<R> A)
         }
         __syncthreads();
         // write-out: lane -> (field group, level in tile); 8 consecutive lanes write 8 consecutive levels of one field
-        const int kk = lane % CHP_KC, fg = lane / CHP_KC;
+        const int kk = (int)threadIdx.x % CHP_KC, fg = (int)threadIdx.x / CHP_KC;
         if (kk < nk) {
             for (int c = 0; c < ncolb; c++) {
                 R *rec = A.rec + (size_t)(col0 + c) * CF_NFIELD * K1 + k0 + kk;
-                for (int f = fg; f < CF_NFIELD; f += 64 / CHP_KC) rec[(size_t)f * K1] = tile[(f * CHP_KC + kk) * 65 + c];
+                for (int f = fg; f < CF_NFIELD; f += 256 / CHP_KC) rec[(size_t)f * K1] = tile[(f * CHP_KC + kk) * 65 + c];
             }
         }
     }

@@ -2316,7 +2316,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             A.rec = (R *)d_ws_ch; A.part = (R *)(d_ws_ch + al((size_t)nc_max * CF_NFIELD * K1 * sizeof(R)));
             A.err = d_err + 2;
             span_begin(10, st);
-            hipLaunchKernelGGL(k_chou_prep<R>, dim3((unsigned)((nc + 63) / 64), (unsigned)chou_prep_tiles<R>(np)), dim3(64), 0, st, A);
+            hipLaunchKernelGGL(k_chou_prep<R>, dim3((unsigned)((nc + 63) / 64), (unsigned)chou_prep_tiles<R>(np)), dim3(256), 0, st, A);
             span_end(st);
             span_begin(11, st);
             hipLaunchKernelGGL(k_chou_bands<R>, dim3((unsigned)((nc + CH_CPW - 1) / CH_CPW), nband), dim3(64), lds, st, A, (const ChouDev<R> *)d_C);
