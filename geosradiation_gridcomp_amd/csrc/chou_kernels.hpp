@@ -803,28 +803,32 @@ __global__ void __launch_bounds__(64) k_chou_bands(ChouArgs<R> A, const ChouDev<
 // column and band - the sums go through an LDS tile [level][column], lanes = columns write 256-byte rows.  (One wavefront per column with
 // lanes = levels wrote 4 bytes per lane at a stride of ld: 65 M write transactions per 100 000 columns, 1.40 ms.)
 // ---------------------------------------------------------------------------------------------------
+constexpr int CHR_KMAX = 96;            // levels per LDS tile (24 / 49 KB): a 72-layer column in one piece, deeper columns in chunks
 template <typename R>
 __global__ void __launch_bounds__(256) k_chou_reduce(ChouArgs<R> A, ChouOut<R> O, int nband)
 {
-    extern __shared__ __align__(16) unsigned char chr_smem[];      // [np + 1][65] reals
-    R *tile = reinterpret_cast<R *>(chr_smem);
+    __shared__ R tile[CHR_KMAX * 65];
     const int col0 = (int)blockIdx.x * 64, q = (int)blockIdx.y, w = (int)threadIdx.x / 64, lane = (int)threadIdx.x % 64;
     const int np = A.np, K2 = np + 2, ld = A.ld, nk = np + 1;
     const int ncolb = (A.m - col0) < 64 ? (A.m - col0) : 64;
     // wavefront w: columns 16 w .. 16 w + 15 of the block
     const int c_lo = 16 * w, c_n = ncolb - c_lo < 16 ? (ncolb - c_lo < 0 ? 0 : ncolb - c_lo) : 16;
-    for (int t = lane; t < c_n * nk; t += 64) {
-        const int c = c_lo + t / nk, k = 1 + t % nk;
-        const R *p = A.part + (size_t)(col0 + c) * CH_NB * CH_NKIND * K2 + (size_t)q * K2 + k;
-        R s = 0;
-        for (int b = 0; b < nband; b++) s = s + p[(size_t)b * CH_NKIND * K2];
-        tile[(k - 1) * 65 + c] = s;
-    }
-    __syncthreads();
     R *o = q == 0 ? O.flxu : (q == 1 ? O.flcu : (q == 2 ? O.flau : (q == 3 ? O.flxau : (q == 4 ? O.flxd : (q == 5 ? O.flcd : (q == 6 ? O.flad :
            (q == 7 ? O.flxad : O.dfdts)))))));
-    if (lane < ncolb)
-        for (int k = w; k < nk; k += 4) o[(size_t)k * ld + col0 + lane] = tile[k * 65 + lane];
+    for (int k0 = 0; k0 < nk; k0 += CHR_KMAX) {          // levels k0 + 1 .. k0 + nc of 1 .. np + 1
+        const int nc = (nk - k0) < CHR_KMAX ? (nk - k0) : CHR_KMAX;
+        for (int t = lane; t < c_n * nc; t += 64) {
+            const int c = c_lo + t / nc, kk = t % nc;
+            const R *p = A.part + (size_t)(col0 + c) * CH_NB * CH_NKIND * K2 + (size_t)q * K2 + k0 + 1 + kk;
+            R s = 0;
+            for (int b = 0; b < nband; b++) s = s + p[(size_t)b * CH_NKIND * K2];
+            tile[kk * 65 + c] = s;
+        }
+        __syncthreads();
+        if (lane < ncolb)
+            for (int kk = w; kk < nc; kk += 4) o[(size_t)(k0 + kk) * ld + col0 + lane] = tile[kk * 65 + lane];
+        __syncthreads();
+    }
     if (q == 0 && (int)threadIdx.x < ncolb) {
         const R *p0 = A.part + (size_t)(col0 + (int)threadIdx.x) * CH_NB * CH_NKIND * K2;
         R s = 0;

@@ -2325,7 +2325,7 @@ template <typename R> struct Ctx : geosrad_ctx {
             auto Q = [&](int k) { return (R *)out[k] + c0; };
             O.flxu = Q(CO_FLXU); O.flcu = Q(CO_FLCU); O.flau = Q(CO_FLAU); O.flxau = Q(CO_FLXAU); O.flxd = Q(CO_FLXD); O.flcd = Q(CO_FLCD);
             O.flad = Q(CO_FLAD); O.flxad = Q(CO_FLXAD); O.dfdts = Q(CO_DFDTS); O.sfcem = Q(CO_SFCEM);
-            hipLaunchKernelGGL(k_chou_reduce<R>, dim3((unsigned)((nc + 63) / 64), 9), dim3(256), (size_t)(np + 1) * 65 * sizeof(R), st, A, O, nband);
+            hipLaunchKernelGGL(k_chou_reduce<R>, dim3((unsigned)((nc + 63) / 64), 9), dim3(256), 0, st, A, O, nband);
             if (!trace)      // band 10 of taudiag stays zero (the reference zeroes the array and never reaches band 10)
                 for (int k = 0; k < np; k++)
                     HIPCHK(hipMemsetAsync((R *)out[CO_TAUDIAG] + ((size_t)9 * np + k) * m + c0, 0, (size_t)nc * sizeof(R), st));
