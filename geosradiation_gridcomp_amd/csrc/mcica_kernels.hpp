@@ -399,8 +399,10 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
     // plane layout (see band_body): band-major, then [layer][g-in-band][column]
     const int bg0 = MODE == 0 ? lw_band_g0(ib) : (MODE == 2 ? sw_band_g0(ib) : 0);
     const int bng = MODE == 0 ? lw_band_ng(ib) : (MODE == 2 ? sw_band_ng(ib) : 0);
-    const size_t tb0 = PLANES ? (size_t)bg0 * nlay * n + (size_t)(s0 - bg0) * n + col : 0;     // + s*n + il*tbs
-    const size_t tbs = PLANES ? (size_t)bng * n : 0;
+    // cell (band ib, layer il, sub-column s0 + s, column) = wave-uniform start of (band, first sub-column of the segment) + a 32-bit lane part
+    // (a band's planes are nlay x ng x ncol reals: < 4 GB for every chunk the context launches)
+    const size_t tbu = PLANES ? (size_t)bg0 * nlay * n + (size_t)(s0 - bg0) * n : 0;
+    const uint32_t tbs = PLANES ? (uint32_t)bng * (uint32_t)n : 0u;
 
     R cprev[MC_S], c3prev[MC_S], cs_lo[MC_S], cs_mid[MC_S], cs_hi[MC_S];
 #pragma unroll
@@ -498,15 +500,15 @@ __global__ void __launch_bounds__(64) k_mcica(McArgs<R> M, McPlan P, const LwDev
                         if (cl > 0) tau = tau + cl * kliq;
                         err |= kerr;
                     }
-                    M.taucmc[tb0 + (size_t)s * n + (size_t)il * tbs] = tau;
+                    stg(M.taucmc + tbu, ((uint32_t)col + (uint32_t)s * (uint32_t)n + (uint32_t)il * tbs) * (uint32_t)sizeof(R), tau);
                     if (tau > 0) M.laycloudy[w] = 1;
                 }
             } else if (MODE == 2) {
                 R taor = 0, tauc = 0, ssac = 1, asmc = 0;
                 if (c) sw_cloud_optics<R>(swc, M.iceflg, ci, cl, taor, tauc, ssac, asmc);
                 if (cf > 0) {
-                    const size_t oc = tb0 + (size_t)s * n + (size_t)il * tbs;
-                    M.taucmc[oc] = tauc; M.ssacmc[oc] = ssac; M.asmcmc[oc] = asmc;
+                    const uint32_t oc = ((uint32_t)col + (uint32_t)s * (uint32_t)n + (uint32_t)il * tbs) * (uint32_t)sizeof(R);
+                    stg(M.taucmc + tbu, oc, tauc); stg(M.ssacmc + tbu, oc, ssac); stg(M.asmcmc + tbu, oc, asmc);
                     if (tauc > 0) M.laycloudy[w] = 1;
                 }
                 // super-layer sums of the un-scaled tau for the PAR diagnostics (SW/rrtmg_sw_spcvmc.F90:760-800)
