@@ -148,6 +148,15 @@ template <typename T> GR_DEV T ch_ldg(const T *base, uint32_t byteoff)
     return *(gT)((gchar)base + byteoff);
 }
 
+// exponentials / powers of the per-layer absorber terms (P0, P1 of the band body) in the fp32 instantiation: v_exp_f32 / v_log_f32 (1 ulp on
+// the base-2 functions; the argument scaling adds |x| 2^-24 relative) instead of the library's expf / powf (15-60 instructions each)
+template <typename R> GR_DEV R ch_exp(R x) { return gr_exp<R>(x); }
+template <typename R> GR_DEV R ch_pow(R x, R y) { return gr_pow<R>(x, y); }
+#ifndef CH_EXACT_EXP
+template <> GR_DEV float ch_exp<float>(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+template <> GR_DEV float ch_pow<float>(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#endif
+
 // tablup (:1887-2011).  The 14 table entries around the cell (ip, iw) stay in registers (`tv`) and are gathered again only when the lane's
 // cell changes: along a row the accumulated amount s1 and its mean pressure move slowly on the tables' logarithmic axes, and 14 gathers of
 // 64 different addresses per step were what made the five table bands 1.7 x as slow as the k-distribution ones (profiles/r04_README.md)
@@ -334,8 +343,8 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
         for (int j = 1; j <= ch_nex(IBN); j++) EX(k, j) = 0;
         // water vapour line exponentials (h2oexps :1379-1458)
         if (!B.h2otable && !B.b10bnd) {
-            R xh = dh2o * gr_pow<R>(pa / (R)500., T.pm[ibn - 1]) * ((R)1. + (T.aw[ibn - 1] + T.bw[ibn - 1] * dt) * dt);
-            R e = gr_exp<R>(-xh * T.xkw[ibn - 1]);
+            R xh = dh2o * ch_pow<R>(pa / (R)500., T.pm[ibn - 1]) * ((R)1. + (T.aw[ibn - 1] + T.bw[ibn - 1] * dt) * dt);
+            R e = ch_exp<R>(-xh * T.xkw[ibn - 1]);
             EX(k, B.h2o_s) = e;
             const int mwv = T.mw[ibn - 1];
             for (int ik = 2; ik <= 6; ik++) {
@@ -347,7 +356,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             }
         }
         if (B.conbnd) {       // conexps :1464-1510
-            const R e = gr_exp<R>(-dcont * T.xke[ibn - 1]);
+            const R e = ch_exp<R>(-dcont * T.xke[ibn - 1]);
             EX(k, B.con_s) = e;
             if (ibn == 3) { const R e2 = e * e; EX(k, B.con_s + 1) = e2; EX(k, B.con_s + 2) = e2 * e2; }
         }
@@ -356,14 +365,14 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                 const R dn2o = rec[CF_DN2O * K1 + k];
                 if (ibn == 6) {
                     R xc = dn2o * ((R)1. + ((R)1.9297e-3 + (R)4.3750e-6 * dt) * dt);
-                    const R e = gr_exp<R>(-xc * (R)6.31582e-2);
+                    const R e = ch_exp<R>(-xc * (R)6.31582e-2);
                     EX(k, B.n2o_s) = e;
                     xc = e * e * e;
                     const R xc1 = xc * xc, xc2 = xc1 * xc1;
                     EX(k, B.n2o_s + 1) = xc * xc1 * xc2;
                 } else {
-                    R xc = dn2o * gr_pow<R>(pa / (R)500.0, (R)0.48) * ((R)1. + ((R)1.3804e-3 + (R)7.4838e-6 * dt) * dt);
-                    R e = gr_exp<R>(-xc * (R)5.35779e-2);
+                    R xc = dn2o * ch_pow<R>(pa / (R)500.0, (R)0.48) * ((R)1. + ((R)1.3804e-3 + (R)7.4838e-6 * dt) * dt);
+                    R e = ch_exp<R>(-xc * (R)5.35779e-2);
                     EX(k, B.n2o_s) = e;
                     for (int q = 1; q <= 3; q++) { xc = e * e; xc = xc * xc; e = xc * xc; EX(k, B.n2o_s + q) = e; }
                 }
@@ -371,10 +380,10 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                 const R dch4 = rec[CF_DCH4 * K1 + k];
                 if (ibn == 6) {
                     const R xc = dch4 * ((R)1. + ((R)1.7007e-2 + (R)1.5826e-4 * dt) * dt);
-                    EX(k, B.ch4_s) = gr_exp<R>(-xc * (R)5.80708e-3);
+                    EX(k, B.ch4_s) = ch_exp<R>(-xc * (R)5.80708e-3);
                 } else {
-                    R xc = dch4 * gr_pow<R>(pa / (R)500.0, (R)0.65) * ((R)1. + ((R)5.9590e-4 - (R)2.2931e-6 * dt) * dt);
-                    R e = gr_exp<R>(-xc * (R)6.29247e-2);
+                    R xc = dch4 * ch_pow<R>(pa / (R)500.0, (R)0.65) * ((R)1. + ((R)5.9590e-4 - (R)2.2931e-6 * dt) * dt);
+                    R e = ch_exp<R>(-xc * (R)6.29247e-2);
                     EX(k, B.ch4_s) = e;
                     for (int q = 1; q <= 3; q++) { xc = e * e * e; xc = xc * xc; e = xc * xc; EX(k, B.ch4_s + q) = e; }
                 }
@@ -382,7 +391,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             if (B.combnd) {   // comexps :1656-1707
                 R xc = ibn == 4 ? dco2 * ((R)1. + ((R)3.5775e-2 + (R)4.0447e-4 * dt) * dt)
                                 : dco2 * ((R)1. + ((R)3.4268e-2 + (R)3.7401e-4 * dt) * dt);
-                R e = gr_exp<R>(-xc * (R)1.922e-7);
+                R e = ch_exp<R>(-xc * (R)1.922e-7);
                 EX(k, B.com_s) = e;
                 for (int ik = 2; ik <= 6; ik++) { xc = e * e; xc = xc * xc; e = xc * e; EX(k, B.com_s + ik - 1) = e; }
             }
@@ -390,28 +399,28 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             if (B.f11bnd) {
                 const R d = rec[CF_DF11 * K1 + k];
                 const R xf = ibn == 4 ? d * ((R)1. + ((R)1.26610e-3 + (R)3.55940e-6 * dt) * dt) : d * ((R)1. + ((R)8.19370e-4 + (R)4.67810e-6 * dt) * dt);
-                EX(k, B.f11_s) = gr_exp<R>(-xf * (ibn == 4 ? (R)1.89736e+1 : (R)1.01487e+1));
+                EX(k, B.f11_s) = ch_exp<R>(-xf * (ibn == 4 ? (R)1.89736e+1 : (R)1.01487e+1));
             }
             if (B.f12bnd) {
                 const R d = rec[CF_DF12 * K1 + k];
                 const R xf = ibn == 4 ? d * ((R)1. + ((R)8.77370e-4 + (R)-5.88440e-6 * dt) * dt) : d * ((R)1. + ((R)8.62000e-4 + (R)-4.22500e-6 * dt) * dt);
-                EX(k, B.f12_s) = gr_exp<R>(-xf * (ibn == 4 ? (R)1.58104e+1 : (R)3.70107e+1));
+                EX(k, B.f12_s) = ch_exp<R>(-xf * (ibn == 4 ? (R)1.58104e+1 : (R)3.70107e+1));
                 const R d2 = rec[CF_DF22 * K1 + k];
                 const R xg = ibn == 4 ? d2 * ((R)1. + ((R)9.65130e-4 + (R)1.31280e-5 * dt) * dt) : d2 * ((R)1. + ((R)-3.00010e-5 + (R)5.25010e-7 * dt) * dt);
-                EX(k, B.f22_s) = gr_exp<R>(-xg * (ibn == 4 ? (R)6.18536e+0 : (R)3.27912e+1));
+                EX(k, B.f22_s) = ch_exp<R>(-xg * (ibn == 4 ? (R)6.18536e+0 : (R)3.27912e+1));
             }
             if (B.b10bnd) {   // b10exps :1769-1884
                 R xx = dh2o * (pa / (R)500.0) * ((R)1. + ((R)0.0149 + (R)6.20e-5 * dt) * dt);
-                R e = gr_exp<R>(-xx * (R)0.10624);
+                R e = ch_exp<R>(-xx * (R)0.10624);
                 EX(k, B.h2o_s) = e;
                 for (int q = 1; q <= 4; q++) { xx = e * e; xx = xx * xx; e = xx * xx; EX(k, B.h2o_s + q) = e; }
-                EX(k, B.con_s) = gr_exp<R>(-dcont * (R)109.0);
-                xx = dco2 * gr_pow<R>(pa / (R)300.0, (R)0.5) * ((R)1. + ((R)0.0179 + (R)1.02e-4 * dt) * dt);
-                e = gr_exp<R>(-xx * (R)2.656e-5);
+                EX(k, B.con_s) = ch_exp<R>(-dcont * (R)109.0);
+                xx = dco2 * ch_pow<R>(pa / (R)300.0, (R)0.5) * ((R)1. + ((R)0.0179 + (R)1.02e-4 * dt) * dt);
+                e = ch_exp<R>(-xx * (R)2.656e-5);
                 EX(k, B.co2_s) = e;
                 for (int q = 1; q <= 5; q++) { xx = e * e; xx = xx * xx; e = xx * xx; EX(k, B.co2_s + q) = e; }
                 xx = rec[CF_DN2O * K1 + k] * ((R)1. + ((R)1.4476e-3 + (R)3.6656e-6 * dt) * dt);
-                e = gr_exp<R>(-xx * (R)0.25238);
+                e = ch_exp<R>(-xx * (R)0.25238);
                 EX(k, B.n2o_s) = e;
                 xx = e * e;
                 R xx1 = xx * xx; xx1 = xx1 * xx1;
@@ -427,10 +436,10 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
             const R wp = (rec[CF_DPPA * K1 + k] * (R)1.0e3) / (R)9.80665;        // MAPL_GRAV
             const R r1 = rec[CF_REFF1 * K1 + k], r2 = rec[CF_REFF2 * K1 + k], r4 = rec[CF_REFF4 * K1 + k];
             const R rs = r4 < (R)112.0 ? r4 : (R)112.0;
-            const R tau1 = r1 <= 0 ? (R)0 : (wp * rec[CF_CWC1 * K1 + k]) * (aib[0] + aib[1] / gr_pow<R>(r1, aib[2]));
+            const R tau1 = r1 <= 0 ? (R)0 : (wp * rec[CF_CWC1 * K1 + k]) * (aib[0] + aib[1] / ch_pow<R>(r1, aib[2]));
             const R tau2 = (wp * rec[CF_CWC2 * K1 + k]) * (awb[0] + (awb[1] + (awb[2] + awb[3] * r2) * r2) * r2);
             const R tau3 = (R)0.00307 * (wp * rec[CF_CWC3 * K1 + k]);
-            const R tau4 = rs <= 0 ? (R)0 : (wp * rec[CF_CWC4 * K1 + k]) * (aib[0] + aib[1] / gr_pow<R>(rs, aib[2]));
+            const R tau4 = rs <= 0 ? (R)0 : (wp * rec[CF_CWC4 * K1 + k]) * (aib[0] + aib[1] / ch_pow<R>(rs, aib[2]));
             if (valid) A.taudiag[((size_t)(ibn - 1) * np + (k - 1)) * ld + i] = tau1 + tau2 + tau3 + tau4;
             R tauc = tau1 + tau2 + tau3 + tau4;
             const R fc = rec[CF_FCLD * K1 + k];
@@ -448,7 +457,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                 const R ff = (R)0.5 + ((R)0.3739 + ((R)0.0076 + (R)0.1185 * gg) * gg) * gg;
                 R sc = (R)1. - ww * ff; sc = sc > 0 ? sc : (R)0;
                 tauc = sc * tauc;
-                const R tcl = gr_exp<R>((R)-1.66 * tauc);
+                const R tcl = ch_exp<R>((R)-1.66 * tauc);
                 tcld[k] = tcl; enn[k] = fc * ((R)1.0 - tcl);
             } else { tcld[k] = 1; enn[k] = 0; }
             R tae = 1;
@@ -464,7 +473,7 @@ GR_DEV void chou_band_body(const ChouArgs<R> &A, const ChouDev<R> &T, unsigned c
                         ta_ = ta_ * ((R)1. - ss * ff);
                         if (valid) { A.asya[j] = as; A.ssaa[j] = ss; A.taua[j] = ta_; }
                     }
-                    tae = gr_exp<R>((R)-1.66 * ta_);
+                    tae = ch_exp<R>((R)-1.66 * ta_);
                 }
             }
             taer[k] = tae;
