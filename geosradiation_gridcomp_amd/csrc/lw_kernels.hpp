@@ -1579,7 +1579,11 @@ __global__ void __launch_bounds__(BLK, BLK == LW_WIDE_BLOCK ? 3 : (sizeof(R) == 
         R2 *const l = reinterpret_cast<R2 *>(lw_lds);
         for (int i = threadIdx.x; i <= NTBL; i += (int)blockDim.x) l[i] = ldg(T.lut, (uint32_t)i * (uint32_t)sizeof(R2));
         {   // the band's small tables, [rows][S] each, in the order selfref (10), forref (4), fracrefa, fracrefb
+#ifdef LW_ONLY_BAND
+            const int ib = LW_ONLY_BAND, S = pad4(lw_band_ng(ib));        // timing experiment: every block runs this band's body
+#else
             const int ib = LW_BAND_ORDER[bslot], S = pad4(lw_band_ng(ib));
+#endif
             R *const sm = reinterpret_cast<R *>(lw_lds + LW_LDS_LUT);
             const BandTab<R> &B = T.b[ib];
             const int na = lw_nfraca(ib), nb = lw_nfracb(ib);
@@ -1595,7 +1599,11 @@ __global__ void __launch_bounds__(BLK, BLK == LW_WIDE_BLOCK ? 3 : (sizeof(R) == 
     const int col = bstart + threadIdx.x;
     if (col >= A.ncol) return;
     if (!DBG && (CLD ? col < nclear : col >= nclear)) return;
+#ifdef LW_ONLY_BAND
+    switch (LW_ONLY_BAND) {
+#else
     switch (LW_BAND_ORDER[bslot]) {
+#endif
         case 1: band_body<R, Band1, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
         case 2: band_body<R, Band2, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
         case 3: band_body<R, Band3, CLD, DBG, BLK == 256>(A, T, col, nclear, luts); break;
